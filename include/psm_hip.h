@@ -1,0 +1,208 @@
+/*
+ * psm_hip.h -- C ABI of the MI355X-native path-tracing core (libpsm_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of EngineWorld/prismarine-core: the three
+ * shader directories ShadersSDK/{radix,hlbvh,raytracing} and the host orchestration in
+ * Include/Prismarine/{Radix.hpp,TriangleHierarchy.inl,Pipeline.inl}.  Where the reference passes
+ * buffers by SSBO binding number and launches by glDispatchCompute, this ABI passes plain
+ * pointers / handles and sizes.  Every entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative psm_status otherwise; nothing throws
+ *   - one psm_ctx per GPU, one in-order HIP stream per context (the reference's single GL
+ *     context + barrier after every dispatch, Utils.hpp:167-171); all calls are asynchronous
+ *     on that stream unless the doc says "synchronises"
+ *   - matrices are row-major float[16] / double[16]:  (M v)[i] = sum_j M[4*i+j] v[j]
+ *   - "device pointer" = hipMalloc'ed memory on the context's device
+ *   - there is NO CPU fallback: without a gfx950 device psm_ctx_create fails
+ */
+#ifndef PSM_HIP_H
+#define PSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PSM_OK = 0,
+    PSM_ERR_INVALID = -1,     /* bad argument / handle */
+    PSM_ERR_HIP = -2,         /* a HIP runtime call failed; see psm_last_error */
+    PSM_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    PSM_ERR_CAPACITY = -4,    /* exceeds an allocated capacity */
+    PSM_ERR_STATE = -5        /* call order violated (e.g. traverse before build) */
+} psm_status;
+
+typedef struct psm_ctx psm_ctx;
+typedef struct psm_bvh psm_bvh;
+typedef struct psm_rt psm_rt;
+
+/* ---------------------------------------------------------------------------------------------
+ * context + buffers: replaces the GL utility shim, Include/Prismarine/Utils.hpp:140-178
+ * (allocateBuffer<T>, glNamedBufferSubData, glGetNamedBufferSubData, dispatch)
+ * ------------------------------------------------------------------------------------------- */
+int psm_ctx_create(int device, psm_ctx** out);
+int psm_ctx_destroy(psm_ctx* ctx);
+int psm_ctx_sync(psm_ctx* ctx);                 /* synchronises (glFinish, Viewer.cpp:314) */
+void* psm_ctx_stream(psm_ctx* ctx);             /* the hipStream_t every launch goes to */
+const char* psm_last_error(psm_ctx* ctx);
+int psm_device_count(void);
+
+/* handle = the GLuint buffer name the header layer passes around (Utils.hpp:140-150) */
+int psm_buf_alloc(psm_ctx* ctx, size_t bytes, uint32_t* handle);
+int psm_buf_free(psm_ctx* ctx, uint32_t handle);
+int psm_buf_upload(psm_ctx* ctx, uint32_t handle, size_t offset, const void* src, size_t bytes);
+int psm_buf_download(psm_ctx* ctx, uint32_t handle, size_t offset, void* dst, size_t bytes); /* synchronises */
+int psm_buf_ptr(psm_ctx* ctx, uint32_t handle, void** dev_ptr, size_t* bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * psm::RadixSort::sort, Include/Prismarine/Radix.hpp:47-74 (+ radix/{histogram,pfx-work,
+ * permute}.comp): stable ascending sort of (u64 key, u32 value) pairs, result in place.
+ * The reference caps n at 2 Mi (Radix.hpp:34-35); here n is bounded by memory only.
+ * ------------------------------------------------------------------------------------------- */
+int psm_sort_u64_u32(psm_ctx* ctx, uint32_t keys_handle, uint32_t vals_handle, uint32_t n);
+int psm_sort_u64_u32_dev(psm_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * psm::TriangleHierarchy, Include/Prismarine/TriangleHierarchy.{hpp,inl}
+ * ------------------------------------------------------------------------------------------- */
+/* allocate(count), TriangleHierarchy.inl:77-112 (capacity = 2*count there; here exactly max_tris) */
+int psm_bvh_create(psm_ctx* ctx, size_t max_tris, psm_bvh** out);
+int psm_bvh_destroy(psm_bvh* bvh);
+/* clearTribuffer(), TriangleHierarchy.inl:161-166 */
+int psm_bvh_clear(psm_bvh* bvh);
+/* loadMesh(), TriangleHierarchy.inl:173-192 + vertex/loader.comp:32-152 reduced to its result:
+ * appends n world-space triangles. positions: 9 floats/triangle; normals: 9 floats/triangle as
+ * stored in the normal mosaic (may be NULL -> face normals, loader.comp:119-128); mats: per
+ * triangle material id (NULL -> material_id for all). Host pointers. */
+int psm_bvh_load_triangles(psm_bvh* bvh, const float* positions, const float* normals,
+                           const int32_t* mats, size_t n, int32_t material_id);
+/* build(optimization), TriangleHierarchy.inl:206-329: bounds -> fit transform -> Morton+leaves
+ * -> radix sort -> emit -> boxes. opt may be NULL (identity). No host synchronisation. */
+int psm_bvh_build(psm_bvh* bvh, const double* opt);
+
+typedef struct {
+    uint32_t triangle_count; /* uploaded triangles (tcounter, TriangleHierarchy.inl:209) */
+    uint32_t leaf_count;     /* non-degenerate triangles (aabbCounter, :280) */
+    int32_t root;            /* root link: >=0 split-gap id of the root, -1 = no traversable tree */
+    float transform[16];     /* geometryUniform.transform as M (row-major, not transposed) */
+    float bounds_min[4], bounds_max[4]; /* minmax.comp result after the -+1e-5 pad */
+} psm_bvh_info;
+int psm_bvh_get_info(psm_bvh* bvh, psm_bvh_info* info); /* synchronises */
+
+/* Stage-level entry points (each = one reference dispatch group); psm_bvh_build runs them in
+ * order. Exposed so parity tests can check every stage against the oracle. */
+int psm_bvh_stage_bounds(psm_bvh* bvh, const double* opt);  /* minmax.comp + host reduce + fit */
+int psm_bvh_stage_morton(psm_bvh* bvh);                     /* aabbmaker.comp */
+int psm_bvh_stage_sort(psm_bvh* bvh);                       /* Radix.hpp:47-74 */
+int psm_bvh_stage_emit(psm_bvh* bvh);                       /* build-new + child-link + refit */
+
+/* Debug / parity downloads (synchronise). `what`: */
+enum {
+    PSM_BVH_KEYS = 0,      /* uint64[leaf_count]   sorted Morton codes (unsorted before stage_sort) */
+    PSM_BVH_INDICES = 1,   /* uint32[leaf_count]   MortonIndices */
+    PSM_BVH_LEAF_BOX = 2,  /* uint32[4][leaf_count] leaf record boxes (packHalf2 mn.xy mn.zw mx.xy mx.zw), slot order */
+    PSM_BVH_LEAF_TRI = 3,  /* int32[leaf_count]    leaf record triangle ids, slot order */
+    PSM_BVH_PAIR_BOX = 4,  /* uint32[8][leaf_count-1] child boxes of internal node (split gap) s: left, right */
+    PSM_BVH_LINK = 5,      /* int32[2][leaf_count-1]  child links: >=0 internal gap id, <0 leaf: ~triangle */
+    PSM_BVH_RANGE = 6,     /* int32[2][leaf_count-1]  sorted-leaf range [first,last] of internal node s */
+    PSM_BVH_SORTED_TRI = 7 /* int32[leaf_count]    triangle id of the k-th sorted leaf */
+};
+int psm_bvh_download(psm_bvh* bvh, int what, void* dst, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * psm::Pipeline, Include/Prismarine/Pipeline.{hpp,inl}
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float lightVector[4]; /* xyz direction, w distance   (Pipeline.inl:93-98) */
+    float lightColor[4];  /* rgb, w radius */
+    float lightOffset[4];
+    float lightAmbient[4];
+} psm_light; /* LightUniformStruct, Structs.hpp:165-170 */
+
+typedef struct {
+    float diffuse[4], specular[4], transmission[4], emissive[4];
+    float ior, roughness, alpharef, unk0f;
+    uint32_t diffusePart, specularPart, bumpPart, emissivePart;
+    int32_t flags, alphafunc, binding, bitfield;
+    int32_t iModifiers0[4];
+} psm_material; /* VirtualMaterial, Structs.hpp:240-262 (128 bytes) */
+
+int psm_rt_create(psm_ctx* ctx, psm_rt** out);
+int psm_rt_destroy(psm_rt* rt);
+/* resizeBuffers(w,h), Pipeline.inl:174-214: ray grid; ray limit = min(4*w*h, 4096*4096) */
+int psm_rt_resize_buffers(psm_rt* rt, uint32_t width, uint32_t height);
+/* resize(w,h), Pipeline.inl:138-172: display image (presampled / filtered) */
+int psm_rt_resize(psm_rt* rt, uint32_t display_width, uint32_t display_height);
+/* tile sharding (new): this context owns ray-grid rows [y0,y1). Default all rows. */
+int psm_rt_set_tile(psm_rt* rt, uint32_t y0, uint32_t y1);
+/* lightColor/lightVector/lightOffset/lightAmbient + setLightCount, Pipeline.hpp:103-121 */
+int psm_rt_set_lights(psm_rt* rt, const psm_light* lights, uint32_t count);
+/* environment: constant colour (the equirect skybox of setSkybox() is a later row) */
+int psm_rt_set_sky(psm_rt* rt, const float rgba[4]);
+/* MaterialSet::loadToVGA + bindWithContext, MaterialSet.inl:13-23 (host pointer, copied) */
+int psm_rt_set_materials(psm_rt* rt, const psm_material* mats, uint32_t count, int32_t load_offset);
+/* camera(persp, frontSide), Pipeline.inl:279-296 -> camera.comp. camInv/projInv are the inverse
+ * matrices the reference uploads (:283-284); `time` replaces the host rand() (:282). Clears the
+ * ray counters (clearRays) and this frame's texel sums. */
+int psm_rt_camera(psm_rt* rt, const float cam_inv[16], const float proj_inv[16], uint32_t time);
+/* raycountCache after reloadQueuedRays, Pipeline.inl:325-359 (the >=32 rule of getRayCount,
+ * :459-461, is applied by the header layer). Synchronises. */
+int psm_rt_ray_count(psm_rt* rt, int32_t* count);
+/* intersection(obj), Pipeline.inl:385-405 -> directTraverse.comp */
+int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
+/* applyMaterials + shade, Pipeline.inl:407-436 -> surface.comp + rayshading.comp, then the
+ * queue hand-off of reloadQueuedRays (:325-359). `time` replaces rand() (:426). */
+int psm_rt_shade(psm_rt* rt, psm_bvh* bvh, uint32_t time);
+/* sample(), Pipeline.inl:251-277 -> sampler.comp, deinterlace.comp, filter.comp */
+int psm_rt_sample(psm_rt* rt);
+/* clearSampler(), Pipeline.inl:314-322 (also zeroes presampled: the GL texture starts undefined) */
+int psm_rt_clear_sampler(psm_rt* rt);
+/* snapHdr()/snapRawHdr(), Pipeline.inl:439-456: display_w*display_h*4 floats to host. Synchronises. */
+int psm_rt_snap(psm_rt* rt, float* rgba, int raw);
+
+/* per-texel frame radiance (sum rgb, deposit count) for the tile gather:
+ * copy rows [y0,y1) to / from a device pointer (width*(y1-y0)*4 floats). */
+int psm_rt_get_texels_dev(psm_rt* rt, uint32_t y0, uint32_t y1, float* d_dst);
+int psm_rt_set_texels_dev(psm_rt* rt, uint32_t y0, uint32_t y1, const float* d_src);
+
+/* Debug / parity downloads of the current ray queue and last traversal result (synchronise). */
+typedef struct {
+    float origin[3], direct[3], color[3];
+    int32_t bitfield, texel;
+    uint32_t pkey;
+} psm_ray;
+typedef struct {
+    float u, v, t;
+    int32_t tri;
+} psm_hit;
+int psm_rt_download_rays(psm_rt* rt, psm_ray* dst, uint32_t max_rays, uint32_t* count);
+/* hits: max_rays*8 entries (chain of ray i at [8*i, 8*i+counts[i])) */
+int psm_rt_download_hits(psm_rt* rt, psm_hit* hits, int32_t* counts, uint32_t max_rays);
+/* replace the current ray queue (host pointer) -- lets tests drive traverse with chosen rays */
+int psm_rt_upload_rays(psm_rt* rt, const psm_ray* src, uint32_t count);
+int psm_rt_download_texels(psm_rt* rt, float* sum_rgba, float* coord_xy, int32_t* flags);
+
+/* ---------------------------------------------------------------------------------------------
+ * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t rays_traced;     /* R: rays handed to traverse since reset */
+    uint64_t node_visits;     /* V (only counted while counting is enabled) */
+    uint64_t tri_tests;       /* T */
+    uint64_t stack_drops, iter_caps, baked_drops, chain_pool_drops, ray_limit_drops;
+    uint32_t traverse_launches;
+    float traverse_ms;        /* sum of HIP-event durations of the traverse kernel */
+    float build_ms, sort_ms, shade_ms, camera_ms, sample_ms;
+    uint32_t rounds;
+} psm_stats;
+int psm_stats_enable(psm_ctx* ctx, int timing, int counting);
+int psm_stats_reset(psm_ctx* ctx);
+int psm_stats_get(psm_ctx* ctx, psm_stats* out); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSM_HIP_H */

@@ -1,0 +1,291 @@
+"""ctypes binding of the CPU oracle (oracle/libpsm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libpsm_oracle.so")
+
+PZERO = np.float32(0.0005)
+INFINITY = np.float32(10000.0)
+BAKED_CAP = 8
+
+NODE_DT = np.dtype([("box", "<u4", 4), ("pdata", "<i4", 4)])
+HIT_DT = np.dtype([("u", "<f4"), ("v", "<f4"), ("t", "<f4"), ("tri", "<i4")])
+RAY_DT = np.dtype([("origin", "<f4", 3), ("direct", "<f4", 3), ("color", "<f4", 3),
+                   ("bitfield", "<i4"), ("texel", "<i4"), ("pkey", "<u4")])
+LIGHT_DT = np.dtype([("lightVector", "<f4", 4), ("lightColor", "<f4", 4),
+                     ("lightOffset", "<f4", 4), ("lightAmbient", "<f4", 4)])
+
+
+class Counters(C.Structure):
+    _fields_ = [("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("stack_drops", C.c_uint64),
+                ("iter_caps", C.c_uint64), ("baked_drops", C.c_uint64)]
+
+
+class FrameCfg(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("display_width", C.c_int),
+                ("display_height", C.c_int), ("light_count", C.c_int), ("material_offset", C.c_int),
+                ("material_count", C.c_int), ("sky", C.c_float * 4), ("ray_limit", C.c_int),
+                ("samples_lock", C.c_int)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.psmo_f32_to_f16.restype = C.c_uint16
+        _lib.psmo_f32_to_f16.argtypes = [C.c_float]
+        _lib.psmo_f16_to_f32.restype = C.c_float
+        _lib.psmo_f16_to_f32.argtypes = [C.c_uint16]
+        _lib.psmo_morton3_64.restype = C.c_uint64
+        _lib.psmo_morton3_64.argtypes = [C.c_uint32] * 3
+        _lib.psmo_hash.restype = C.c_uint32
+        _lib.psmo_hash.argtypes = [C.c_uint32]
+        for f in ("psmo_sinf", "psmo_cosf"):
+            getattr(_lib, f).restype = C.c_float
+            getattr(_lib, f).argtypes = [C.c_float]
+        _lib.psmo_powf.restype = C.c_float
+        _lib.psmo_powf.argtypes = [C.c_float, C.c_float]
+        _lib.psmo_find_split.restype = C.c_int
+        _lib.psmo_build_nodes.restype = C.c_int
+        _lib.psmo_morton_leaves.restype = C.c_int
+        _lib.psmo_build.restype = C.c_int
+        _lib.psmo_traverse.restype = C.c_int
+        _lib.psmo_brute_force.restype = C.c_int
+        _lib.psmo_camera.restype = C.c_int
+        _lib.psmo_shade.restype = C.c_int
+        _lib.psmo_rand_next.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f32_to_f16(x):
+    return int(lib().psmo_f32_to_f16(float(np.float32(x))))
+
+
+def f16_to_f32(h):
+    return np.float32(lib().psmo_f16_to_f32(int(h)))
+
+
+def morton3(x, y, z):
+    return int(lib().psmo_morton3_64(int(x), int(y), int(z)))
+
+
+def hash32(x):
+    return int(lib().psmo_hash(int(x) & 0xFFFFFFFF))
+
+
+IDENTITY_D = np.eye(4, dtype=np.float64).reshape(16)
+
+
+def minmax(tris, M):
+    tris = np.ascontiguousarray(tris, np.float32)
+    M = np.ascontiguousarray(M, np.float32)
+    mn = np.zeros(4, np.float32)
+    mx = np.zeros(4, np.float32)
+    lib().psmo_minmax(_p(tris), C.c_int(tris.shape[0]), _p(M), _p(mn), _p(mx))
+    return mn, mx
+
+
+def fit_transform(mn, mx, opt=None):
+    opt = np.ascontiguousarray(IDENTITY_D if opt is None else opt, np.float64)
+    M = np.zeros(16, np.float32)
+    Minv = np.zeros(16, np.float32)
+    lib().psmo_fit_transform(_p(np.ascontiguousarray(mn, np.float32)), _p(np.ascontiguousarray(mx, np.float32)),
+                             _p(opt), _p(M), _p(Minv))
+    return M, Minv
+
+
+def inverse_opt(opt=None):
+    opt = np.ascontiguousarray(IDENTITY_D if opt is None else opt, np.float64)
+    M = np.zeros(16, np.float32)
+    lib().psmo_inverse_opt(_p(opt), _p(M))
+    return M
+
+
+def morton_leaves(tris, M):
+    tris = np.ascontiguousarray(tris, np.float32)
+    n = tris.shape[0]
+    keys = np.zeros(max(n, 1), np.uint64)
+    idx = np.zeros(max(n, 1), np.int32)
+    leafs = np.zeros(max(n, 1), NODE_DT)
+    cnt = lib().psmo_morton_leaves(_p(tris), C.c_int(n), _p(np.ascontiguousarray(M, np.float32)),
+                                   _p(keys), _p(idx), _p(leafs))
+    return keys[:cnt].copy(), idx[:cnt].copy(), leafs[:cnt].copy()
+
+
+def radix_sort(keys, vals):
+    keys = np.ascontiguousarray(keys, np.uint64).copy()
+    vals = np.ascontiguousarray(vals, np.int32).copy()
+    lib().psmo_radix_sort(_p(keys), _p(vals), C.c_int(keys.shape[0]))
+    return keys, vals
+
+
+def find_split(keys, first, last):
+    keys = np.ascontiguousarray(keys, np.uint64)
+    return int(lib().psmo_find_split(_p(keys), C.c_int(first), C.c_int(last), None))
+
+
+def build_nodes(keys, idx, leafs):
+    """Returns (nodes[count], levels, key_reads). leafs is updated in place (pdata.z)."""
+    n = keys.shape[0]
+    nodes = np.zeros(max(2 * n, 1), NODE_DT)
+    levels = C.c_int(0)
+    reads = C.c_uint64(0)
+    cnt = lib().psmo_build_nodes(_p(np.ascontiguousarray(keys, np.uint64)), _p(np.ascontiguousarray(idx, np.int32)),
+                                 _p(leafs), C.c_int(n), _p(nodes), C.byref(levels), C.byref(reads))
+    return nodes[:cnt].copy(), levels.value, reads.value
+
+
+def build_scene(tris, opt=None):
+    """Whole TriangleHierarchy::build. Returns dict(M, keys, idx, leafs, nodes, count)."""
+    tris = np.ascontiguousarray(tris, np.float32)
+    M0 = inverse_opt(opt)
+    mn, mx = minmax(tris, M0)
+    M, Minv = fit_transform(mn, mx, opt)
+    keys, idx, leafs = morton_leaves(tris, M)
+    skeys, sidx = radix_sort(keys, idx)
+    nodes, levels, reads = build_nodes(skeys, sidx, leafs)
+    return {"M": M, "Minv": Minv, "mn": mn, "mx": mx, "keys_unsorted": keys, "keys": skeys, "idx": sidx,
+            "leafs": leafs, "nodes": nodes, "count": keys.shape[0], "levels": levels, "key_reads": reads}
+
+
+def traverse(nodes, tris, M, origins, directs, nthreads=0, want_hits=True):
+    tris = np.ascontiguousarray(tris, np.float32)
+    origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    directs = np.ascontiguousarray(directs, np.float32).reshape(-1, 3)
+    n = origins.shape[0]
+    hits = np.zeros((n, BAKED_CAP), HIT_DT) if want_hits else None
+    counts = np.zeros(n, np.int32)
+    ctr = Counters()
+    lib().psmo_traverse_batch(_p(np.ascontiguousarray(nodes)), _p(tris), _p(np.ascontiguousarray(M, np.float32)),
+                              _p(origins), _p(directs), C.c_int(n), _p(hits) if want_hits else None,
+                              _p(counts), C.byref(ctr), C.c_int(nthreads))
+    return hits, counts, ctr
+
+
+def brute_force(tris, origin, direct):
+    tris = np.ascontiguousarray(tris, np.float32)
+    best = np.zeros(1, HIT_DT)
+    found = lib().psmo_brute_force(_p(tris), C.c_int(tris.shape[0]), _p(np.ascontiguousarray(origin, np.float32)),
+                                   _p(np.ascontiguousarray(direct, np.float32)), _p(best))
+    return bool(found), best[0]
+
+
+def make_cfg(width, height, display=None, lights=1, material_count=1, material_offset=0,
+             sky=(0.5, 0.7, 1.0), ray_limit=None, samples_lock=4):
+    cfg = FrameCfg()
+    cfg.width, cfg.height = width, height
+    cfg.display_width, cfg.display_height = display if display else (width, height)
+    cfg.light_count = lights
+    cfg.material_offset, cfg.material_count = material_offset, material_count
+    for k in range(3):
+        cfg.sky[k] = sky[k]
+    cfg.sky[3] = 1.0
+    cfg.ray_limit = ray_limit if ray_limit is not None else min(4 * width * height, 4096 * 4096)
+    cfg.samples_lock = samples_lock
+    return cfg
+
+
+def default_lights(n=1):
+    """Pipeline.inl:93-98"""
+    L = np.zeros(n, LIGHT_DT)
+    for i in range(n):
+        L[i]["lightColor"] = (np.float32(255.0) / np.float32(255.0) * np.float32(150.0),
+                              np.float32(250.0) / np.float32(255.0) * np.float32(150.0),
+                              np.float32(244.0) / np.float32(255.0) * np.float32(150.0), 40.0)
+        L[i]["lightVector"] = (0.3, 1.0, 0.1, 400.0)
+    return L
+
+
+def camera(cfg, cam_inv, proj_inv, time, y0=0, y1=None):
+    y1 = cfg.height if y1 is None else y1
+    wh = cfg.width * cfg.height
+    rays = np.zeros((y1 - y0) * cfg.width, RAY_DT)
+    coord = np.zeros((wh, 2), np.float32)
+    tsum = np.zeros((wh, 4), np.float32)
+    flag = np.zeros(wh, np.int32)
+    n = lib().psmo_camera(C.byref(cfg), _p(np.ascontiguousarray(cam_inv, np.float32)),
+                          _p(np.ascontiguousarray(proj_inv, np.float32)), C.c_uint32(time),
+                          C.c_int(y0), C.c_int(y1), _p(rays), _p(coord), _p(tsum), _p(flag))
+    return rays[:n], coord, tsum, flag
+
+
+def shade(cfg, lights, materials, tri_mats, tris, normals, time, rays, hits, counts, tsum, flag):
+    out = np.zeros(cfg.ray_limit, RAY_DT)
+    n = lib().psmo_shade(C.byref(cfg), _p(lights), _p(materials), _p(np.ascontiguousarray(tri_mats, np.int32)),
+                         _p(np.ascontiguousarray(tris, np.float32)), _p(np.ascontiguousarray(normals, np.float32)),
+                         C.c_uint32(time), _p(np.ascontiguousarray(rays)), C.c_int(rays.shape[0]),
+                         _p(np.ascontiguousarray(hits)), _p(np.ascontiguousarray(counts, np.int32)), _p(out),
+                         _p(tsum), _p(flag))
+    return out[:n].copy()
+
+
+def sample(cfg, coord, tsum, flag, presampled):
+    filtered = np.zeros_like(presampled)
+    lib().psmo_sample(C.byref(cfg), _p(coord), _p(tsum), _p(flag), _p(presampled), _p(filtered))
+    return filtered
+
+
+def rand_next(state):
+    s = C.c_uint32(state)
+    v = lib().psmo_rand_next(C.byref(s))
+    return int(v), int(s.value)
+
+
+def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, built=None,
+                  cam=None, rows=None, record=None):
+    """Viewer.cpp:296-312 call order on the oracle: build, camera, <=depth x (traverse, shade), sample.
+    Returns (filtered image [h,w,4], stats)."""
+    from importlib import import_module
+    scenes = import_module("prismarine-core_amd.scenes")
+    tris = scene["tris"]
+    if built is None:
+        built = build_scene(tris)
+    mats = scenes.materials_array(scene["materials"])
+    cfg = make_cfg(width, height, material_count=len(mats))
+    lights = default_lights(1)
+    cam_inv, proj_inv = cam if cam else scenes.camera_matrices(scene["eye"], scene["view"], width, height)
+    presampled = np.zeros((width * height, 4), np.float32)
+    state = seed
+    stats = {"rays": 0, "rounds": [], "node_visits": 0, "tri_tests": 0}
+    y0, y1 = rows if rows else (0, height)
+    for f in range(frames):
+        t, state = rand_next(state)
+        rays, coord, tsum, flag = camera(cfg, cam_inv, proj_inv, t, y0, y1)
+        for j in range(depth):
+            if rays.shape[0] < 32:  # Pipeline::getRayCount, Pipeline.inl:459-461
+                break
+            hits, counts, ctr = traverse(built["nodes"], tris, built["M"], rays["origin"], rays["direct"], nthreads)
+            stats["rays"] += rays.shape[0]
+            stats["rounds"].append(int(rays.shape[0]))
+            stats["node_visits"] += ctr.node_visits
+            stats["tri_tests"] += ctr.tri_tests
+            if record is not None:
+                record.append({"frame": f, "round": j, "rays": rays.copy(), "hits": hits.copy(), "counts": counts.copy()})
+            t, state = rand_next(state)
+            rays = shade(cfg, lights, mats, scene["mats"], tris, scene["normals"], t, rays, hits, counts, tsum, flag)
+        filtered = sample(cfg, coord, tsum, flag, presampled)
+    return filtered.reshape(height, width, 4), stats

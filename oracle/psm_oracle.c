@@ -1,0 +1,714 @@
+/*
+ * psm_oracle.c -- CPU restatement of the prismarine-core hot path (build + trace).
+ * See psm_oracle.h: TEST INFRASTRUCTURE ONLY, PARITY UNPINNED BY THE REFERENCE.
+ *
+ * Reference files restated (paths relative to /root/reference):
+ *   ShadersSDK/include/{morton,mathlib,vertex,structs,constants}.glsl
+ *   ShadersSDK/hlbvh/{minmax,aabbmaker,build-new,child-link,refit}.comp
+ *   ShadersSDK/radix/{histogram,pfx-work,permute}.comp  (collapse to a stable LSD sort)
+ *   ShadersSDK/raytracing/directTraverse.comp
+ *   Include/Prismarine/TriangleHierarchy.inl:206-329, Radix.hpp:47-74
+ */
+#include "psm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* canonical scalar helpers (DESIGN.md "canonical arithmetic")         */
+/* ------------------------------------------------------------------ */
+#include "psm_oracle_internal.h"
+
+/* packHalf2x16 rounding: round-to-nearest-even (SURVEY a-8 canonical rule) */
+uint16_t psmo_f32_to_f16(float f) {
+    uint32_t x = f2u(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t e = (x >> 23) & 0xffu;
+    uint32_t m = x & 0x7fffffu;
+    if (e == 255u) return (uint16_t)(sign | 0x7c00u | (m ? (0x200u | (m >> 13)) : 0u));
+    int32_t E = (int32_t)e - 127 + 15;
+    if (E >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (E <= 0) {
+        if (E < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        uint32_t shift = (uint32_t)(14 - E);
+        uint32_t hm = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (hm & 1u))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t h = ((uint32_t)E << 10) | (m >> 13);
+    uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+float psmo_f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return u2f(sign);
+        /* subnormal: m * 2^-24 */
+        float v = (float)m * 5.9604644775390625e-08f;
+        return (sign ? -v : v);
+    }
+    if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
+    return u2f(sign | ((e - 15 + 127) << 23) | (m << 13));
+}
+
+/* include/morton.glsl:37-51 */
+static inline uint64_t part1by2_64(uint32_t a) {
+    uint64_t x = a & 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+uint64_t psmo_morton3_64(uint32_t x, uint32_t y, uint32_t z) {
+    return part1by2_64(x) | (part1by2_64(y) << 1) | (part1by2_64(z) << 2);
+}
+
+/* ------------------------------------------------------------------ */
+/* build                                                               */
+/* ------------------------------------------------------------------ */
+
+static inline void load_tri_xformed(const float* tris, int t, const float M[16], float v[3][4]) {
+    for (int k = 0; k < 3; k++) {
+        float p[4] = {tris[9 * t + 3 * k + 0], tris[9 * t + 3 * k + 1], tris[9 * t + 3 * k + 2], 1.0f};
+        mat_vec(M, p, v[k]);
+    }
+}
+
+/* hlbvh/minmax.comp:50-79 + host reduce TriangleHierarchy.inl:248-255.
+ * min/max are exact and order independent; every partial carries the -+1e-5
+ * pad (minmax.comp:76-77) so the reduced result is (exact min) - 1e-5f. */
+void psmo_minmax(const float* tris, int n, const float M[16], float mn[4], float mx[4]) {
+    for (int c = 0; c < 4; c++) { mn[c] = 100000.f; mx[c] = -100000.f; }
+    for (int t = 0; t < n; t++) {
+        float v[3][4];
+        load_tri_xformed(tris, t, M, v);
+        for (int c = 0; c < 4; c++) {
+            float lo = pmin(pmin(v[0][c], v[1][c]), v[2][c]);
+            float hi = pmax(pmax(v[0][c], v[1][c]), v[2][c]);
+            mn[c] = pmin(mn[c], lo);
+            mx[c] = pmax(mx[c], hi);
+        }
+    }
+    for (int c = 0; c < 4; c++) { mn[c] = mn[c] - 0.00001f; mx[c] = mx[c] + 0.00001f; }
+}
+
+/* general 4x4 inverse in double by cofactors (what glm::inverse does structurally) */
+static void inverse4d(const double* m, double* o) {
+    /* m row-major */
+    double a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3];
+    double a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
+    double a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11];
+    double a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
+    double b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10;
+    double b02 = a00 * a13 - a03 * a10, b03 = a01 * a12 - a02 * a11;
+    double b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
+    double b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30;
+    double b08 = a20 * a33 - a23 * a30, b09 = a21 * a32 - a22 * a31;
+    double b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
+    double det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
+    double id = 1.0 / det;
+    o[0] = (a11 * b11 - a12 * b10 + a13 * b09) * id;
+    o[1] = (-a01 * b11 + a02 * b10 - a03 * b09) * id;
+    o[2] = (a31 * b05 - a32 * b04 + a33 * b03) * id;
+    o[3] = (-a21 * b05 + a22 * b04 - a23 * b03) * id;
+    o[4] = (-a10 * b11 + a12 * b08 - a13 * b07) * id;
+    o[5] = (a00 * b11 - a02 * b08 + a03 * b07) * id;
+    o[6] = (-a30 * b05 + a32 * b02 - a33 * b01) * id;
+    o[7] = (a20 * b05 - a22 * b02 + a23 * b01) * id;
+    o[8] = (a10 * b10 - a11 * b08 + a13 * b06) * id;
+    o[9] = (-a00 * b10 + a01 * b08 - a03 * b06) * id;
+    o[10] = (a30 * b04 - a31 * b02 + a33 * b00) * id;
+    o[11] = (-a20 * b04 + a21 * b02 - a23 * b00) * id;
+    o[12] = (-a10 * b09 + a11 * b07 - a12 * b06) * id;
+    o[13] = (a00 * b09 - a01 * b07 + a02 * b06) * id;
+    o[14] = (-a30 * b03 + a31 * b01 - a32 * b00) * id;
+    o[15] = (a20 * b03 - a21 * b01 + a22 * b00) * id;
+}
+static void mul4d(const double* a, const double* b, double* o) {
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
+            o[4 * i + j] = s;
+        }
+}
+
+/* first-pass transform: inverse(optimization), TriangleHierarchy.inl:226-232 */
+void psmo_inverse_opt(const double opt[16], float M[16]) {
+    double inv[16];
+    inverse4d(opt, inv);
+    for (int i = 0; i < 16; i++) M[i] = (float)inv[i];
+}
+
+/* TriangleHierarchy.inl:257-267: scale = mx-mn, offset = mn (float);
+ * mat = inverse(translate(offset) * scale(scale)) * inverse(opt) in double, cast to float. */
+void psmo_fit_transform(const float mn[4], const float mx[4], const double opt[16], float M[16],
+                        float Minv[16]) {
+    float scale[3], offset[3];
+    for (int c = 0; c < 3; c++) { scale[c] = mx[c] - mn[c]; offset[c] = mn[c]; }
+    double TS[16] = {(double)scale[0], 0, 0, (double)offset[0],
+                     0, (double)scale[1], 0, (double)offset[1],
+                     0, 0, (double)scale[2], (double)offset[2],
+                     0, 0, 0, 1};
+    double iTS[16], iopt[16], mat[16], imat[16];
+    inverse4d(TS, iTS);
+    inverse4d(opt, iopt);
+    mul4d(iTS, iopt, mat);
+    for (int i = 0; i < 16; i++) M[i] = (float)mat[i];
+    double Md[16];
+    for (int i = 0; i < 16; i++) Md[i] = (double)M[i];
+    inverse4d(Md, imat);
+    for (int i = 0; i < 16; i++) Minv[i] = (float)imat[i];
+}
+
+/* hlbvh/aabbmaker.comp:142-232 at splitLimit = 0 (:139-140).
+ * Canonical leaf slot: rank among kept triangles in ascending t (SURVEY a-8). */
+int psmo_morton_leaves(const float* tris, int n, const float M[16], uint64_t* keys, int32_t* idx,
+                       psmo_node* leafs) {
+    int to = 0;
+    for (int t = 0; t < n; t++) {
+        float v[3][4];
+        load_tri_xformed(tris, t, M, v);
+        float c[4];
+        for (int k = 0; k < 4; k++) c[k] = ((v[0][k] + v[1][k]) + v[2][k]) * 0.33333333333333f;
+        float s[3];
+        for (int k = 0; k < 3; k++)
+            s[k] = (fabsf(v[0][k] - c[k]) + fabsf(v[1][k] - c[k])) + fabsf(v[2][k] - c[k]);
+        if (len3(s) < 1.e-5f) continue; /* :160 */
+        float bmn[4], bmx[4];
+        for (int k = 0; k < 4; k++) {
+            bmn[k] = pmin(pmin(v[0][k], v[1][k]), v[2][k]);
+            bmx[k] = pmax(pmax(v[0][k], v[1][k]), v[2][k]);
+        }
+        /* :176 greaterEqualF(branges, 0) on x,y,z */
+        if (!(greaterEqualF(bmx[0] - bmn[0], 0.f) && greaterEqualF(bmx[1] - bmn[1], 0.f) &&
+              greaterEqualF(bmx[2] - bmn[2], 0.f)))
+            continue;
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            float f = floorf(pclamp(c[k], 0.0f, 0.99999f) * 2097152.0f);
+            uint32_t u = (uint32_t)f;
+            q[k] = u > 0x1FFFFFu ? 0x1FFFFFu : u;
+        }
+        keys[to] = psmo_morton3_64(q[0], q[1], q[2]);
+        idx[to] = to;
+        for (int k = 0; k < 4; k++) { bmn[k] = bmn[k] - PSMO_PZERO; bmx[k] = bmx[k] + PSMO_PZERO; }
+        pack_half4(bmn, &leafs[to].box[0]);
+        pack_half4(bmx, &leafs[to].box[2]);
+        leafs[to].pdata[0] = to;
+        leafs[to].pdata[1] = to;
+        leafs[to].pdata[2] = -1;
+        leafs[to].pdata[3] = t;
+        to++;
+    }
+    return to;
+}
+
+/* Radix.hpp:47-74 + radix/{histogram,pfx-work,permute}.comp: 8 passes of 8 bits, stable, ascending,
+ * (u64 key, u32 value).  Restated as the literal LSD counting sort. */
+void psmo_radix_sort(uint64_t* keys, int32_t* vals, int n) {
+    if (n <= 1) return;
+    uint64_t* tk = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+    int32_t* tv = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    for (int pass = 0; pass < 8; pass++) {
+        size_t count[257];
+        memset(count, 0, sizeof(count));
+        int sh = pass * 8;
+        for (int i = 0; i < n; i++) count[((keys[i] >> sh) & 0xff) + 1]++;
+        for (int d = 0; d < 256; d++) count[d + 1] += count[d];
+        for (int i = 0; i < n; i++) {
+            size_t p = count[(keys[i] >> sh) & 0xff]++;
+            tk[p] = keys[i];
+            tv[p] = vals[i];
+        }
+        memcpy(keys, tk, sizeof(uint64_t) * (size_t)n);
+        memcpy(vals, tv, sizeof(int32_t) * (size_t)n);
+    }
+    free(tk);
+    free(tv);
+}
+
+/* hlbvh/build-new.comp:18-23 */
+static inline int nlz64(uint64_t x) {
+    if (x == 0) return 64;
+    int n = 0;
+    while (!(x & 0x8000000000000000ull)) { x <<= 1; n++; }
+    return n;
+}
+
+/* hlbvh/build-new.comp:33-56 */
+int psmo_find_split(const uint64_t* keys, int first, int last, uint64_t* key_reads) {
+    uint64_t firstCode = keys[first];
+    uint64_t lastCode = keys[last];
+    uint64_t reads = 2;
+    int split = (first + last) >> 1;
+    if (firstCode != lastCode) {
+        split = first;
+        int commonPrefix = nlz64(firstCode ^ lastCode);
+        int step = last - first;
+        for (int i = 0; i < 8192; i++) {
+            step = (step + 1) >> 1;
+            int newSplit = split + step;
+            if (newSplit < last) {
+                uint64_t splitCode = keys[newSplit];
+                reads++;
+                int splitPrefix = nlz64(firstCode ^ splitCode);
+                if (splitPrefix > commonPrefix) split = newSplit;
+            }
+            if (step <= 1) break;
+        }
+    }
+    if (key_reads) *key_reads += reads;
+    if (split < first) split = first;
+    if (split > last - 1) split = last - 1;
+    return split;
+}
+
+static const uint32_t HALF_P1000 = 0x63D0u; /* packHalf(1000.0)  */
+static const uint32_t HALF_N1000 = 0xE3D0u; /* packHalf(-1000.0) */
+
+/* fp16 min/max with -0 < +0 (order-independent refit) */
+static inline int32_t half_key(uint16_t h) { return (h & 0x8000u) ? -(int32_t)(h & 0x7fffu) - 1 : (int32_t)h; }
+static inline uint16_t half_min(uint16_t a, uint16_t b) { return half_key(b) < half_key(a) ? b : a; }
+static inline uint16_t half_max(uint16_t a, uint16_t b) { return half_key(a) < half_key(b) ? b : a; }
+static inline uint32_t half2_min(uint32_t a, uint32_t b) {
+    return (uint32_t)half_min((uint16_t)a, (uint16_t)b) | ((uint32_t)half_min((uint16_t)(a >> 16), (uint16_t)(b >> 16)) << 16);
+}
+static inline uint32_t half2_max(uint32_t a, uint32_t b) {
+    return (uint32_t)half_max((uint16_t)a, (uint16_t)b) | ((uint32_t)half_max((uint16_t)(a >> 16), (uint16_t)(b >> 16)) << 16);
+}
+
+/* build-new.comp:120-153 (level loop driven by TriangleHierarchy.inl:304-313),
+ * child-link.comp:16-59, refit.comp:21-114.
+ * Canonical numbering = BFS (SURVEY a-9): root 0; the i-th queued node of a level gets
+ * children base+2i, base+2i+1; internal children are enqueued left then right.
+ * Returns the node count. */
+int psmo_build_nodes(const uint64_t* keys, const int32_t* idx, psmo_node* leafs, int n,
+                     psmo_node* nodes, int* levels, uint64_t* key_reads) {
+    if (levels) *levels = 0;
+    if (n <= 0) return 0;
+    int* cur = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int* nxt = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int* leafIndices = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int ncur = 0, nleaf = 0, lcounter = 0;
+    /* root, build-new.comp:128-141 */
+    {
+        int hid = lcounter++;
+        cur[ncur++] = hid;
+        nodes[hid].box[0] = nodes[hid].box[1] = HALF_P1000 | (HALF_P1000 << 16);
+        nodes[hid].box[2] = nodes[hid].box[3] = HALF_N1000 | (HALF_N1000 << 16);
+        nodes[hid].pdata[0] = 0;
+        nodes[hid].pdata[1] = n - 1;
+        nodes[hid].pdata[2] = -1;
+        nodes[hid].pdata[3] = -1;
+    }
+    int nlev = 0;
+    while (ncur > 0) {
+        int nnxt = 0;
+        int base = lcounter;
+        for (int i = 0; i < ncur; i++) {
+            int prID = cur[i];
+            psmo_node parent = nodes[prID];
+            if (parent.pdata[0] == parent.pdata[1]) continue; /* splitNode :74 */
+            int split = psmo_find_split(keys, parent.pdata[0], parent.pdata[1], key_reads);
+            int hid = base + 2 * i;
+            /* all queued nodes are internal except possibly a 1-leaf root */
+            int tr[4] = {parent.pdata[0], split, split + 1, parent.pdata[1]};
+            for (int c = 0; c < 2; c++) {
+                int h = hid + c;
+                nodes[h].box[0] = nodes[h].box[1] = HALF_P1000 | (HALF_P1000 << 16);
+                nodes[h].box[2] = nodes[h].box[3] = HALF_N1000 | (HALF_N1000 << 16);
+                nodes[h].pdata[0] = tr[2 * c];
+                nodes[h].pdata[1] = tr[2 * c + 1];
+                nodes[h].pdata[2] = prID;
+                nodes[h].pdata[3] = -1;
+                int isLeaf = (tr[2 * c + 1] - tr[2 * c]) < 1;
+                if (isLeaf) leafIndices[nleaf++] = h; else nxt[nnxt++] = h;
+            }
+            nodes[prID].pdata[0] = hid;
+            nodes[prID].pdata[1] = hid + 1;
+            if (lcounter < hid + 2) lcounter = hid + 2;
+        }
+        int* tmp = cur; cur = nxt; nxt = tmp;
+        ncur = nnxt;
+        nlev++;
+    }
+    if (levels) *levels = nlev;
+    /* child-link.comp:27-53 */
+    for (int g = 0; g < nleaf; g++) {
+        int id = leafIndices[g];
+        psmo_node child = nodes[id];
+        int leafID = idx[child.pdata[0]];
+        leafs[leafID].pdata[2] = id;
+        memcpy(child.box, leafs[leafID].box, sizeof(child.box));
+        int ry = child.pdata[1];
+        child.pdata[0] = ry;
+        child.pdata[1] = ry;
+        child.pdata[3] = leafs[leafID].pdata[3];
+        nodes[id] = child;
+    }
+    /* refit.comp:63-110: bottom-up union; the BFS numbering puts children after parents,
+     * so a reverse sweep visits children first. min/max are exact => any schedule agrees. */
+    for (int id = lcounter - 1; id >= 0; id--) {
+        psmo_node* nd = &nodes[id];
+        if (nd->pdata[0] != nd->pdata[1]) {
+            const psmo_node* ln = &nodes[nd->pdata[0]];
+            const psmo_node* rn = &nodes[nd->pdata[1]];
+            nd->box[0] = half2_min(ln->box[0], rn->box[0]);
+            nd->box[1] = half2_min(ln->box[1], rn->box[1]);
+            nd->box[2] = half2_max(ln->box[2], rn->box[2]);
+            nd->box[3] = half2_max(ln->box[3], rn->box[3]);
+        }
+    }
+    free(cur); free(nxt); free(leafIndices);
+    return lcounter;
+}
+
+/* TriangleHierarchy::build, TriangleHierarchy.inl:206-329 */
+int psmo_build(const float* tris, int n, const double opt[16], float M[16], uint64_t* keys,
+               int32_t* idx, psmo_node* leafs, psmo_node* nodes) {
+    float M0[16], Minv[16], mn[4], mx[4];
+    psmo_inverse_opt(opt, M0);
+    psmo_minmax(tris, n, M0, mn, mx);
+    psmo_fit_transform(mn, mx, opt, M, Minv);
+    int cnt = psmo_morton_leaves(tris, n, M, keys, idx, leafs);
+    if (cnt <= 0) return 0;
+    psmo_radix_sort(keys, idx, cnt);
+    psmo_build_nodes(keys, idx, leafs, cnt, nodes, NULL, NULL);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ */
+/* traversal, raytracing/directTraverse.comp                           */
+/* ------------------------------------------------------------------ */
+
+/* include/mathlib.glsl:107-126 */
+static float intersectCubeSingle(const float o[3], const float ray[3], const float cmn[3],
+                                 const float cmx[3], float* near, float* far) {
+    float t1[3], t2[3];
+    for (int k = 0; k < 3; k++) {
+        float dr = 1.0f / ray[k];
+        float norig = -o[k] * dr;
+        float tMin = fmaf(cmn[k], dr, norig);
+        float tMax = fmaf(cmx[k], dr, norig);
+        t1[k] = pmin(tMin, tMax);
+        t2[k] = pmax(tMin, tMax);
+    }
+    float tNear = pmax(pmax(t1[0], t1[1]), t1[2]);
+    float tFar = pmin(pmin(t2[0], t2[1]), t2[2]);
+    int isCube = greaterEqualF(tFar, tNear) && greaterEqualF(tFar, 0.0f);
+    float inf = PSMO_INFINITY;
+    *near = isCube ? pmin(tNear, tFar) : inf;
+    *far = isCube ? pmax(tNear, tFar) : inf;
+    return isCube ? (lessF(*near, 0.0f) ? *far : *near) : inf;
+}
+
+/* include/mathlib.glsl:129-193, fp32 branch (canonical = fp32 slab
+ * maths on fp16-stored boxes). One child at a time; the dual form is component-wise. */
+static float intersectCubeChild(const float o[3], const float dr[3], const float cmn[4],
+                                const float cmx[4], float* near, float* far) {
+    float t1[3], t2[3];
+    for (int k = 0; k < 3; k++) {
+        float norig = -o[k] * dr[k];
+        float tMin = fmaf(cmn[k], dr[k], norig);
+        float tMax = fmaf(cmx[k], dr[k], norig);
+        t1[k] = pmin(tMin, tMax);
+        t2[k] = pmax(tMin, tMax);
+    }
+    float tNear = pmax(pmax(t1[0], t1[1]), t1[2]);
+    float tFar = pmin(pmin(t2[0], t2[1]), t2[2]);
+    float inf = PSMO_INFINITY;
+    int isCube = ((tFar + PSMO_PZERO) >= tNear) && ((tFar + PSMO_PZERO) >= 0.0f);
+    *near = isCube ? pmin(tNear, tFar) : inf;
+    *far = isCube ? pmax(tNear, tFar) : inf;
+    return ((*near + PSMO_PZERO) <= 0.0f) ? *far : *near;
+}
+
+/* include/vertex.glsl:140-189 */
+static float intersectTriangle(const float* tris, const float orig[3], const float dir[3], int tri,
+                               float* U, float* V, int valid, psmo_counters* ctr) {
+    float T = PSMO_INFINITY;
+    if (tri == -1) valid = 0;
+    if (valid) {
+        const float* v0 = &tris[9 * tri + 0];
+        const float* v1 = &tris[9 * tri + 3];
+        const float* v2 = &tris[9 * tri + 6];
+        if (ctr) ctr->tri_tests++;
+        float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+        float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+        float pvec[3];
+        cross3(dir, e2, pvec);
+        float det = dot3(e1, pvec);
+        if (fabsf(det) <= 0.0f) valid = 0;
+        if (valid) {
+            float invDev = 1.f / (pmax(fabsf(det), 0.000001f) * psign(det));
+            float tvec[3] = {orig[0] - v0[0], orig[1] - v0[1], orig[2] - v0[2]};
+            float u = dot3(tvec, pvec) * invDev;
+            if (u < -0.00001f || u > 1.00001f) valid = 0;
+            if (valid) {
+                float qvec[3];
+                cross3(tvec, e1, qvec);
+                float v = dot3(dir, qvec) * invDev;
+                if (v < -0.00001f || (u + v) > 1.00001f) valid = 0;
+                if (valid) {
+                    float t = dot3(e2, qvec) * invDev;
+                    if (greaterEqualF(t, 0.0f) && valid) {
+                        T = t;
+                        *U = u;
+                        *V = v;
+                    }
+                }
+            }
+        }
+    }
+    return T;
+}
+
+typedef struct {
+    float predist;
+    int triangleID;
+    int bakedCount;
+    psmo_hit baked[PSMO_BAKED_CAP];
+} tstate;
+
+static void bake_push(tstate* st, float u, float v, float t, int tri, psmo_counters* ctr) {
+    int at = st->bakedCount++;
+    if (at < PSMO_BAKED_CAP) {
+        st->baked[at].u = u; st->baked[at].v = v; st->baked[at].t = t; st->baked[at].tri = tri;
+    } else if (ctr) {
+        ctr->baked_drops++; /* reference writes out of bounds here (:294); canonical = drop */
+    }
+}
+
+/* directTraverse.comp:261-309, non-AMD branch (single-triangle test) */
+static void testIntersectionPacked(tstate* st, const float* tris, const float orig[3],
+                                   const float dir[3], int tx, int ty, int vx, int vy,
+                                   psmo_counters* ctr) {
+    int validx = (tx >= 0) && (tx != -1) && (tx != st->triangleID) && vx;
+    int validy = (ty >= 0) && (ty != -1) && (ty != st->triangleID) && vy;
+    validy = validy && (tx != ty);
+    if (!validx) {
+        int t = tx; tx = ty; ty = t;
+        t = validx; validx = validy; validy = t;
+    }
+    if (validx || validy) {
+        float ux = 0.f, vxx = 0.f, uy = 0.f, vyy = 0.f;
+        float dx = intersectTriangle(tris, orig, dir, tx, &ux, &vxx, validx, ctr);
+        float dy = intersectTriangle(tris, orig, dir, ty, &uy, &vyy, validy, ctr);
+        int near = validx && lessF(dx, PSMO_INFINITY) && lessEqualF(dx, st->predist) && greaterEqualF(dx, 0.0f);
+        if (near) {
+            if (!equalF(dx, st->predist)) st->bakedCount = 0;
+            st->predist = dx;
+            st->triangleID = tx;
+            bake_push(st, ux, vxx, dx, tx, ctr);
+        }
+        near = validy && lessF(dy, PSMO_INFINITY) && lessEqualF(dy, st->predist) && greaterEqualF(dy, 0.0f);
+        if (near) {
+            if (!equalF(dy, st->predist)) st->bakedCount = 0;
+            st->predist = dy;
+            st->triangleID = ty;
+            bake_push(st, uy, vyy, dy, ty, ctr);
+        }
+    }
+}
+
+/* directTraverse.comp:74-112 */
+static void reorderTriangles(tstate* st) {
+    if (st->bakedCount > PSMO_BAKED_CAP) st->bakedCount = PSMO_BAKED_CAP;
+    int n = st->bakedCount;
+    for (int iround = 1; iround < n; iround++) {
+        for (int index = 0; index < n - iround; index++) {
+            psmo_hit a = st->baked[index], b = st->baked[index + 1];
+            int lessIdx = a.tri <= b.tri;
+            int deeper = lessF(a.t, b.t);
+            if (lessIdx || deeper) { st->baked[index] = b; st->baked[index + 1] = a; }
+        }
+    }
+    int clean = 0;
+    for (int iround = 0; iround < PSMO_BAKED_CAP; iround++) {
+        if (iround >= n - 1) break;
+        if (st->baked[iround + 1].tri != st->baked[iround].tri) st->baked[clean++] = st->baked[iround];
+    }
+    if (n > 0 && clean <= PSMO_BAKED_CAP) st->baked[clean++] = st->baked[n - 1];
+    st->bakedCount = clean;
+}
+
+/* directTraverse.comp:333-484 for a fresh ray (ray.hit == -1). Returns the chain length;
+ * out[0] is the head of the chain ("hit triangle index"). */
+int psmo_traverse(const psmo_node* nodes, const float* tris, const float M[16],
+                  const float origin[3], const float direct_in[3], psmo_hit out[PSMO_BAKED_CAP],
+                  psmo_counters* ctr) {
+    tstate st;
+    st.predist = PSMO_INFINITY;
+    st.triangleID = -1;
+    st.bakedCount = 0;
+    for (int i = 0; i < PSMO_BAKED_CAP; i++) { st.baked[i].u = 0; st.baked[i].v = 0; st.baked[i].t = PSMO_INFINITY; st.baked[i].tri = -1; }
+    int deferredStack[PSMO_STACK_CAP];
+    int deferredPtr = 0;
+    deferredStack[0] = -1;
+
+    float direct[3];
+    normalize3(direct_in, direct); /* :350 */
+
+    float o4[4] = {origin[0], origin[1], origin[2], 1.0f};
+    float d4[4] = {direct[0], direct[1], direct[2], 1.0f};
+    float torig4[4], tdir4[4];
+    mat_vec(M, o4, torig4);   /* :353 projectVoxels */
+    matT_vec(M, d4, tdir4);   /* :354 */
+    float dirlen = len3(tdir4) / pmax(len3(direct), 0.000001f);
+    float dirlenInv = 1.f / pmax(dirlen, 0.000001f);
+    float dirproj[3];
+    normalize3(tdir4, dirproj);
+
+    float near = PSMO_INFINITY, far = PSMO_INFINITY;
+    const float cmn[3] = {-0.00001f, -0.00001f, -0.00001f};
+    const float cmx[3] = {1.00001f, 1.00001f, 1.00001f};
+    float d = intersectCubeSingle(torig4, dirproj, cmn, cmx, &near, &far);
+    float toffset = pmax(near, 0.f);
+    float origined[3], divident[3];
+    for (int k = 0; k < 3; k++) {
+        origined[k] = torig4[k] + dirproj[k] * toffset;
+        divident[k] = 1.f / dirproj[k];
+    }
+
+    int idx = 0, found = -1;
+    int validBox = lessF(d, PSMO_INFINITY) && lessF(d * dirlenInv, PSMO_INFINITY) && greaterEqualF(d, 0.0f);
+    psmo_node node = nodes[idx];
+    int skipUpstream = 0;
+    const float IP = PSMO_INFINITY - PSMO_PZERO;
+    int i;
+    for (i = 0; i < PSMO_MAX_ITERS; i++) {
+        if (!validBox) break;
+        int notLeaf = node.pdata[0] != node.pdata[1];
+        if (notLeaf) {
+            if (ctr) ctr->node_visits++;
+            const psmo_node* L = &nodes[node.pdata[0]];
+            const psmo_node* R = &nodes[node.pdata[1]];
+            float lmn[4], lmx[4], rmn[4], rmx[4];
+            unpack_half4(&L->box[0], lmn); unpack_half4(&L->box[2], lmx);
+            unpack_half4(&R->box[0], rmn); unpack_half4(&R->box[2], rmx);
+            float nears[2], fars[2], hits[2];
+            hits[0] = intersectCubeChild(origined, divident, lmn, lmx, &nears[0], &fars[0]);
+            hits[1] = intersectCubeChild(origined, divident, rmn, rmx, &nears[1], &fars[1]);
+            int leftNear = lessEqualF(nears[0], nears[1]);
+            int og[2];
+            for (int c = 0; c < 2; c++) {
+                og[c] = (hits[c] <= IP) && (hits[c] * dirlenInv <= IP) && (hits[c] > -PSMO_PZERO) &&
+                        (nears[c] <= IP) && (nears[c] * dirlenInv <= IP) &&
+                        (((nears[c] + toffset) * dirlenInv - PSMO_PZERO) <= st.predist) &&
+                        (node.pdata[0] != -1) && (node.pdata[1] != -1);
+                /* the esc terms of :429 are vestigial */
+            }
+            int lp[4] = {-1, -1, -1, -1}, rp[4] = {-1, -1, -1, -1};
+            if (og[0]) memcpy(lp, L->pdata, sizeof(lp));
+            if (og[1]) memcpy(rp, R->pdata, sizeof(rp));
+            int ov[2] = {og[0] && (lp[0] != lp[1]), og[1] && (rp[0] != rp[1])}; /* nodes */
+            int lf[2] = {og[0] && (lp[0] == lp[1]), og[1] && (rp[0] == rp[1])}; /* leafs */
+            if (lf[0] || lf[1]) {
+                int leftOrder = (lf[0] && lf[1]) ? leftNear : lf[0];
+                if (leftOrder)
+                    testIntersectionPacked(&st, tris, origin, direct, lp[3], rp[3], lf[0], lf[1], ctr);
+                else
+                    testIntersectionPacked(&st, tris, origin, direct, rp[3], lp[3], lf[1], lf[0], ctr);
+            }
+            int anyOverlap = ov[0] || ov[1];
+            if (anyOverlap) {
+                int leftOrder = (ov[0] && ov[1]) ? leftNear : ov[0];
+                int lr0 = ov[0] ? node.pdata[0] : -1;
+                int lr1 = ov[1] ? node.pdata[1] : -1;
+                if (!leftOrder) { int t = lr0; lr0 = lr1; lr1 = t; }
+                if (lr1 != -1 && lr0 != lr1) {
+                    if (deferredPtr < PSMO_STACK_CAP) deferredStack[deferredPtr++] = lr1;
+                    else if (ctr) ctr->stack_drops++;
+                }
+                found = lr0;
+            }
+            skipUpstream = skipUpstream || anyOverlap;
+        }
+        /* :467-476 */
+        {
+            int ptr = skipUpstream ? deferredPtr : --deferredPtr;
+            idx = ptr >= 0 ? (skipUpstream ? found : deferredStack[ptr]) : -1;
+            validBox = validBox && idx >= 0 && ptr >= 0;
+            if (validBox) node = nodes[idx];
+        }
+        skipUpstream = 0;
+    }
+    if (i >= PSMO_MAX_ITERS && validBox && ctr) ctr->iter_caps++;
+    reorderTriangles(&st);
+    for (int k = 0; k < st.bakedCount; k++) out[k] = st.baked[k];
+    return st.bakedCount;
+}
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+void psmo_traverse_batch(const psmo_node* nodes, const float* tris, const float M[16],
+                         const float* origins, const float* directs, int nrays, psmo_hit* hits,
+                         int32_t* counts, psmo_counters* ctr, int nthreads) {
+    psmo_counters total;
+    memset(&total, 0, sizeof(total));
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+    {
+        psmo_counters local;
+        memset(&local, 0, sizeof(local));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int r = 0; r < nrays; r++) {
+            psmo_hit tmp[PSMO_BAKED_CAP];
+            int c = psmo_traverse(nodes, tris, M, &origins[3 * r], &directs[3 * r], tmp, &local);
+            counts[r] = c;
+            if (hits) {
+                for (int k = 0; k < PSMO_BAKED_CAP; k++) {
+                    if (k < c) hits[(size_t)r * PSMO_BAKED_CAP + k] = tmp[k];
+                    else { psmo_hit z = {0.f, 0.f, PSMO_INFINITY, -1}; hits[(size_t)r * PSMO_BAKED_CAP + k] = z; }
+                }
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            total.node_visits += local.node_visits;
+            total.tri_tests += local.tri_tests;
+            total.stack_drops += local.stack_drops;
+            total.iter_caps += local.iter_caps;
+            total.baked_drops += local.baked_drops;
+        }
+    }
+    if (ctr) *ctr = total;
+}
+
+/* Independent cross-check (not a restatement): closest triangle by testing all of them
+ * with the same triangle test, smallest t wins. */
+int psmo_brute_force(const float* tris, int ntris, const float origin[3], const float direct_in[3],
+                     psmo_hit* best) {
+    float direct[3];
+    normalize3(direct_in, direct);
+    int found = 0;
+    best->t = PSMO_INFINITY; best->tri = -1; best->u = 0; best->v = 0;
+    for (int t = 0; t < ntris; t++) {
+        float u = 0, v = 0;
+        float T = intersectTriangle(tris, origin, direct, t, &u, &v, 1, NULL);
+        if (T < PSMO_INFINITY - PSMO_PZERO && T < best->t) {
+            best->t = T; best->tri = t; best->u = u; best->v = v;
+            found = 1;
+        }
+    }
+    return found;
+}

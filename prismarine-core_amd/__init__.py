@@ -1,0 +1,471 @@
+"""prismarine-core_amd -- MI355X-native path-tracing core (hot path of EngineWorld/prismarine-core).
+
+Python host-side mirror of the reference's header-only API (Include/Prismarine/*.hpp) over the
+C ABI of include/psm_hip.h.  The compute lives in libpsm_hip.so (hand-written gfx950 HIP kernels,
+prismarine-core_amd/csrc); this package is plumbing: ctypes signatures and the call order of
+psm::RadixSort / psm::TriangleHierarchy / psm::Pipeline.
+
+There is no CPU fallback: importing works anywhere (so the library's exports can be checked), but
+every compute entry point needs a gfx950 device and raises PsmError otherwise.
+
+The directory name contains a hyphen; import it with
+    importlib.import_module("prismarine-core_amd")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsm_hip.so")
+
+EXPORTS = [
+    "psm_device_count", "psm_ctx_create", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
+    "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
+    "psm_sort_u64_u32", "psm_sort_u64_u32_dev",
+    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_build",
+    "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
+    "psm_bvh_stage_emit", "psm_bvh_download",
+    "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile",
+    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
+    "psm_rt_traverse", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_download_rays", "psm_rt_download_hits",
+    "psm_rt_upload_rays", "psm_rt_download_texels",
+    "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
+]
+
+(BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
+ BVH_SORTED_TRI) = range(8)
+
+RAY_DT = np.dtype([("origin", "<f4", 3), ("direct", "<f4", 3), ("color", "<f4", 3),
+                   ("bitfield", "<i4"), ("texel", "<i4"), ("pkey", "<u4")])
+HIT_DT = np.dtype([("u", "<f4"), ("v", "<f4"), ("t", "<f4"), ("tri", "<i4")])
+LIGHT_DT = np.dtype([("lightVector", "<f4", 4), ("lightColor", "<f4", 4),
+                     ("lightOffset", "<f4", 4), ("lightAmbient", "<f4", 4)])
+
+
+class PsmError(RuntimeError):
+    pass
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("triangle_count", C.c_uint32), ("leaf_count", C.c_uint32), ("root", C.c_int32),
+                ("transform", C.c_float * 16), ("bounds_min", C.c_float * 4), ("bounds_max", C.c_float * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_traced", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("stack_drops", C.c_uint64), ("iter_caps", C.c_uint64), ("baked_drops", C.c_uint64),
+                ("chain_pool_drops", C.c_uint64), ("ray_limit_drops", C.c_uint64),
+                ("traverse_launches", C.c_uint32), ("traverse_ms", C.c_float), ("build_ms", C.c_float),
+                ("sort_ms", C.c_float), ("shade_ms", C.c_float), ("camera_ms", C.c_float),
+                ("sample_ms", C.c_float), ("rounds", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libpsm_hip.so (built by __graft_entry__.build()). Fails loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PsmError("libpsm_hip.so is missing at %s -- run `make -C prismarine-core_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.psm_last_error.restype = C.c_char_p
+        _lib.psm_ctx_stream.restype = C.c_void_p
+        for name in EXPORTS:
+            getattr(_lib, name)  # AttributeError if an export is missing
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU, one in-order stream (the reference's single GL context, Viewer.cpp:371)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().psm_ctx_create(C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise PsmError("psm_ctx_create(device=%d) failed with %d: a gfx950 (MI355X) device is required; "
+                           "there is no CPU fallback" % (device, rc))
+        self.device = device
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            msg = lib().psm_last_error(self._h)
+            raise PsmError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def sync(self):
+        self.check(lib().psm_ctx_sync(self._h), "psm_ctx_sync")
+
+    @property
+    def stream(self):
+        return lib().psm_ctx_stream(self._h)
+
+    def stats_enable(self, timing=True, counting=False):
+        self.check(lib().psm_stats_enable(self._h, C.c_int(int(timing)), C.c_int(int(counting))), "psm_stats_enable")
+
+    def stats_reset(self):
+        self.check(lib().psm_stats_reset(self._h), "psm_stats_reset")
+
+    def stats(self):
+        s = Stats()
+        self.check(lib().psm_stats_get(self._h, C.byref(s)), "psm_stats_get")
+        return s
+
+    def close(self):
+        if self._h:
+            lib().psm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    # buffers (the GLuint names the header layer passes around, Utils.hpp:140-150)
+    def buf_alloc(self, nbytes):
+        h = C.c_uint32()
+        self.check(lib().psm_buf_alloc(self._h, C.c_size_t(nbytes), C.byref(h)), "psm_buf_alloc")
+        return h.value
+
+    def buf_free(self, h):
+        self.check(lib().psm_buf_free(self._h, C.c_uint32(h)), "psm_buf_free")
+
+    def buf_upload(self, h, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        self.check(lib().psm_buf_upload(self._h, C.c_uint32(h), C.c_size_t(offset), _p(arr), C.c_size_t(arr.nbytes)),
+                   "psm_buf_upload")
+
+    def buf_download(self, h, dtype, count, offset=0):
+        out = np.zeros(count, dtype)
+        self.check(lib().psm_buf_download(self._h, C.c_uint32(h), C.c_size_t(offset), _p(out), C.c_size_t(out.nbytes)),
+                   "psm_buf_download")
+        return out
+
+
+class RadixSort:
+    """psm::RadixSort (Include/Prismarine/Radix.hpp:27-74)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def sort(self, keys_handle, vals_handle, size=1, descending=0):
+        # `descending` is accepted and ignored like the reference's shaders do (radix/includes.glsl:50-55)
+        self.ctx.check(lib().psm_sort_u64_u32(self.ctx._h, C.c_uint32(keys_handle), C.c_uint32(vals_handle),
+                                              C.c_uint32(size)), "psm_sort_u64_u32")
+
+    def sort_arrays(self, keys, vals):
+        """Convenience: host arrays in, sorted host arrays out."""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        vals = np.ascontiguousarray(vals, np.uint32)
+        n = keys.shape[0]
+        hk = self.ctx.buf_alloc(max(n, 1) * 8)
+        hv = self.ctx.buf_alloc(max(n, 1) * 4)
+        try:
+            if n:
+                self.ctx.buf_upload(hk, keys)
+                self.ctx.buf_upload(hv, vals)
+            self.sort(hk, hv, n)
+            return self.ctx.buf_download(hk, np.uint64, n), self.ctx.buf_download(hv, np.uint32, n)
+        finally:
+            self.ctx.buf_free(hk)
+            self.ctx.buf_free(hv)
+
+
+class TriangleHierarchy:
+    """psm::TriangleHierarchy (Include/Prismarine/TriangleHierarchy.hpp:75-94)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self.triangleCount = 0
+        self.materialID = 0
+        self._dirty = False
+        self.maxt = 0
+
+    def allocate(self, count):
+        if self._h:
+            lib().psm_bvh_destroy(self._h)
+            self._h = C.c_void_p()
+        self.ctx.check(lib().psm_bvh_create(self.ctx._h, C.c_size_t(count), C.byref(self._h)), "psm_bvh_create")
+        self.maxt = count
+        self.clearTribuffer()
+
+    def clearTribuffer(self):
+        self.markDirty()
+        self.ctx.check(lib().psm_bvh_clear(self._h), "psm_bvh_clear")
+        self.triangleCount = 0
+
+    def setMaterialID(self, mid):
+        self.materialID = mid
+
+    def loadTriangles(self, tris, normals=None, mats=None):
+        """loadMesh() reduced to its result: append world-space triangles (loader.comp:115-135)."""
+        tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+        n = tris.shape[0]
+        nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 9)
+        mm = None if mats is None else np.ascontiguousarray(mats, np.int32)
+        self.ctx.check(lib().psm_bvh_load_triangles(self._h, _p(tris), _p(nrm) if nrm is not None else None,
+                                                    _p(mm) if mm is not None else None, C.c_size_t(n),
+                                                    C.c_int32(self.materialID)), "psm_bvh_load_triangles")
+        self.triangleCount += n
+        self.markDirty()
+
+    def isDirty(self):
+        return self._dirty
+
+    def markDirty(self):
+        self._dirty = True
+
+    def resolve(self):
+        self._dirty = False
+
+    def build(self, optimization=None):
+        if self.triangleCount <= 0 or not self._dirty:  # TriangleHierarchy.inl:214
+            return
+        opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
+        self.ctx.check(lib().psm_bvh_build(self._h, _p(opt) if opt is not None else None), "psm_bvh_build")
+        self.resolve()
+
+    def stage(self, name, optimization=None):
+        if name == "bounds":
+            opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
+            rc = lib().psm_bvh_stage_bounds(self._h, _p(opt) if opt is not None else None)
+        else:
+            rc = getattr(lib(), "psm_bvh_stage_" + name)(self._h)
+        self.ctx.check(rc, "psm_bvh_stage_" + name)
+
+    def info(self):
+        i = BvhInfo()
+        self.ctx.check(lib().psm_bvh_get_info(self._h, C.byref(i)), "psm_bvh_get_info")
+        return i
+
+    def download(self, what, dtype, count):
+        out = np.zeros(count, dtype)
+        if count:
+            self.ctx.check(lib().psm_bvh_download(self._h, C.c_int(what), _p(out), C.c_size_t(out.nbytes)),
+                           "psm_bvh_download")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().psm_bvh_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class MaterialSet:
+    """psm::MaterialSet (Include/Prismarine/MaterialSet.hpp:28-41): a host-side material array."""
+
+    def __init__(self):
+        self.submats = []
+        self.loadOffset = 0
+
+    def addSubmat(self, m):
+        self.submats.append(m)
+        return len(self.submats) - 1
+
+    def setSumbat(self, i, m):
+        while len(self.submats) <= i:
+            self.submats.append(dict(self.submats[-1]) if self.submats else m)
+        self.submats[i] = m
+
+    def clearSubmats(self):
+        self.submats = []
+
+    def getMaterialCount(self):
+        return len(self.submats)
+
+    def setLoadingOffset(self, off):
+        self.loadOffset = off
+
+    def loadToVGA(self):
+        pass  # uploaded by Pipeline.applyMaterials
+
+
+class Pipeline:
+    """psm::Pipeline (Include/Prismarine/Pipeline.hpp:84-137)."""
+
+    def __init__(self, ctx, seed=1):
+        from . import scenes as _sc
+        self._sc = _sc
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        ctx.check(lib().psm_rt_create(ctx._h, C.byref(self._h)), "psm_rt_create")
+        self.width = self.height = self.displayWidth = self.displayHeight = 256  # Pipeline.hpp:87-90
+        self.raycountCache = 0
+        self._rand_state = seed & 0xFFFFFFFF
+        self._mat_sig = None
+        self.resizeBuffers(256, 256)
+        self.resize(256, 256)
+
+    # host rand() of Pipeline.inl:282,426 made explicit: the MSVC CRT LCG, seedable
+    def setSeed(self, seed):
+        self._rand_state = seed & 0xFFFFFFFF
+
+    def _rand(self):
+        self._rand_state = (self._rand_state * 214013 + 2531011) & 0xFFFFFFFF
+        return (self._rand_state >> 16) & 0x7FFF
+
+    def resizeBuffers(self, w, h):
+        self.width, self.height = w, h
+        self.ctx.check(lib().psm_rt_resize_buffers(self._h, C.c_uint32(w), C.c_uint32(h)), "psm_rt_resize_buffers")
+
+    def resize(self, w, h):
+        self.displayWidth, self.displayHeight = w, h
+        self.ctx.check(lib().psm_rt_resize(self._h, C.c_uint32(w), C.c_uint32(h)), "psm_rt_resize")
+
+    def setTile(self, y0, y1):
+        self.ctx.check(lib().psm_rt_set_tile(self._h, C.c_uint32(y0), C.c_uint32(y1)), "psm_rt_set_tile")
+
+    def setLights(self, lights):
+        lights = np.ascontiguousarray(lights, LIGHT_DT)
+        self.ctx.check(lib().psm_rt_set_lights(self._h, _p(lights), C.c_uint32(lights.shape[0])), "psm_rt_set_lights")
+
+    def setSky(self, rgb):
+        a = np.asarray(list(rgb)[:3] + [1.0], np.float32)
+        self.ctx.check(lib().psm_rt_set_sky(self._h, _p(a)), "psm_rt_set_sky")
+
+    def setSkybox(self, handle):
+        self._skybox = handle  # equirect lookup is a later row; constant sky until then
+
+    def clearSampler(self):
+        self.ctx.check(lib().psm_rt_clear_sampler(self._h), "psm_rt_clear_sampler")
+
+    def camera_matrices(self, cam_inv, proj_inv, time=None):
+        t = self._rand() if time is None else time
+        ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
+        pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
+        self.ctx.check(lib().psm_rt_camera(self._h, _p(ci), _p(pi), C.c_uint32(t)), "psm_rt_camera")
+        self._reload()
+
+    def camera(self, eye, view):
+        ci, pi = self._sc.camera_matrices(eye, view, self.displayWidth, self.displayHeight)
+        self.camera_matrices(ci, pi)
+
+    def _reload(self):
+        n = C.c_int32()
+        self.ctx.check(lib().psm_rt_ray_count(self._h, C.byref(n)), "psm_rt_ray_count")
+        self.raycountCache = n.value
+
+    def getRayCount(self):
+        return self.raycountCache if self.raycountCache >= 32 else 0  # Pipeline.inl:459-461
+
+    def intersection(self, obj, clearDepth=0, force=False):
+        """force=True skips the local >=32 rule (tile-sharded frames decide on the global count)."""
+        if obj is None or obj.triangleCount <= 0:
+            return 0
+        if (self.raycountCache if force else self.getRayCount()) <= 0:
+            return 0
+        self._obj = obj
+        self.ctx.check(lib().psm_rt_traverse(self._h, obj._h), "psm_rt_traverse")
+        return 1
+
+    def applyMaterials(self, mat):
+        sig = (id(mat), len(mat.submats), mat.loadOffset)
+        if sig != self._mat_sig:
+            arr = self._sc.materials_array(mat.submats)
+            self.ctx.check(lib().psm_rt_set_materials(self._h, _p(arr), C.c_uint32(arr.shape[0]),
+                                                      C.c_int32(mat.loadOffset)), "psm_rt_set_materials")
+            self._mat_sig = sig
+
+    def shade(self, time=None, force=False):
+        if not force and self.getRayCount() <= 0:
+            return
+        t = self._rand() if time is None else time  # drawn every round so sharded ranks stay in step
+        if self.raycountCache <= 0:
+            return
+        self.ctx.check(lib().psm_rt_shade(self._h, self._obj._h, C.c_uint32(t)), "psm_rt_shade")
+        self._reload()
+
+    def reclaim(self):
+        pass  # Pipeline.inl:361-369 is a no-op
+
+    def sample(self):
+        self.ctx.check(lib().psm_rt_sample(self._h), "psm_rt_sample")
+
+    def render(self):
+        pass  # display quad: out of scope (render.vert/frag)
+
+    def snapHdr(self, raw=False):
+        out = np.zeros((self.displayHeight, self.displayWidth, 4), np.float32)
+        self.ctx.check(lib().psm_rt_snap(self._h, _p(out), C.c_int(int(raw))), "psm_rt_snap")
+        return out
+
+    def snapRawHdr(self):
+        return self.snapHdr(True)
+
+    # parity / debug access
+    def download_rays(self):
+        n = self.raycountCache
+        out = np.zeros(max(n, 1), RAY_DT)
+        cnt = C.c_uint32()
+        self.ctx.check(lib().psm_rt_download_rays(self._h, _p(out), C.c_uint32(n), C.byref(cnt)), "psm_rt_download_rays")
+        return out[:n]
+
+    def upload_rays(self, rays):
+        rays = np.ascontiguousarray(rays, RAY_DT)
+        self.ctx.check(lib().psm_rt_upload_rays(self._h, _p(rays), C.c_uint32(rays.shape[0])), "psm_rt_upload_rays")
+        self.raycountCache = rays.shape[0]
+
+    def download_hits(self, n):
+        hits = np.zeros((max(n, 1), 8), HIT_DT)
+        counts = np.zeros(max(n, 1), np.int32)
+        self.ctx.check(lib().psm_rt_download_hits(self._h, _p(hits), _p(counts), C.c_uint32(n)), "psm_rt_download_hits")
+        return hits[:n], counts[:n]
+
+    def download_texels(self):
+        wh = self.width * self.height
+        s = np.zeros((wh, 4), np.float32)
+        c = np.zeros((wh, 2), np.float32)
+        f = np.zeros(wh, np.int32)
+        self.ctx.check(lib().psm_rt_download_texels(self._h, _p(s), _p(c), _p(f)), "psm_rt_download_texels")
+        return s, c, f
+
+    def get_texels_dev(self, y0, y1, dev_ptr):
+        self.ctx.check(lib().psm_rt_get_texels_dev(self._h, C.c_uint32(y0), C.c_uint32(y1), C.c_void_p(dev_ptr)),
+                       "psm_rt_get_texels_dev")
+
+    def set_texels_dev(self, y0, y1, dev_ptr):
+        self.ctx.check(lib().psm_rt_set_texels_dev(self._h, C.c_uint32(y0), C.c_uint32(y1), C.c_void_p(dev_ptr)),
+                       "psm_rt_set_texels_dev")
+
+    def close(self):
+        if self._h:
+            lib().psm_rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def sharded_rounds(rays, intersector, materials, depth=16):
+    """The bounce loop of Viewer.cpp:304-310 for one tile of a sharded frame, as a generator: yields
+    the local ray count and is sent the GLOBAL count (sum over tiles), so the reference's
+    `getRayCount() < 32 -> stop` rule (Pipeline.inl:459-461) is applied to the whole frame and the
+    sharded image equals the unsharded one."""
+    rays.applyMaterials(materials)
+    for _ in range(depth):
+        total = yield rays.raycountCache
+        if total < 32:
+            break
+        rays.intersection(intersector, force=True)
+        rays.shade(force=True)
+        rays.reclaim()
+
+
+def render_frame(rays, intersector, materials, eye, view, depth=16):
+    """GltfViewer::process(), Source/Examples/Viewer.cpp:296-312 (minus display)."""
+    materials.loadToVGA()
+    intersector.markDirty()
+    intersector.build()
+    rays.camera(eye, view)
+    rounds = 0
+    for _ in range(depth):
+        if rays.getRayCount() <= 0:
+            break
+        rays.intersection(intersector)
+        rays.applyMaterials(materials)
+        rays.shade()
+        rays.reclaim()
+        rounds += 1
+    rays.sample()
+    rays.render()
+    return rounds

@@ -1,0 +1,724 @@
+// api.hip -- the C ABI of include/psm_hip.h: contexts, buffers, object lifetime, stage order.
+// Host logic only; the kernels live in sort.hip, bvh.hip, trace.hip, shade.hip.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "psm_common.h"
+#include "psm_internal.h"
+
+namespace psm {
+
+constexpr int SM_COUNT = 24;
+constexpr int SM_ROOT = 25;
+constexpr int SM_BFLOAT = 26;
+constexpr int SM_WORDS = 64;
+constexpr int SHADE_BLOCK = 256;
+
+int set_err(psm_ctx* c, int code, const char* what, hipError_t e) {
+    if (c) {
+        c->err = what ? what : "";
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+TimedScope::TimedScope(psm_ctx* ctx, int cat) : c(ctx) {
+    if (!c->timing) return;
+    psm_ctx::Timed t;
+    for (hipEvent_t* ev : {&t.a, &t.b}) {
+        if (!c->free_events.empty()) {
+            *ev = c->free_events.back();
+            c->free_events.pop_back();
+        } else if (hipEventCreate(ev) != hipSuccess) {
+            return;
+        }
+    }
+    t.cat = cat;
+    (void)hipEventRecord(t.a, c->stream);
+    c->timed.push_back(t);
+    idx = (int)c->timed.size() - 1;
+}
+TimedScope::~TimedScope() {
+    if (idx >= 0) (void)hipEventRecord(c->timed[(size_t)idx].b, c->stream);
+}
+
+static void collect_timing(psm_ctx* c) {
+    for (auto& t : c->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            c->cat_ms[t.cat] += ms;
+            c->cat_launches[t.cat]++;
+        }
+        c->free_events.push_back(t.a);
+        c->free_events.push_back(t.b);
+    }
+    c->timed.clear();
+}
+
+template <typename T>
+static int dev_alloc(psm_ctx* c, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    PSM_HIP(c, hipMalloc((void**)p, count * sizeof(T)));
+    return PSM_OK;
+}
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace psm
+
+using namespace psm;
+
+extern "C" {
+
+int psm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int psm_ctx_create(int device, psm_ctx** out) {
+    if (!out) return PSM_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PSM_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return PSM_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PSM_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "psm: device %d is %s; this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return PSM_ERR_NO_DEVICE;
+    }
+    psm_ctx* c = new (std::nothrow) psm_ctx();
+    if (!c) return PSM_ERR_INVALID;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, sizeof(DevCounters)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream) != hipSuccess) {
+        delete c;
+        return PSM_ERR_HIP;
+    }
+    *out = c;
+    return PSM_OK;
+}
+
+int psm_ctx_destroy(psm_ctx* c) {
+    if (!c) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_timing(c);
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    for (auto& b : c->bufs) if (b.ptr) (void)hipFree(b.ptr);
+    dev_free(c->sort_keys_tmp);
+    dev_free(c->sort_vals_tmp);
+    dev_free(c->sort_hist);
+    dev_free(c->d_counters);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PSM_OK;
+}
+
+int psm_ctx_sync(psm_ctx* c) {
+    if (!c) return PSM_ERR_INVALID;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return PSM_OK;
+}
+void* psm_ctx_stream(psm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+const char* psm_last_error(psm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ---- buffers ------------------------------------------------------------------------------------
+int psm_buf_alloc(psm_ctx* c, size_t bytes, uint32_t* handle) {
+    if (!c || !handle) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    Buf b;
+    b.bytes = bytes;
+    PSM_HIP(c, hipMalloc(&b.ptr, bytes ? bytes : 1));
+    for (size_t i = 0; i < c->bufs.size(); i++) {
+        if (!c->bufs[i].ptr) {
+            c->bufs[i] = b;
+            *handle = (uint32_t)i + 1;
+            return PSM_OK;
+        }
+    }
+    c->bufs.push_back(b);
+    *handle = (uint32_t)c->bufs.size();
+    return PSM_OK;
+}
+static Buf* get_buf(psm_ctx* c, uint32_t h) {
+    if (!c || h == 0 || h > c->bufs.size() || !c->bufs[h - 1].ptr) return nullptr;
+    return &c->bufs[h - 1];
+}
+int psm_buf_free(psm_ctx* c, uint32_t h) {
+    Buf* b = get_buf(c, h);
+    if (!b) return c ? set_err(c, PSM_ERR_INVALID, "psm_buf_free: bad handle") : PSM_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(b->ptr);
+    b->ptr = nullptr;
+    b->bytes = 0;
+    return PSM_OK;
+}
+int psm_buf_upload(psm_ctx* c, uint32_t h, size_t offset, const void* src, size_t bytes) {
+    Buf* b = get_buf(c, h);
+    if (!b || !src || offset + bytes > b->bytes) return c ? set_err(c, PSM_ERR_INVALID, "psm_buf_upload: bad handle or range") : PSM_ERR_INVALID;
+    PSM_HIP(c, hipMemcpyAsync((char*)b->ptr + offset, src, bytes, hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));  // src may be pageable host memory
+    return PSM_OK;
+}
+int psm_buf_download(psm_ctx* c, uint32_t h, size_t offset, void* dst, size_t bytes) {
+    Buf* b = get_buf(c, h);
+    if (!b || !dst || offset + bytes > b->bytes) return c ? set_err(c, PSM_ERR_INVALID, "psm_buf_download: bad handle or range") : PSM_ERR_INVALID;
+    PSM_HIP(c, hipMemcpyAsync(dst, (char*)b->ptr + offset, bytes, hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return PSM_OK;
+}
+int psm_buf_ptr(psm_ctx* c, uint32_t h, void** p, size_t* bytes) {
+    Buf* b = get_buf(c, h);
+    if (!b) return c ? set_err(c, PSM_ERR_INVALID, "psm_buf_ptr: bad handle") : PSM_ERR_INVALID;
+    if (p) *p = b->ptr;
+    if (bytes) *bytes = b->bytes;
+    return PSM_OK;
+}
+
+// ---- sort -----------------------------------------------------------------------------------------
+int psm_sort_u64_u32_dev(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n) {
+    if (!c || (n && (!d_keys || !d_vals))) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    return launch_sort(c, d_keys, d_vals, n, nullptr);
+}
+int psm_sort_u64_u32(psm_ctx* c, uint32_t hk, uint32_t hv, uint32_t n) {
+    Buf* k = get_buf(c, hk);
+    Buf* v = get_buf(c, hv);
+    if (!k || !v) return c ? set_err(c, PSM_ERR_INVALID, "psm_sort: bad handle") : PSM_ERR_INVALID;
+    if ((size_t)n * 8 > k->bytes || (size_t)n * 4 > v->bytes) return set_err(c, PSM_ERR_CAPACITY, "psm_sort: n exceeds buffer");
+    return psm_sort_u64_u32_dev(c, (uint64_t*)k->ptr, (uint32_t*)v->ptr, n);
+}
+
+// ---- TriangleHierarchy ----------------------------------------------------------------------------
+int psm_bvh_destroy(psm_bvh* b) {
+    if (!b) return PSM_ERR_INVALID;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    dev_free(b->d_pos); dev_free(b->d_nrm); dev_free(b->d_mats); dev_free(b->d_tri48);
+    dev_free(b->d_keys); dev_free(b->d_idx); dev_free(b->d_leafbox); dev_free(b->d_leaftri);
+    dev_free(b->d_block); dev_free(b->d_small); dev_free(b->d_opt); dev_free(b->d_seg);
+    dev_free(b->d_sorted_tri); dev_free(b->d_pairbox); dev_free(b->d_link); dev_free(b->d_range);
+    delete b;
+    return PSM_OK;
+}
+
+int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
+    if (!c || !out || max_tris == 0) return PSM_ERR_INVALID;
+    if (max_tris > 0x7FFFFF00ull / 9) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_create: max_tris exceeds 32-bit indexing");
+    (void)hipSetDevice(c->device);
+    psm_bvh* b = new (std::nothrow) psm_bvh();
+    if (!b) return PSM_ERR_INVALID;
+    b->ctx = c;
+    b->cap = max_tris;
+    size_t n = max_tris;
+    // segment tree level offsets: level L has ceil(n / 2^L) entries
+    size_t off = 0;
+    for (size_t cnt = n;; cnt = (cnt + 1) / 2) {
+        b->seg_off.push_back(off);
+        off += cnt;
+        if (cnt == 1) break;
+    }
+    b->seg_off.push_back(off);
+    int rc = PSM_OK;
+    auto A = [&](int r) { if (rc == PSM_OK) rc = r; };
+    A(dev_alloc(c, &b->d_pos, 9 * n)); A(dev_alloc(c, &b->d_nrm, 9 * n)); A(dev_alloc(c, &b->d_mats, n));
+    A(dev_alloc(c, &b->d_tri48, 3 * n)); A(dev_alloc(c, &b->d_keys, n)); A(dev_alloc(c, &b->d_idx, n));
+    A(dev_alloc(c, &b->d_leafbox, n)); A(dev_alloc(c, &b->d_leaftri, n));
+    A(dev_alloc(c, &b->d_block, (n + 255) / 256 + 1)); A(dev_alloc(c, &b->d_small, (size_t)SM_WORDS));
+    A(dev_alloc(c, &b->d_opt, (size_t)16)); A(dev_alloc(c, &b->d_seg, off));
+    A(dev_alloc(c, &b->d_sorted_tri, n)); A(dev_alloc(c, &b->d_pairbox, 2 * n)); A(dev_alloc(c, &b->d_link, n));
+    A(dev_alloc(c, &b->d_range, n));
+    if (rc != PSM_OK) { psm_bvh_destroy(b); return rc; }
+    if (hipMemsetAsync(b->d_small, 0, SM_WORDS * 4, c->stream) != hipSuccess) { psm_bvh_destroy(b); return PSM_ERR_HIP; }
+    *out = b;
+    return PSM_OK;
+}
+
+int psm_bvh_clear(psm_bvh* b) {
+    if (!b) return PSM_ERR_INVALID;
+    b->tri_count = 0;
+    b->built = b->bounds_done = b->morton_done = b->sort_done = false;
+    return PSM_OK;
+}
+
+int psm_bvh_load_triangles(psm_bvh* b, const float* positions, const float* normals, const int32_t* mats, size_t n,
+                           int32_t material_id) {
+    if (!b || (n && !positions)) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    if (b->tri_count + n > b->cap) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_load_triangles: exceeds allocate() capacity");
+    if (n == 0) return PSM_OK;
+    uint32_t first = b->tri_count;
+    PSM_HIP(c, hipMemcpyAsync(b->d_pos + (size_t)9 * first, positions, n * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    std::vector<float> fn;
+    if (!normals) {
+        // loader.comp:119-128: no normal accessor -> normalize(normalize(cross(v1-v0, v2-v0)))
+        fn.resize(n * 9);
+        for (size_t t = 0; t < n; t++) {
+            const float* p = positions + 9 * t;
+            v3 e1 = mk3(p[3] - p[0], p[4] - p[1], p[5] - p[2]), e2 = mk3(p[6] - p[0], p[7] - p[1], p[8] - p[2]);
+            v3 nn = normalize3(normalize3(cross3(e1, e2)));
+            for (int k = 0; k < 3; k++) { fn[9 * t + 3 * k] = nn.x; fn[9 * t + 3 * k + 1] = nn.y; fn[9 * t + 3 * k + 2] = nn.z; }
+        }
+        normals = fn.data();
+    }
+    PSM_HIP(c, hipMemcpyAsync(b->d_nrm + (size_t)9 * first, normals, n * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    std::vector<int32_t> mm;
+    if (!mats) { mm.assign(n, material_id); mats = mm.data(); }
+    PSM_HIP(c, hipMemcpyAsync(b->d_mats + first, mats, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));  // sources may be pageable / temporaries
+    b->tri_count += (uint32_t)n;
+    b->built = b->bounds_done = b->morton_done = b->sort_done = false;
+    return launch_bvh_prepare_tris(b, first, (uint32_t)n);
+}
+
+int psm_bvh_stage_bounds(psm_bvh* b, const double* opt) {
+    if (!b) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    if (b->tri_count == 0) return set_err(c, PSM_ERR_STATE, "build: no triangles");
+    static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    PSM_HIP(c, hipMemcpyAsync(b->d_opt, opt ? opt : ident, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (opt) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = launch_bvh_bounds(b);
+    if (rc == PSM_OK) b->bounds_done = true;
+    return rc;
+}
+int psm_bvh_stage_morton(psm_bvh* b) {
+    if (!b) return PSM_ERR_INVALID;
+    (void)hipSetDevice(b->ctx->device);
+    if (!b->bounds_done) return set_err(b->ctx, PSM_ERR_STATE, "morton before bounds");
+    int rc = launch_bvh_morton(b);
+    if (rc == PSM_OK) b->morton_done = true;
+    return rc;
+}
+int psm_bvh_stage_sort(psm_bvh* b) {
+    if (!b) return PSM_ERR_INVALID;
+    (void)hipSetDevice(b->ctx->device);
+    if (!b->morton_done) return set_err(b->ctx, PSM_ERR_STATE, "sort before morton");
+    int rc = launch_sort(b->ctx, b->d_keys, b->d_idx, b->tri_count, b->d_small + SM_COUNT);
+    if (rc == PSM_OK) b->sort_done = true;
+    return rc;
+}
+int psm_bvh_stage_emit(psm_bvh* b) {
+    if (!b) return PSM_ERR_INVALID;
+    (void)hipSetDevice(b->ctx->device);
+    if (!b->sort_done) return set_err(b->ctx, PSM_ERR_STATE, "emit before sort");
+    int rc = launch_bvh_emit(b);
+    if (rc == PSM_OK) b->built = true;
+    return rc;
+}
+int psm_bvh_build(psm_bvh* b, const double* opt) {
+    if (!b) return PSM_ERR_INVALID;
+    TimedScope ts(b->ctx, CAT_BUILD);
+    int rc = psm_bvh_stage_bounds(b, opt);
+    if (rc == PSM_OK) rc = psm_bvh_stage_morton(b);
+    if (rc == PSM_OK) rc = psm_bvh_stage_sort(b);
+    if (rc == PSM_OK) rc = psm_bvh_stage_emit(b);
+    return rc;
+}
+
+int psm_bvh_get_info(psm_bvh* b, psm_bvh_info* info) {
+    if (!b || !info) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    uint32_t sm[SM_WORDS];
+    PSM_HIP(c, hipMemcpyAsync(sm, b->d_small, sizeof(sm), hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    info->triangle_count = b->tri_count;
+    info->leaf_count = sm[SM_COUNT];
+    info->root = (int32_t)sm[SM_ROOT];
+    std::memcpy(info->transform, sm, 16 * sizeof(float));
+    std::memcpy(info->bounds_min, sm + SM_BFLOAT, 4 * sizeof(float));
+    std::memcpy(info->bounds_max, sm + SM_BFLOAT + 4, 4 * sizeof(float));
+    return PSM_OK;
+}
+
+int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
+    if (!b || !dst) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    const void* src = nullptr;
+    size_t elem = 0;
+    switch (what) {
+        case PSM_BVH_KEYS: src = b->d_keys; elem = 8; break;
+        case PSM_BVH_INDICES: src = b->d_idx; elem = 4; break;
+        case PSM_BVH_LEAF_BOX: src = b->d_leafbox; elem = 16; break;
+        case PSM_BVH_LEAF_TRI: src = b->d_leaftri; elem = 4; break;
+        case PSM_BVH_PAIR_BOX: src = b->d_pairbox; elem = 32; break;
+        case PSM_BVH_LINK: src = b->d_link; elem = 8; break;
+        case PSM_BVH_RANGE: src = b->d_range; elem = 8; break;
+        case PSM_BVH_SORTED_TRI: src = b->d_sorted_tri; elem = 4; break;
+        default: return set_err(c, PSM_ERR_INVALID, "psm_bvh_download: unknown item");
+    }
+    if (bytes > b->cap * elem) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_download: too many bytes");
+    PSM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return PSM_OK;
+}
+
+// ---- Pipeline -----------------------------------------------------------------------------------
+static void rt_free_grid(psm_rt* r) {
+    for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); }
+    dev_free(r->sA); dev_free(r->sB); dev_free(r->sC); dev_free(r->d_block);
+    dev_free(r->hit0); dev_free(r->hitN); dev_free(r->pool);
+    dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag);
+}
+
+int psm_rt_destroy(psm_rt* r) {
+    if (!r) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    rt_free_grid(r);
+    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt);
+    delete r;
+    return PSM_OK;
+}
+
+int psm_rt_create(psm_ctx* c, psm_rt** out) {
+    if (!c || !out) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    psm_rt* r = new (std::nothrow) psm_rt();
+    if (!r) return PSM_ERR_INVALID;
+    r->ctx = c;
+    int rc = dev_alloc(c, &r->d_cnt, (size_t)8);
+    if (rc == PSM_OK) rc = dev_alloc(c, &r->d_lights, (size_t)16);
+    if (rc != PSM_OK) { psm_rt_destroy(r); return rc; }
+    (void)hipMemsetAsync(r->d_cnt, 0, 32, c->stream);
+    // default sun, Pipeline.inl:93-98
+    psm_light L[16];
+    std::memset(L, 0, sizeof(L));
+    for (int i = 0; i < 16; i++) {
+        L[i].lightColor[0] = (255.f / 255.f) * 150.f;
+        L[i].lightColor[1] = (250.f / 255.f) * 150.f;
+        L[i].lightColor[2] = (244.f / 255.f) * 150.f;
+        L[i].lightColor[3] = 40.0f;
+        L[i].lightVector[0] = 0.3f; L[i].lightVector[1] = 1.0f; L[i].lightVector[2] = 0.1f; L[i].lightVector[3] = 400.0f;
+    }
+    if (hipMemcpyAsync(r->d_lights, L, sizeof(L), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { psm_rt_destroy(r); return PSM_ERR_HIP; }
+    *out = r;
+    return PSM_OK;
+}
+
+int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
+    if (!r || w == 0 || h == 0) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    rt_free_grid(r);
+    r->w = w; r->h = h; r->y0 = 0; r->y1 = h;
+    uint64_t wr = (uint64_t)w * h;
+    uint64_t lim = std::min<uint64_t>(wr * 4, 4096ull * 4096ull);  // Pipeline.inl:187-189
+    r->limit = (uint32_t)lim;
+    size_t L = r->limit;
+    size_t nb = (L + SHADE_BLOCK - 1) / SHADE_BLOCK;
+    int rc = PSM_OK;
+    auto A = [&](int x) { if (rc == PSM_OK) rc = x; };
+    for (int q = 0; q < 2; q++) { A(dev_alloc(c, &r->qA[q], L)); A(dev_alloc(c, &r->qB[q], L)); A(dev_alloc(c, &r->qC[q], L)); }
+    A(dev_alloc(c, &r->sA, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sB, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sC, nb * SHADE_BLOCK * 4));
+    A(dev_alloc(c, &r->d_block, 2 * nb + 2));
+    A(dev_alloc(c, &r->hit0, L)); A(dev_alloc(c, &r->hitN, L));
+    r->pool_cap = (uint32_t)std::max<size_t>(L / 2, 1024);  // hits buffer = L/2 in the reference, Pipeline.inl:193
+    A(dev_alloc(c, &r->pool, (size_t)r->pool_cap));
+    A(dev_alloc(c, &r->t_coord, (size_t)wr)); A(dev_alloc(c, &r->t_sum, (size_t)wr)); A(dev_alloc(c, &r->t_flag, (size_t)wr));
+    if (rc != PSM_OK) return rc;
+    PSM_HIP(c, hipMemsetAsync(r->t_sum, 0, wr * sizeof(float4), c->stream));
+    PSM_HIP(c, hipMemsetAsync(r->t_flag, 0, wr * sizeof(int32_t), c->stream));
+    PSM_HIP(c, hipMemsetAsync(r->t_coord, 0, wr * sizeof(float2), c->stream));
+    PSM_HIP(c, hipMemsetAsync(r->d_cnt, 0, 32, c->stream));
+    r->ray_count = 0; r->count_valid = true; r->cur = 0;
+    if (r->dw == 0) return psm_rt_resize(r, w, h);
+    return PSM_OK;
+}
+
+int psm_rt_resize(psm_rt* r, uint32_t dw, uint32_t dh) {
+    if (!r || dw == 0 || dh == 0) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    dev_free(r->presampled); dev_free(r->filtered);
+    r->dw = dw; r->dh = dh;
+    int rc = dev_alloc(c, &r->presampled, (size_t)dw * dh);
+    if (rc == PSM_OK) rc = dev_alloc(c, &r->filtered, (size_t)dw * dh);
+    if (rc != PSM_OK) return rc;
+    return psm_rt_clear_sampler(r);
+}
+
+int psm_rt_clear_sampler(psm_rt* r) {
+    if (!r || !r->presampled) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipMemsetAsync(r->presampled, 0, (size_t)r->dw * r->dh * sizeof(float4), c->stream));
+    PSM_HIP(c, hipMemsetAsync(r->filtered, 0, (size_t)r->dw * r->dh * sizeof(float4), c->stream));
+    return PSM_OK;
+}
+
+int psm_rt_set_tile(psm_rt* r, uint32_t y0, uint32_t y1) {
+    if (!r || y0 > y1 || y1 > r->h) return PSM_ERR_INVALID;
+    r->y0 = y0; r->y1 = y1;
+    return PSM_OK;
+}
+
+int psm_rt_set_lights(psm_rt* r, const psm_light* lights, uint32_t count) {
+    if (!r || !lights || count == 0 || count > 16) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipMemcpyAsync(r->d_lights, lights, count * sizeof(psm_light), hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    r->light_count = count;
+    return PSM_OK;
+}
+
+int psm_rt_set_sky(psm_rt* r, const float rgba[4]) {
+    if (!r || !rgba) return PSM_ERR_INVALID;
+    for (int k = 0; k < 4; k++) r->sky[k] = rgba[k];
+    return PSM_OK;
+}
+
+int psm_rt_set_materials(psm_rt* r, const psm_material* mats, uint32_t count, int32_t load_offset) {
+    if (!r || (count && !mats)) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    dev_free(r->d_mats);
+    int rc = dev_alloc(c, &r->d_mats, (size_t)std::max<uint32_t>(count, 1));
+    if (rc != PSM_OK) return rc;
+    if (count) {
+        PSM_HIP(c, hipMemcpyAsync(r->d_mats, mats, count * sizeof(psm_material), hipMemcpyHostToDevice, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    r->mat_count = count;
+    r->mat_offset = load_offset;
+    return PSM_OK;
+}
+
+int psm_rt_camera(psm_rt* r, const float cam_inv[16], const float proj_inv[16], uint32_t time) {
+    if (!r || !cam_inv || !proj_inv) return PSM_ERR_INVALID;
+    if (!r->qA[0]) return set_err(r->ctx, PSM_ERR_STATE, "camera before resizeBuffers");
+    (void)hipSetDevice(r->ctx->device);
+    return launch_rt_camera(r, cam_inv, proj_inv, time);
+}
+
+int psm_rt_ray_count(psm_rt* r, int32_t* count) {
+    if (!r || !count) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    if (!r->count_valid) {
+        uint32_t v = 0;
+        PSM_HIP(c, hipMemcpyAsync(&v, r->d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+        r->ray_count = v;
+        r->count_valid = true;
+    }
+    *count = (int32_t)r->ray_count;
+    return PSM_OK;
+}
+
+int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
+    if (!r || !b) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    if (!b->built) return set_err(r->ctx, PSM_ERR_STATE, "traverse before build");
+    int32_t n;
+    int rc = psm_rt_ray_count(r, &n);
+    if (rc != PSM_OK) return rc;
+    return launch_rt_traverse(r, b);
+}
+
+int psm_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
+    if (!r || !b) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    if (!r->d_mats) return set_err(r->ctx, PSM_ERR_STATE, "shade before set_materials");
+    int32_t n;
+    int rc = psm_rt_ray_count(r, &n);
+    if (rc != PSM_OK) return rc;
+    return launch_rt_shade(r, b, time);
+}
+
+int psm_rt_sample(psm_rt* r) {
+    if (!r || !r->presampled || !r->t_sum) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    return launch_rt_sample(r);
+}
+
+int psm_rt_snap(psm_rt* r, float* rgba, int raw) {
+    if (!r || !rgba || !r->presampled) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipMemcpyAsync(rgba, raw ? r->presampled : r->filtered, (size_t)r->dw * r->dh * sizeof(float4),
+                              hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return PSM_OK;
+}
+
+int psm_rt_get_texels_dev(psm_rt* r, uint32_t y0, uint32_t y1, float* d_dst) {
+    if (!r || !d_dst || y0 > y1 || y1 > r->h) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipMemcpyAsync(d_dst, r->t_sum + (size_t)y0 * r->w, (size_t)(y1 - y0) * r->w * sizeof(float4),
+                              hipMemcpyDeviceToDevice, c->stream));
+    return PSM_OK;
+}
+int psm_rt_set_texels_dev(psm_rt* r, uint32_t y0, uint32_t y1, const float* d_src) {
+    if (!r || !d_src || y0 > y1 || y1 > r->h) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipMemcpyAsync(r->t_sum + (size_t)y0 * r->w, d_src, (size_t)(y1 - y0) * r->w * sizeof(float4),
+                              hipMemcpyDeviceToDevice, c->stream));
+    return PSM_OK;
+}
+
+int psm_rt_download_rays(psm_rt* r, psm_ray* dst, uint32_t max_rays, uint32_t* count) {
+    if (!r || !dst) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    int32_t n;
+    int rc = psm_rt_ray_count(r, &n);
+    if (rc != PSM_OK) return rc;
+    uint32_t m = std::min<uint32_t>((uint32_t)n, max_rays);
+    std::vector<float4> A(m), B(m), C(m);
+    if (m) {
+        PSM_HIP(c, hipMemcpyAsync(A.data(), r->qA[r->cur], m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipMemcpyAsync(B.data(), r->qB[r->cur], m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipMemcpyAsync(C.data(), r->qC[r->cur], m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    for (uint32_t i = 0; i < m; i++) {
+        dst[i].origin[0] = A[i].x; dst[i].origin[1] = A[i].y; dst[i].origin[2] = A[i].z;
+        dst[i].direct[0] = B[i].x; dst[i].direct[1] = B[i].y; dst[i].direct[2] = B[i].z;
+        dst[i].color[0] = C[i].x; dst[i].color[1] = C[i].y; dst[i].color[2] = C[i].z;
+        std::memcpy(&dst[i].texel, &A[i].w, 4);
+        std::memcpy(&dst[i].bitfield, &B[i].w, 4);
+        std::memcpy(&dst[i].pkey, &C[i].w, 4);
+    }
+    if (count) *count = (uint32_t)n;
+    return PSM_OK;
+}
+
+int psm_rt_upload_rays(psm_rt* r, const psm_ray* src, uint32_t count) {
+    if (!r || (count && !src)) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    if (!r->qA[0]) return set_err(c, PSM_ERR_STATE, "upload_rays before resizeBuffers");
+    if (count > r->limit) return set_err(c, PSM_ERR_CAPACITY, "upload_rays: exceeds currentRayLimit");
+    std::vector<float4> A(count), B(count), C(count);
+    for (uint32_t i = 0; i < count; i++) {
+        A[i].x = src[i].origin[0]; A[i].y = src[i].origin[1]; A[i].z = src[i].origin[2];
+        B[i].x = src[i].direct[0]; B[i].y = src[i].direct[1]; B[i].z = src[i].direct[2];
+        C[i].x = src[i].color[0]; C[i].y = src[i].color[1]; C[i].z = src[i].color[2];
+        std::memcpy(&A[i].w, &src[i].texel, 4);
+        std::memcpy(&B[i].w, &src[i].bitfield, 4);
+        std::memcpy(&C[i].w, &src[i].pkey, 4);
+    }
+    if (count) {
+        PSM_HIP(c, hipMemcpyAsync(r->qA[r->cur], A.data(), count * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        PSM_HIP(c, hipMemcpyAsync(r->qB[r->cur], B.data(), count * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        PSM_HIP(c, hipMemcpyAsync(r->qC[r->cur], C.data(), count * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    }
+    uint32_t cnt[3] = {count, 0, 0};
+    PSM_HIP(c, hipMemcpyAsync(r->d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    r->ray_count = count;
+    r->count_valid = true;
+    return PSM_OK;
+}
+
+int psm_rt_download_hits(psm_rt* r, psm_hit* hits, int32_t* counts, uint32_t max_rays) {
+    if (!r || !hits || !counts) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    uint32_t m = std::min<uint32_t>(r->limit, max_rays);
+    std::vector<float4> h0(m), pool(r->pool_cap);
+    std::vector<uint32_t> hn(m);
+    if (m) {
+        PSM_HIP(c, hipMemcpyAsync(h0.data(), r->hit0, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipMemcpyAsync(hn.data(), r->hitN, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipMemcpyAsync(pool.data(), r->pool, (size_t)r->pool_cap * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    for (uint32_t i = 0; i < m; i++) {
+        uint32_t n = hn[i] & 15u, off = hn[i] >> 4;
+        counts[i] = (int32_t)n;
+        for (uint32_t k = 0; k < 8; k++) {
+            psm_hit& o = hits[(size_t)i * 8 + k];
+            float4 v = make_float4(0.f, 0.f, INF, 0.f);
+            int tri = -1;
+            if (k < n) {
+                v = (k == 0) ? h0[i] : pool[off + k - 1];
+                std::memcpy(&tri, &v.w, 4);
+            }
+            o.u = v.x; o.v = v.y; o.t = v.z; o.tri = tri;
+        }
+    }
+    return PSM_OK;
+}
+
+int psm_rt_download_texels(psm_rt* r, float* sum_rgba, float* coord_xy, int32_t* flags) {
+    if (!r || !r->t_sum) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    size_t wr = (size_t)r->w * r->h;
+    if (sum_rgba) PSM_HIP(c, hipMemcpyAsync(sum_rgba, r->t_sum, wr * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (coord_xy) PSM_HIP(c, hipMemcpyAsync(coord_xy, r->t_coord, wr * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    if (flags) PSM_HIP(c, hipMemcpyAsync(flags, r->t_flag, wr * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return PSM_OK;
+}
+
+// ---- statistics ---------------------------------------------------------------------------------
+int psm_stats_enable(psm_ctx* c, int timing, int counting) {
+    if (!c) return PSM_ERR_INVALID;
+    c->timing = timing != 0;
+    c->counting = counting != 0;
+    return PSM_OK;
+}
+int psm_stats_reset(psm_ctx* c) {
+    if (!c) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    for (int i = 0; i < CAT_COUNT; i++) { c->cat_ms[i] = 0.f; c->cat_launches[i] = 0; }
+    c->rays_traced = 0;
+    c->rounds = 0;
+    PSM_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
+    return PSM_OK;
+}
+int psm_stats_get(psm_ctx* c, psm_stats* out) {
+    if (!c || !out) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    DevCounters d;
+    PSM_HIP(c, hipMemcpyAsync(&d, c->d_counters, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    std::memset(out, 0, sizeof(*out));
+    out->rays_traced = c->rays_traced;
+    out->node_visits = d.node_visits;
+    out->tri_tests = d.tri_tests;
+    out->stack_drops = d.stack_drops;
+    out->iter_caps = d.iter_caps;
+    out->baked_drops = d.baked_drops;
+    out->chain_pool_drops = d.chain_pool_drops;
+    out->ray_limit_drops = d.ray_limit_drops;
+    out->traverse_launches = c->cat_launches[CAT_TRAVERSE];
+    out->traverse_ms = c->cat_ms[CAT_TRAVERSE];
+    out->build_ms = c->cat_ms[CAT_BUILD];
+    out->sort_ms = c->cat_ms[CAT_SORT];
+    out->shade_ms = c->cat_ms[CAT_SHADE];
+    out->camera_ms = c->cat_ms[CAT_CAMERA];
+    out->sample_ms = c->cat_ms[CAT_SAMPLE];
+    out->rounds = c->rounds;
+    return PSM_OK;
+}
+
+}  // extern "C"

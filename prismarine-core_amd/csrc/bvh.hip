@@ -1,0 +1,484 @@
+// bvh.hip -- HLBVH builder for gfx950: bounds, Morton + leaf records, emit, boxes.
+//
+// Replaces ShadersSDK/hlbvh/{minmax,aabbmaker,build-new,child-link,refit}.comp and the host
+// orchestration of psm::TriangleHierarchy::build (Include/Prismarine/TriangleHierarchy.inl:206-329).
+//
+// MI355X-first structure (DESIGN.md "build"):
+//   * no host readbacks: bounds -> fit transform (double, on device) -> Morton -> sort -> emit all
+//     run back to back on one stream; the leaf count lives in device memory
+//   * the reference emits one BVH level per dispatch (build-new.comp, tens of levels) and refits
+//     with ONE workgroup (refit.comp); here every internal node is identified by its split gap s
+//     (between sorted leaves s and s+1), finds its own range [first,last] from the sorted keys,
+//     and reads its children's boxes from a min/max segment tree over the sorted leaf boxes --
+//     one launch for the whole tree, no atomics, no level synchronisation.  The tree SHAPE is
+//     the reference's (findSplit, build-new.comp:33-56); node numbering is an internal choice
+//     (SURVEY a-9: numbering never changes results).
+#include "psm_common.h"
+#include "psm_internal.h"
+
+namespace psm {
+
+// d_small layout (uint32 words)
+constexpr int SM_M = 0;        // 16 floats: fit transform M
+constexpr int SM_BOUNDS = 16;  // 8 ordered ints: min xyzw, max xyzw (exact, before the pad)
+constexpr int SM_COUNT = 24;   // leaf count
+constexpr int SM_ROOT = 25;    // root link
+constexpr int SM_BFLOAT = 26;  // 8 floats: bounds after the -+1e-5 pad
+constexpr int SM_M0 = 34;      // 16 floats: first-pass transform inverse(opt)
+constexpr int SM_WORDS = 64;
+
+PSM_D int32_t float_to_ordered(float f) {
+    int32_t i = (int32_t)f2u(f);
+    return i >= 0 ? i : (i ^ 0x7fffffff);
+}
+PSM_D float ordered_to_float(int32_t i) { return u2f((uint32_t)(i >= 0 ? i : (i ^ 0x7fffffff))); }
+
+// ---- stage: bounds (hlbvh/minmax.comp:50-79 + TriangleHierarchy.inl:248-267) -------------------
+
+__global__ void bvh_init_bounds(uint32_t* sm, const double* opt) {
+    if (threadIdx.x == 0) {
+        double inv[16];
+        inverse4d(opt, inv);  // TriangleHierarchy.inl:226-232
+        for (int i = 0; i < 16; i++) sm[SM_M0 + i] = f2u((float)inv[i]);
+        for (int c = 0; c < 4; c++) {
+            sm[SM_BOUNDS + c] = (uint32_t)float_to_ordered(100000.f);       // minmax.comp:56
+            sm[SM_BOUNDS + 4 + c] = (uint32_t)float_to_ordered(-100000.f);
+        }
+        sm[SM_COUNT] = 0;
+        sm[SM_ROOT] = (uint32_t)-1;
+    }
+}
+
+__global__ __launch_bounds__(256) void bvh_bounds(const float* __restrict__ pos, uint32_t n, uint32_t* sm) {
+    __shared__ float red[8][4];
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) M[i] = u2f(sm[SM_M0 + i]);
+    float mn[4] = {100000.f, 100000.f, 100000.f, 100000.f};
+    float mx[4] = {-100000.f, -100000.f, -100000.f, -100000.f};
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const float* p = pos + (size_t)9 * t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float o[4];
+            mat_vec(M, p[3 * k], p[3 * k + 1], p[3 * k + 2], 1.0f, o);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { mn[c] = pmin(mn[c], o[c]); mx[c] = pmax(mx[c], o[c]); }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            mn[c] = pmin(mn[c], __shfl_xor(mn[c], d, 64));
+            mx[c] = pmax(mx[c], __shfl_xor(mx[c], d, 64));
+        }
+    }
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) { red[c][w] = mn[c]; red[4 + c][w] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int c = threadIdx.x;
+        float v = red[c][0];
+        for (int q = 1; q < 4; q++) v = (c < 4) ? pmin(v, red[c][q]) : pmax(v, red[c][q]);
+        if (c < 4) atomicMin((int32_t*)&sm[SM_BOUNDS + c], float_to_ordered(v));
+        else atomicMax((int32_t*)&sm[SM_BOUNDS + c], float_to_ordered(v));
+    }
+}
+
+// TriangleHierarchy.inl:257-267: mat = inverse(translate(mn) * scale(mx - mn)) * inverse(opt),
+// double precision, cast to float -- evaluated on the device so the build never leaves the stream.
+__global__ void bvh_fit_transform(uint32_t* sm, const double* opt) {
+    if (threadIdx.x != 0) return;
+    float mn[4], mx[4];
+    for (int c = 0; c < 4; c++) {
+        mn[c] = ordered_to_float((int32_t)sm[SM_BOUNDS + c]) - 0.00001f;  // minmax.comp:76-77
+        mx[c] = ordered_to_float((int32_t)sm[SM_BOUNDS + 4 + c]) + 0.00001f;
+        sm[SM_BFLOAT + c] = f2u(mn[c]);
+        sm[SM_BFLOAT + 4 + c] = f2u(mx[c]);
+    }
+    float scale[3], offset[3];
+    for (int c = 0; c < 3; c++) { scale[c] = mx[c] - mn[c]; offset[c] = mn[c]; }
+    double TS[16] = {(double)scale[0], 0, 0, (double)offset[0], 0, (double)scale[1], 0, (double)offset[1],
+                     0, 0, (double)scale[2], (double)offset[2], 0, 0, 0, 1};
+    double iTS[16], iopt[16], mat[16];
+    inverse4d(TS, iTS);
+    inverse4d(opt, iopt);
+    mul4d(iTS, iopt, mat);
+    for (int i = 0; i < 16; i++) sm[SM_M + i] = f2u((float)mat[i]);
+}
+
+// traversal layout: v0, e1 = v1 - v0, e2 = v2 - v0 (the first three operations of
+// intersectTriangle, include/vertex.glsl:148-156, hoisted; same IEEE results)
+__global__ __launch_bounds__(256) void bvh_prepare_tris(const float* __restrict__ pos, float4* __restrict__ tri48,
+                                                        uint32_t first, uint32_t n) {
+    uint32_t t = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= first + n) return;
+    const float* p = pos + (size_t)9 * t;
+    float4 v0 = make_float4(p[0], p[1], p[2], 1.0f);
+    float4 e1 = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.0f);
+    float4 e2 = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f);
+    tri48[(size_t)3 * t + 0] = v0;
+    tri48[(size_t)3 * t + 1] = e1;
+    tri48[(size_t)3 * t + 2] = e2;
+}
+
+// ---- stage: Morton + leaf records (hlbvh/aabbmaker.comp:142-232, splitLimit = 0) --------------
+
+struct LeafCalc {
+    bool keep;
+    uint64_t key;
+    uint4 box;
+};
+
+PSM_D LeafCalc leaf_calc(const float* __restrict__ pos, uint32_t t, const float* M) {
+    LeafCalc r;
+    const float* p = pos + (size_t)9 * t;
+    float v[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) mat_vec(M, p[3 * k], p[3 * k + 1], p[3 * k + 2], 1.0f, v[k]);
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = ((v[0][k] + v[1][k]) + v[2][k]) * 0.33333333333333f;  // :159
+    v3 s;
+    s.x = (pabs(v[0][0] - c[0]) + pabs(v[1][0] - c[0])) + pabs(v[2][0] - c[0]);
+    s.y = (pabs(v[0][1] - c[1]) + pabs(v[1][1] - c[1])) + pabs(v[2][1] - c[1]);
+    s.z = (pabs(v[0][2] - c[2]) + pabs(v[1][2] - c[2])) + pabs(v[2][2] - c[2]);
+    r.keep = !(len3(s) < 1.e-5f);  // :160
+    float bmn[4], bmx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        bmn[k] = pmin(pmin(v[0][k], v[1][k]), v[2][k]);
+        bmx[k] = pmax(pmax(v[0][k], v[1][k]), v[2][k]);
+    }
+    r.keep = r.keep && greaterEqualF(bmx[0] - bmn[0], 0.f) && greaterEqualF(bmx[1] - bmn[1], 0.f) &&
+             greaterEqualF(bmx[2] - bmn[2], 0.f);  // :176
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float f = floorf(pclamp(c[k], 0.0f, 0.99999f) * 2097152.0f);  // :187-189
+        uint32_t u = (uint32_t)f;
+        q[k] = u > 0x1FFFFFu ? 0x1FFFFFu : u;
+    }
+    r.key = morton3_64(q[0], q[1], q[2]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { bmn[k] = bmn[k] - PZERO; bmx[k] = bmx[k] + PZERO; }  // :193-194
+    r.box = make_uint4(pack_half2(bmn[0], bmn[1]), pack_half2(bmn[2], bmn[3]), pack_half2(bmx[0], bmx[1]),
+                       pack_half2(bmx[2], bmx[3]));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void bvh_morton_count(const float* __restrict__ pos, uint32_t n,
+                                                        const uint32_t* __restrict__ sm,
+                                                        uint32_t* __restrict__ blockCounts) {
+    __shared__ uint32_t wsum[4];
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) M[i] = u2f(sm[SM_M + i]);
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (t < n) keep = leaf_calc(pos, t, M).keep;
+    uint64_t b = __ballot(keep);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) blockCounts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of nb block counts in place; total -> *total_out
+__global__ __launch_bounds__(1024) void scan_blocks(uint32_t* __restrict__ g, uint32_t nb, uint32_t* total_out) {
+    __shared__ uint32_t tmp[32];
+    uint32_t tid = threadIdx.x;
+    uint32_t chunk = (nb + 1023u) / 1024u;
+    uint32_t s = min(tid * chunk, nb), e = min(s + chunk, nb);
+    uint32_t sum = 0;
+    for (uint32_t i = s; i < e; i++) sum += g[i];
+    uint32_t total;
+    uint32_t run = block_scan_excl<1024>(sum, tmp, &total);
+    for (uint32_t i = s; i < e; i++) {
+        uint32_t v = g[i];
+        g[i] = run;
+        run += v;
+    }
+    if (tid == 0 && total_out) *total_out = total;
+}
+
+// canonical leaf slot `to` = rank among kept triangles in ascending t (SURVEY a-8)
+__global__ __launch_bounds__(256) void bvh_morton_write(const float* __restrict__ pos, uint32_t n,
+                                                        const uint32_t* __restrict__ sm,
+                                                        const uint32_t* __restrict__ blockBase,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                        uint4* __restrict__ leafbox, int32_t* __restrict__ leaftri) {
+    __shared__ uint32_t wsum[4];
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) M[i] = u2f(sm[SM_M + i]);
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    LeafCalc lc;
+    lc.keep = false;
+    if (t < n) lc = leaf_calc(pos, t, M);
+    uint64_t b = __ballot(lc.keep);
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 0) wsum[w] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int q = 0; q < w; q++) wbase += wsum[q];
+    if (lc.keep) {
+        uint32_t to = blockBase[blockIdx.x] + wbase + (uint32_t)__popcll(b & lanemask_lt());
+        keys[to] = lc.key;
+        idx[to] = to;  // :185
+        leafbox[to] = lc.box;
+        leaftri[to] = (int32_t)t;
+    }
+}
+
+// ---- stage: emit + boxes ---------------------------------------------------------------------
+
+// sortable-key box: mins in x,y (min-reduced), maxes in z,w (max-reduced), per 16-bit lane
+PSM_D uint4 box_union(uint4 a, uint4 b) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint4 r;
+    r.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a.x), __builtin_bit_cast(us2, b.x)));
+    r.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a.y), __builtin_bit_cast(us2, b.y)));
+    r.z = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a.z), __builtin_bit_cast(us2, b.z)));
+    r.w = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a.w), __builtin_bit_cast(us2, b.w)));
+    return r;
+}
+PSM_D uint4 box_identity() { return make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u); }
+PSM_D uint4 box_to_key(uint4 h) { return make_uint4(half2_to_key(h.x), half2_to_key(h.y), half2_to_key(h.z), half2_to_key(h.w)); }
+PSM_D uint4 key_to_box(uint4 k) { return make_uint4(key_to_half2(k.x), key_to_half2(k.y), key_to_half2(k.z), key_to_half2(k.w)); }
+
+PSM_D uint4 shfl_down4(uint4 v, int d) {
+    return make_uint4(__shfl_down(v.x, d, 64), __shfl_down(v.y, d, 64), __shfl_down(v.z, d, 64), __shfl_down(v.w, d, 64));
+}
+
+// Builds 8 levels of the min/max segment tree per launch. Level L entry j covers sorted leaves
+// [j*2^L, (j+1)*2^L). Level 0 is gathered through the sorted MortonIndices (child-link.comp:34-45).
+// lvl[q] = entry offset of level (L0+q) inside seg; in_count = entries of level L0 (upper bound).
+struct SegLevels {
+    uint32_t off[9];
+};
+template <bool GATHER>
+__global__ __launch_bounds__(256) void bvh_segtree(uint4* __restrict__ seg, SegLevels lv, uint32_t in_count_max,
+                                                   const uint32_t* __restrict__ sm, const uint32_t* __restrict__ idx,
+                                                   const uint4* __restrict__ leafbox, const int32_t* __restrict__ leaftri,
+                                                   int32_t* __restrict__ sorted_tri, int L0, int nvalid) {
+    __shared__ uint4 sh[4];
+    uint32_t count = sm[SM_COUNT];
+    uint32_t in_count = GATHER ? count : ((count + (1u << L0) - 1u) >> L0);
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    uint4 v = box_identity();
+    if (GATHER) {
+        if (k < in_count) {
+            uint32_t leaf = idx[k];
+            v = box_to_key(leafbox[leaf]);
+            sorted_tri[k] = leaftri[leaf];
+        }
+        if (k < in_count_max) seg[lv.off[0] + k] = v;
+    } else {
+        if (k < in_count) v = seg[lv.off[0] + k];
+    }
+    int l = lane_id();
+#pragma unroll
+    for (int s = 1; s <= 6; s++) {
+        uint4 o = shfl_down4(v, 1 << (s - 1));
+        v = box_union(v, o);
+        if (s < nvalid && (l & ((1 << s) - 1)) == 0) {
+            uint32_t j = k >> s;
+            if (j < ((in_count_max + (1u << s) - 1u) >> s)) seg[lv.off[s] + j] = v;
+        }
+    }
+    if (l == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint4 a = box_union(sh[0], sh[1]), b = box_union(sh[2], sh[3]);
+        uint32_t j7 = k >> 7;
+        if (7 < nvalid && j7 < ((in_count_max + 127u) >> 7)) seg[lv.off[7] + j7] = a;
+        if (7 < nvalid && j7 + 1 < ((in_count_max + 127u) >> 7)) seg[lv.off[7] + j7 + 1] = b;
+        uint32_t j8 = k >> 8;
+        if (8 < nvalid && j8 < ((in_count_max + 255u) >> 8)) seg[lv.off[8] + j8] = box_union(a, b);
+    }
+}
+
+struct SegTree {
+    const uint4* seg;
+    uint32_t off[32];
+};
+
+// union of sorted leaves [f, l]
+PSM_D uint4 seg_query(const SegTree& st, uint32_t f, uint32_t l) {
+    uint32_t lo = f, hi = l + 1;
+    uint4 acc = box_identity();
+    int level = 0;
+    while (lo < hi) {
+        if (lo & 1u) { acc = box_union(acc, st.seg[st.off[level] + lo]); lo++; }
+        if (hi & 1u) { hi--; acc = box_union(acc, st.seg[st.off[level] + hi]); }
+        lo >>= 1; hi >>= 1; level++;
+    }
+    return acc;
+}
+
+// findSplit, hlbvh/build-new.comp:33-56
+PSM_D int find_split(const uint64_t* __restrict__ keys, int first, int last) {
+    uint64_t firstCode = keys[first];
+    uint64_t lastCode = keys[last];
+    int split = (first + last) >> 1;
+    if (firstCode != lastCode) {
+        split = first;
+        int commonPrefix = nlz64(firstCode ^ lastCode);
+        int step = last - first;
+        for (int i = 0; i < 8192; i++) {
+            step = (step + 1) >> 1;
+            int newSplit = split + step;
+            if (newSplit < last) {
+                uint64_t splitCode = keys[newSplit];
+                if (nlz64(firstCode ^ splitCode) > commonPrefix) split = newSplit;
+            }
+            if (step <= 1) break;
+        }
+    }
+    return min(max(split, first), last - 1);
+}
+
+// One thread per split gap s (internal node). The node whose findSplit lands on gap s is unique:
+//  * keys differ across the gap: it is the radix-tree node whose range is every key sharing the
+//    first delta = nlz(key[s]^key[s+1]) bits with key[s];
+//  * keys equal across the gap: the gap lies inside a run of equal keys [a,b]; the run is a node
+//    of the reference tree and below it findSplit halves ranges at (first+last)>>1.
+__global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ keys, const int32_t* __restrict__ sorted_tri,
+                                                SegTree st, uint32_t* __restrict__ sm, uint4* __restrict__ pairbox,
+                                                int2* __restrict__ link, int2* __restrict__ range) {
+    int count = (int)sm[SM_COUNT];
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) sm[SM_ROOT] = (uint32_t)(count >= 2 ? find_split(keys, 0, count - 1) : -1);
+    if (s >= count - 1) return;
+    uint64_t ks = keys[s], ks1 = keys[s + 1];
+    int f, l;
+    if (ks != ks1) {
+        int delta = nlz64(ks ^ ks1);
+        // leftmost f with nlz(key[f]^ks) >= delta (monotone towards s)
+        {
+            int step = 1, lo = s;  // lo: known inside
+            while (lo - step >= 0 && nlz64(keys[lo - step] ^ ks) >= delta) { lo -= step; step <<= 1; }
+            // answer in (lo-step, lo]
+            int bad = max(lo - step, -1);
+            while (lo - bad > 1) {
+                int mid = (lo + bad) >> 1;
+                if (nlz64(keys[mid] ^ ks) >= delta) lo = mid; else bad = mid;
+            }
+            f = lo;
+        }
+        {
+            int step = 1, hi = s + 1;
+            while (hi + step < count && nlz64(keys[hi + step] ^ ks) >= delta) { hi += step; step <<= 1; }
+            int bad = min(hi + step, count);
+            while (bad - hi > 1) {
+                int mid = (hi + bad) >> 1;
+                if (nlz64(keys[mid] ^ ks) >= delta) hi = mid; else bad = mid;
+            }
+            l = hi;
+        }
+    } else {
+        int a, b;
+        {
+            int step = 1, lo = s;
+            while (lo - step >= 0 && keys[lo - step] == ks) { lo -= step; step <<= 1; }
+            int bad = max(lo - step, -1);
+            while (lo - bad > 1) {
+                int mid = (lo + bad) >> 1;
+                if (keys[mid] == ks) lo = mid; else bad = mid;
+            }
+            a = lo;
+        }
+        {
+            int step = 1, hi = s + 1;
+            while (hi + step < count && keys[hi + step] == ks) { hi += step; step <<= 1; }
+            int bad = min(hi + step, count);
+            while (bad - hi > 1) {
+                int mid = (hi + bad) >> 1;
+                if (keys[mid] == ks) hi = mid; else bad = mid;
+            }
+            b = hi;
+        }
+        f = a; l = b;
+        for (;;) {
+            int m = (f + l) >> 1;
+            if (s == m) break;
+            if (s < m) l = m; else f = m + 1;
+        }
+    }
+    // children [f,s] and [s+1,l] (splitNode, build-new.comp:70-117; leaf link child-link.comp:34-53)
+    int2 lk;
+    lk.x = (f == s) ? ~sorted_tri[s] : find_split(keys, f, s);
+    lk.y = (s + 1 == l) ? ~sorted_tri[l] : find_split(keys, s + 1, l);
+    uint4 lb = key_to_box(seg_query(st, (uint32_t)f, (uint32_t)s));          // refit.comp:91-98
+    uint4 rb = key_to_box(seg_query(st, (uint32_t)(s + 1), (uint32_t)l));
+    pairbox[2 * (size_t)s + 0] = lb;
+    pairbox[2 * (size_t)s + 1] = rb;
+    link[s] = lk;
+    range[s] = make_int2(f, l);
+}
+
+// ---- launch wrappers ----------------------------------------------------------------------------
+
+int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n) {
+    if (n == 0) return PSM_OK;
+    bvh_prepare_tris<<<(n + 255) / 256, 256, 0, b->ctx->stream>>>(b->d_pos, b->d_tri48, first, n);
+    PSM_HIP(b->ctx, hipGetLastError());
+    return PSM_OK;
+}
+
+int launch_bvh_bounds(psm_bvh* b) {
+    psm_ctx* c = b->ctx;
+    uint32_t n = b->tri_count;
+    bvh_init_bounds<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
+    uint32_t grid = min((n + 255u) / 256u, 2048u);
+    if (grid) bvh_bounds<<<grid, 256, 0, c->stream>>>(b->d_pos, n, b->d_small);
+    bvh_fit_transform<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+int launch_bvh_morton(psm_bvh* b) {
+    psm_ctx* c = b->ctx;
+    uint32_t n = b->tri_count;
+    uint32_t nb = (n + 255u) / 256u;
+    if (nb == 0) return PSM_OK;
+    bvh_morton_count<<<nb, 256, 0, c->stream>>>(b->d_pos, n, b->d_small, b->d_block);
+    scan_blocks<<<1, 1024, 0, c->stream>>>(b->d_block, nb, b->d_small + SM_COUNT);
+    bvh_morton_write<<<nb, 256, 0, c->stream>>>(b->d_pos, n, b->d_small, b->d_block, b->d_keys, b->d_idx,
+                                                b->d_leafbox, b->d_leaftri);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+int launch_bvh_emit(psm_bvh* b) {
+    psm_ctx* c = b->ctx;
+    uint32_t n = b->tri_count;  // upper bound of the leaf count
+    if (n == 0) return PSM_OK;
+    int nlev = (int)b->seg_off.size() - 1;  // levels 0..nlev-1
+    for (int L0 = 0; L0 < nlev; L0 += 8) {
+        SegLevels lv;
+        for (int q = 0; q < 9; q++) lv.off[q] = (uint32_t)b->seg_off[(size_t)std::min(L0 + q, nlev)];
+        uint32_t in_max = (n + (1u << L0) - 1u) >> L0;
+        uint32_t grid = (in_max + 255u) / 256u;
+        if (L0 == 0)
+            bvh_segtree<true><<<grid, 256, 0, c->stream>>>(b->d_seg, lv, in_max, b->d_small, b->d_idx, b->d_leafbox,
+                                                           b->d_leaftri, b->d_sorted_tri, L0, nlev - L0);
+        else
+            bvh_segtree<false><<<grid, 256, 0, c->stream>>>(b->d_seg, lv, in_max, b->d_small, nullptr, nullptr, nullptr,
+                                                            nullptr, L0, nlev - L0);
+    }
+    SegTree st;
+    st.seg = b->d_seg;
+    for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
+    uint32_t grid = (n + 255u) / 256u;
+    bvh_emit<<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
+                                          b->d_range);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+}  // namespace psm

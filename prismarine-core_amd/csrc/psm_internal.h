@@ -1,0 +1,139 @@
+// psm_internal.h -- host-side objects behind the C ABI (include/psm_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/psm_hip.h"
+
+namespace psm {
+
+enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_COUNT };
+
+// device-resident counters (one block per context)
+struct DevCounters {
+    unsigned long long node_visits, tri_tests, stack_drops, iter_caps, baked_drops, chain_pool_drops,
+        ray_limit_drops, pad;
+};
+
+struct Buf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace psm
+
+struct psm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<psm::Buf> bufs;  // handle = index+1
+    bool timing = false, counting = false;
+    psm::DevCounters* d_counters = nullptr;
+    struct Timed {
+        hipEvent_t a, b;
+        int cat;
+    };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> free_events;
+    float cat_ms[psm::CAT_COUNT] = {0};
+    uint32_t cat_launches[psm::CAT_COUNT] = {0};
+    uint64_t rays_traced = 0;
+    uint32_t rounds = 0;
+    // sort scratch (grown on demand)
+    uint64_t* sort_keys_tmp = nullptr;
+    uint32_t* sort_vals_tmp = nullptr;
+    uint32_t* sort_hist = nullptr;
+    size_t sort_cap = 0, sort_hist_cap = 0;
+};
+
+struct psm_bvh {
+    psm_ctx* ctx = nullptr;
+    size_t cap = 0;
+    uint32_t tri_count = 0;
+    bool built = false, bounds_done = false, morton_done = false, sort_done = false;
+    float* d_pos = nullptr;       // 9 floats / triangle
+    float* d_nrm = nullptr;       // 9 floats / triangle
+    int32_t* d_mats = nullptr;    // material id / triangle
+    float4* d_tri48 = nullptr;    // v0, e1, e2 (xyz, w unused) / triangle -- traversal layout
+    uint64_t* d_keys = nullptr;   // Morton codes, slot order then sorted in place
+    uint32_t* d_idx = nullptr;    // MortonIndices
+    uint4* d_leafbox = nullptr;   // leaf record box, slot order
+    int32_t* d_leaftri = nullptr; // leaf record triangle, slot order
+    uint32_t* d_block = nullptr;  // per-block counts / bases for the leaf compaction
+    // small device block: [0..15] M (float), [16..23] bounds as ordered ints, [24] leaf count,
+    // [25] root link, [26..33] bounds floats after pad
+    uint32_t* d_small = nullptr;
+    double* d_opt = nullptr;      // optimisation matrix (16 doubles)
+    uint4* d_seg = nullptr;       // segment tree of sortable-key boxes, levels concatenated
+    std::vector<size_t> seg_off;  // level offsets (entries)
+    int32_t* d_sorted_tri = nullptr;
+    uint4* d_pairbox = nullptr;   // 2 x uint4 per internal node (split gap)
+    int2* d_link = nullptr;
+    int2* d_range = nullptr;
+};
+
+struct psm_rt {
+    psm_ctx* ctx = nullptr;
+    uint32_t w = 0, h = 0, dw = 0, dh = 0, y0 = 0, y1 = 0;
+    uint32_t limit = 0;           // currentRayLimit
+    int cur = 0;                  // current queue index
+    uint32_t ray_count = 0;       // host mirror of the current queue length (valid after sync points)
+    bool count_valid = true;
+    float4* qA[2] = {nullptr, nullptr};  // origin.xyz, texel
+    float4* qB[2] = {nullptr, nullptr};  // direct.xyz, bitfield
+    float4* qC[2] = {nullptr, nullptr};  // color.xyz, pkey
+    float4* sA = nullptr;         // staging (4 outputs per input ray, block-compacted)
+    float4* sB = nullptr;
+    float4* sC = nullptr;
+    uint32_t* d_block = nullptr;  // per-block output counts / bases
+    uint32_t* d_cnt = nullptr;    // [0] current count, [1] next count, [2] chain pool cursor
+    float4* hit0 = nullptr;       // head of chain per ray: u, v, t, tri
+    uint32_t* hitN = nullptr;     // chain length | pool offset << 4
+    float4* pool = nullptr;       // chain entries beyond the head
+    uint32_t pool_cap = 0;
+    float2* t_coord = nullptr;
+    float4* t_sum = nullptr;
+    int32_t* t_flag = nullptr;
+    float4* presampled = nullptr;
+    float4* filtered = nullptr;
+    psm_light* d_lights = nullptr;
+    uint32_t light_count = 1;
+    psm_material* d_mats = nullptr;
+    uint32_t mat_count = 0;
+    int32_t mat_offset = 0;
+    float sky[4] = {0.5f, 0.7f, 1.0f, 1.0f};
+    int samples_lock = 4;         // SAMPLES_LOCK, constants.glsl:35
+};
+
+namespace psm {
+
+// RAII-free helpers -----------------------------------------------------------------------------
+int set_err(psm_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+#define PSM_HIP(ctx, call)                                                   \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return psm::set_err((ctx), PSM_ERR_HIP, #call, e__); \
+    } while (0)
+
+struct TimedScope {
+    psm_ctx* c;
+    int idx = -1;
+    TimedScope(psm_ctx* ctx, int cat);
+    ~TimedScope();
+};
+
+// kernels (launch wrappers) ------------------------------------------------------------------------
+int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n);
+int launch_bvh_bounds(psm_bvh* b);
+int launch_bvh_morton(psm_bvh* b);
+int launch_bvh_emit(psm_bvh* b);
+int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
+int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
+int launch_rt_traverse(psm_rt* r, psm_bvh* b);
+int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
+int launch_rt_sample(psm_rt* r);
+
+}  // namespace psm

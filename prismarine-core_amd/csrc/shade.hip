@@ -1,0 +1,635 @@
+// shade.hip -- wavefront loop stages for gfx950: camera, surface+shade, queue hand-off, sample.
+//
+// Replaces ShadersSDK/raytracing/{camera,surface,rayshading,sampler,deinterlace,filter}.comp with
+// include/{random,rayslib,shadinglib}.glsl, as driven by psm::Pipeline::{camera,applyMaterials,
+// shade,reloadQueuedRays,sample} (Include/Prismarine/Pipeline.inl:251-436).
+//
+// Differences in mechanism, not in results (DESIGN.md "wavefront loop"):
+//   * rays live in three float4 SoA queues (origin|texel, direct|bitfield, color|pkey) instead of
+//     80-byte AoS RayRework records addressed through index lists (rayslib.glsl:12-46)
+//   * surface.comp is fused in front of rayshading.comp (no 112-byte HitRework round trip)
+//   * the next queue is built by an ordered compaction (block scan -> staging -> ordered copy), so
+//     queue order is the canonical [current, diffuse, reflection, shadow] per input ray instead of
+//     the arrival order of wave-aggregated atomics (ballotlib.glsl:106-131)
+//   * radiance is summed per texel with float atomics instead of colour-chain linked lists
+//     (rayslib.glsl:59-79 + sampler.comp:15-35)
+//   * the RNG stream id is the ray's path key, not its queue slot (SURVEY a-15)
+#include "psm_common.h"
+#include "psm_internal.h"
+
+namespace psm {
+
+constexpr float TWO_PI_F = 6.2831853071795864769252867665590057683943f;
+constexpr float SQRT_OF_ONE_THIRD_F = 0.5773502691896257645091487805019574556476f;
+constexpr int SHADE_BLOCK = 256;
+constexpr int SHADE_SEG = SHADE_BLOCK * 4;
+
+// ray bitfield, include/structs.glsl:73-78
+PSM_HD int bf_get(int bf, int off, int bits) { return (bf >> off) & ((1 << bits) - 1); }
+PSM_HD int bf_set(int bf, int v, int off, int bits) {
+    int mask = ((1 << bits) - 1) << off;
+    return (bf & ~mask) | ((v << off) & mask);
+}
+#define R_ACTIVE(b) bf_get(b, 0, 1)
+#define R_TYPE(b) bf_get(b, 1, 2)
+#define R_DL(b) bf_get(b, 3, 1)
+#define R_TARGET(b) bf_get(b, 4, 4)
+#define R_BOUNCE(b) bf_get(b, 8, 4)
+#define R_BASIS(b) bf_get(b, 12, 1)
+#define S_ACTIVE(b, v) b = bf_set(b, v, 0, 1)
+#define S_TYPE(b, v) b = bf_set(b, v, 1, 2)
+#define S_DL(b, v) b = bf_set(b, v, 3, 1)
+#define S_TARGET(b, v) b = bf_set(b, v, 4, 4)
+#define S_BOUNCE(b, v) b = bf_set(b, v, 8, 4)
+#define S_BASIS(b, v) b = bf_set(b, v, 12, 1)
+
+struct Mat16 {
+    float m[16];
+};
+
+// ---- camera, raytracing/camera.comp:22-101 ------------------------------------------------------
+__global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, uint32_t time, uint32_t w, uint32_t h,
+                                                 uint32_t y0, uint32_t y1, float4* __restrict__ qA,
+                                                 float4* __restrict__ qB, float4* __restrict__ qC,
+                                                 float2* __restrict__ t_coord, float4* __restrict__ t_sum,
+                                                 int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt) {
+    uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) { cnt[0] = (y1 - y0) * w; cnt[1] = 0; cnt[2] = 0; }
+    if (idx >= w * h) return;
+    uint32_t x = idx % w, y = idx / w;
+    float invw = 1.0f / (float)w, invh = 1.0f / (float)h;
+    Rng g{idx, 0u, time << 5};
+    float rx = g.next();
+    float ry = g.next();
+    float cx = ((float)x + pclamp(rx, 0.00001f, 0.99999f)) * invw;  // :35
+    float cy = ((float)y + pclamp(ry, 0.00001f, 0.99999f)) * invh;
+    t_coord[idx] = make_float2(cx, cy);
+    t_sum[idx] = make_float4(0.f, 0.f, 0.f, 1.f);  // pre-collected zero sample (:99)
+    t_flag[idx] = 1;
+    if (y < y0 || y >= y1) return;
+    float nx = cx * 2.0f - 1.0f, ny = cy * 2.0f - 1.0f;
+    float t0[4], co[4], orig[4];
+    mat_vec(projInv.m, nx, ny, 0.999f, 1.0f, t0);
+    mat_vec(camInv.m, t0[0], t0[1], t0[2], t0[3], co);
+    mat_vec(projInv.m, nx, ny, 0.0f, 1.0f, t0);
+    mat_vec(camInv.m, t0[0], t0[1], t0[2], t0[3], orig);
+    float cw = co[3], ow = orig[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { co[k] = co[k] / cw; orig[k] = orig[k] / ow; }
+    v3 dir = normalize3(mk3(co[0] - orig[0], co[1] - orig[1], co[2] - orig[2]));
+    int bf = 0;
+    S_ACTIVE(bf, 1); S_TYPE(bf, 0); S_DL(bf, 0); S_BOUNCE(bf, 4); S_BASIS(bf, 1);
+    S_BOUNCE(bf, R_BOUNCE(bf) - 1);  // createRayIdx -> createRayStrict, rayslib.glsl:130-156
+    uint32_t q = idx - y0 * w;
+    qA[q] = make_float4(orig[0], orig[1], orig[2], __int_as_float((int)idx));
+    qB[q] = make_float4(dir.x, dir.y, dir.z, __int_as_float(bf));
+    qC[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(idx));
+}
+
+// ---- surface: interpolateMeshData (directTraverse.comp:116-217) + surface.comp:165-195 -----------
+struct Surf {
+    float t;
+    v3 normal_trav, normal;
+    float albedo[4], emission[4], mr[4];
+    bool active;
+};
+
+PSM_D void unpack4(uint32_t lo, uint32_t hi, float* o) {
+    o[0] = half_lo(lo); o[1] = half_hi(lo); o[2] = half_lo(hi); o[3] = half_hi(hi);
+}
+
+PSM_D Surf surface_eval(float4 hit, const float4* __restrict__ tri48, const float* __restrict__ nrm,
+                        const int32_t* __restrict__ tri_mats, const psm_material* __restrict__ mats,
+                        int mat_offset, int mat_count) {
+    Surf s;
+    int tri = __float_as_int(hit.w);
+    float u = hit.x, v = hit.y;
+    s.t = hit.z;
+    float4 b = tri48[(size_t)3 * tri + 1], c = tri48[(size_t)3 * tri + 2];
+    v3 d1 = mk3(b.x, b.y, b.z), d2 = mk3(c.x, c.y, c.z);
+    const float* n = nrm + (size_t)9 * tri;
+    float vs0 = (1.0f - u) - v, vs1 = u, vs2 = v;
+    v3 nor = normalize3(cross3(d1, d2));
+    v3 nn = mk3((vs0 * n[0] + vs1 * n[3]) + vs2 * n[6], (vs0 * n[1] + vs1 * n[4]) + vs2 * n[7],
+                (vs0 * n[2] + vs1 * n[5]) + vs2 * n[8]);
+    nn = normalize3(nn);
+    float sg = psign(dot3(nn, nor));
+    nn = nn * sg;
+    s.normal_trav = nn;
+    s.normal = normalize3(normalize3(nn));  // surface.comp:176-186 with no normal map
+    int matID = tri_mats[tri] - mat_offset;
+    s.active = !(matID >= mat_count || matID < 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s.albedo[k] = 0.f; s.emission[k] = 0.f; s.mr[k] = 0.f; }
+    if (s.active) {
+        const psm_material* m = mats + matID;
+        float d0 = pmax(m->diffuse[0], 0.f), dd1 = pmax(m->diffuse[1], 0.f), dd2 = pmax(m->diffuse[2], 0.f);
+        unpack4(pack_half2(d0, dd1), pack_half2(dd2, 1.0f), s.albedo);
+        unpack4(pack_half2(0.f * 2.f, 0.f * 2.f), pack_half2(0.f * 2.f, 1.0f), s.emission);
+        unpack4(pack_half2(m->specular[1], m->specular[2]), pack_half2(0.f, 0.f), s.mr);
+    }
+    return s;
+}
+
+// include/random.glsl:48-69
+PSM_D v3 randomCosine(Rng& g, v3 normal) {
+    float up = sqrtf(g.next());
+    float over = sqrtf(1.f - up * up);
+    float around = g.next() * TWO_PI_F;
+    v3 p0 = mk3(0, 0, 1);
+    if (pabs(normal.x) < SQRT_OF_ONE_THIRD_F) p0 = mk3(1, 0, 0);
+    else if (pabs(normal.y) < SQRT_OF_ONE_THIRD_F) p0 = mk3(0, 1, 0);
+    v3 p1 = normalize3(cross3(normal, p0));
+    v3 p2 = cross3(normal, p1);
+    float ca = pcos(around) * over, sa = psin(around) * over;
+    v3 v = mk3(fmaf(normal.x, up, fmaf(p1.x, ca, p2.x * sa)), fmaf(normal.y, up, fmaf(p1.y, ca, p2.y * sa)),
+               fmaf(normal.z, up, fmaf(p1.z, ca, p2.z * sa)));
+    return normalize3(v);
+}
+// include/random.glsl:71-76
+PSM_D v3 randomDirectionInSphere(Rng& g) {
+    float up = fmaf(g.next(), 2.0f, -1.0f);
+    float over = sqrtf(1.f - up * up);
+    float around = g.next() * TWO_PI_F;
+    return normalize3(mk3(up, pcos(around) * over, psin(around) * over));
+}
+// shadinglib.glsl:22-26
+PSM_D v3 lightCenter(const psm_light& L) {
+    v3 lv = normalize3(mk3(L.lightVector[0], L.lightVector[1], L.lightVector[2]));
+    float s = (L.lightVector[1] < 0.0f) ? -1.0f : 1.0f;
+    return mk3(fmaf(lv.x * s, L.lightVector[3], L.lightOffset[0] + 0.0f), fmaf(lv.y * s, L.lightVector[3], L.lightOffset[1] + 0.0f),
+               fmaf(lv.z * s, L.lightVector[3], L.lightOffset[2] + 0.0f));
+}
+// shadinglib.glsl:32-48
+PSM_D float intersectSphere(v3 origin, v3 ray, v3 c, float radius) {
+    v3 ts = origin - c;
+    float a = dot3(ray, ray);
+    float b = 2.0f * dot3(ts, ray);
+    float cc = dot3(ts, ts) - radius * radius;
+    float disc = fmaf(b, b, -4.0f * a * cc);
+    float t = INF;
+    if (disc > 0.0f) {
+        float da = 0.5f / a;
+        float sq = sqrtf(disc);
+        float t1 = (-b - sq) * da;
+        float t2 = (-b + sq) * da;
+        float mn = pmin(t1, t2), mx = pmax(t1, t2);
+        t = mx >= 0.0f ? (mn >= 0.0f ? mn : mx) : t;
+    }
+    return t;
+}
+
+struct WRay {
+    v3 origin, direct, color, fin;
+    int bf;
+};
+
+// _collect, rayslib.glsl:59-79 (direct per-texel sum)
+PSM_D void deposit(v3 fin, int texel, float4* __restrict__ t_sum, int32_t* __restrict__ t_flag) {
+    v3 c = mk3(pmax(fin.x, 0.f), pmax(fin.y, 0.f), pmax(fin.z, 0.f));
+    bool bad = isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z);
+    if (mlength3(c) < 10000.f && !bad) {
+        float* p = (float*)&t_sum[texel];
+        atomicAdd(p + 0, c.x);
+        atomicAdd(p + 1, c.y);
+        atomicAdd(p + 2, c.z);
+        atomicAdd(p + 3, 1.0f);
+        t_flag[texel] = 1;
+    }
+}
+
+struct OutRay {
+    float4 A, B, C;
+};
+
+// createRay, rayslib.glsl:162-203 (+createRayStrict :130-156): returns true when the ray is queued
+PSM_D bool create_ray(WRay& r, int texel, uint32_t pkey, OutRay& o, float4* __restrict__ t_sum,
+                      int32_t* __restrict__ t_flag) {
+    bool invalid = R_ACTIVE(r.bf) == 0 || R_BOUNCE(r.bf) <= 0 || mlength3(r.color) < 0.0001f;
+    if (mlength3(r.fin) >= 0.0001f && R_ACTIVE(r.bf) == 0) deposit(r.fin, texel, t_sum, t_flag);
+    if (invalid) return false;
+    S_BASIS(r.bf, 0);
+    S_BOUNCE(r.bf, R_BOUNCE(r.bf) - 1);
+    o.A = make_float4(r.origin.x, r.origin.y, r.origin.z, __int_as_float(texel));
+    o.B = make_float4(r.direct.x, r.direct.y, r.direct.z, __int_as_float(r.bf));
+    o.C = make_float4(r.color.x, r.color.y, r.color.z, __uint_as_float(pkey));
+    return true;
+}
+
+struct ShadeArgs {
+    const float4 *qA, *qB, *qC;
+    const float4* hit0;
+    const uint32_t* hitN;
+    const float4* pool;
+    const float4* tri48;
+    const float* nrm;
+    const int32_t* tri_mats;
+    const psm_material* mats;
+    const psm_light* lights;
+    float4 *sA, *sB, *sC;
+    uint32_t* blockCounts;
+    float4* t_sum;
+    int32_t* t_flag;
+    uint32_t nrays;
+    uint32_t time;
+    int mat_offset, mat_count, light_count;
+    float sky[3];
+};
+
+// surface.comp + rayshading.comp:48-278
+__global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
+    __shared__ uint32_t scan_tmp[8];
+    uint32_t it = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+    OutRay outs[4];
+    uint32_t nout = 0;
+    if (it < a.nrays) {
+        float4 A = a.qA[it], B = a.qB[it], C = a.qC[it];
+        int in_texel = __float_as_int(A.w);
+        uint32_t in_pkey = __float_as_uint(C.w);
+        Rng g{in_pkey, 0u, a.time << 5};
+        WRay ray;
+        ray.origin = mk3(A.x, A.y, A.z);
+        ray.direct = mk3(B.x, B.y, B.z);
+        ray.color = mk3(C.x, C.y, C.z);
+        ray.fin = mk3(0.f, 0.f, 0.f);
+        ray.bf = __float_as_int(B.w);
+        bool skipping = false;
+        uint32_t hn = a.hitN[it];
+        int n = (int)(hn & 15u);
+        uint32_t poff = hn >> 4;
+
+        // hit composite, rayshading.comp:60-116
+        float uvt_t = INF;
+        float c_albedo[4] = {0, 0, 0, 0}, c_emission[4] = {0, 0, 0, 0}, c_mr[4] = {0, 0, 0, 0};
+        v3 c_normal = mk3(0, 0, 0);
+        int next = -1;
+        if (n > 0) {
+            int k = 0;
+            Surf s = surface_eval(a.hit0[it], a.tri48, a.nrm, a.tri_mats, a.mats, a.mat_offset, a.mat_count);
+            while (!s.active && k + 1 < n) {
+                k++;
+                s = surface_eval(a.pool[poff + k - 1], a.tri48, a.nrm, a.tri_mats, a.mats, a.mat_offset, a.mat_count);
+            }
+            uvt_t = s.t;
+            if (!s.active) {
+                c_normal = s.normal_trav;
+                next = -1;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) { c_albedo[c] = s.albedo[c]; c_emission[c] = s.emission[c]; c_mr[c] = s.mr[c]; }
+                c_normal = s.normal;
+                next = (k + 1 < n) ? k + 1 : -1;
+            }
+        }
+        for (int i = 0; i < 8; i++) {
+            if (next == -1) break;
+            Surf h = surface_eval(a.pool[poff + next - 1], a.tri48, a.nrm, a.tri_mats, a.mats, a.mat_offset, a.mat_count);
+            if (!equalF(uvt_t, h.t)) break;
+            if (!h.active) { next = (next + 1 < n) ? next + 1 : -1; continue; }
+            // composite(), rayshading.comp:25-28
+            float oa = c_albedo[3] + h.albedo[3] * (1.0f - c_albedo[3]);
+            float den = pmax(oa, 0.00001f);
+            float comp[4];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                comp[c] = pclamp((c_albedo[c] * c_albedo[3] + h.albedo[c] * h.albedo[3] * (1.0f - c_albedo[3])) / den, 0.f, 1.f);
+            comp[3] = pclamp(oa, 0.f, 1.f);
+            float aw = h.albedo[3];
+            uvt_t = h.t;
+#pragma unroll
+            for (int c = 0; c < 4; c++) c_albedo[c] = comp[c];
+            c_normal = mk3(mixf(c_normal.x, h.normal.x, aw), mixf(c_normal.y, h.normal.y, aw), mixf(c_normal.z, h.normal.z, aw));
+#pragma unroll
+            for (int c = 0; c < 4; c++) { c_mr[c] = mixf(c_mr[c], h.mr[c], aw); c_emission[c] = mixf(c_emission[c], h.emission[c], aw); }
+            if (c_albedo[3] > 0.99999f) break;
+            next = (next + 1 < n) ? next + 1 : -1;
+        }
+
+        // physical lights, :119-138
+        int lc = -1;
+        int type = R_TYPE(ray.bf);
+        if (R_DL(ray.bf) > 0 && (type == 1 || type == 2) && !skipping) {
+            int nl = a.light_count < 16 ? a.light_count : 16;
+            for (int i = 0; i < nl; i++) {
+                v3 ctr = lightCenter(a.lights[i]);
+                float dt = intersectSphere(ray.origin, ray.direct, ctr, a.lights[i].lightColor[3] + GAP);
+                float t = 1.0f * dt;
+                if (lessF(dt, INF) && lessEqualF(t, uvt_t)) lc = i;
+            }
+        }
+        if (lc >= 0 && (R_TARGET(ray.bf) == lc || type != 2)) {
+            ray.fin = mk3(ray.color.x * pmax(a.lights[lc].lightColor[0], 0.f), ray.color.y * pmax(a.lights[lc].lightColor[1], 0.f),
+                          ray.color.z * pmax(a.lights[lc].lightColor[2], 0.f));
+            ray.color = ray.color * 0.0f;
+            S_ACTIVE(ray.bf, 0);
+            skipping = true;
+        }
+        // background, :141-152 (constant sky)
+        if (greaterEqualF(uvt_t, INF) && type != 2 && !skipping) {
+            ray.fin = mk3(ray.color.x * a.sky[0], ray.color.y * a.sky[1], ray.color.z * a.sky[2]);
+            ray.color = ray.color * 0.0f;
+            S_ACTIVE(ray.bf, 0);
+            skipping = true;
+        }
+        // :155-161
+        ray.direct = normalize3(ray.direct);
+        ray.origin = mk3(ray.origin.x + ray.direct.x * uvt_t, ray.origin.y + ray.direct.y * uvt_t, ray.origin.z + ray.direct.z * uvt_t);
+        if (R_ACTIVE(ray.bf) < 1 || n == 0) skipping = true;
+
+        // :164-180
+        v3 normal;
+        {
+            float dn = dot3(c_normal, ray.direct);
+            normal = (dn < 0.0f) ? c_normal : mk3(-c_normal.x, -c_normal.y, -c_normal.z);
+        }
+        float refly = c_mr[0];
+        float pw = pclamp(ppow(pabs(dot3(ray.direct, normal)), 1.400f - 1.f), 0.0f, 1.0f);
+        float sm_ = sqrtf(c_mr[1]);
+        float diel = mixf(1.f, 0.05f, pw);
+        v3 sc = mk3(mixf(diel, c_albedo[0], sm_), mixf(diel, c_albedo[1], sm_), mixf(diel, c_albedo[2], sm_));
+        float emis = mlength3(mk3(c_emission[0], c_emission[1], c_emission[2]));
+        float spca = pclamp(mlength3(sc), 0.0f, 1.0f);
+        float prom = 1.0f - c_albedo[3];
+        float aprom = (type == 2) ? prom : ((g.next() < prom) ? 1.f : 0.f);
+
+        WRay diffuseRay = ray, reflectionRay = ray, emissiveRay = ray;
+        diffuseRay.fin = diffuseRay.fin * 0.0f;
+        reflectionRay.fin = reflectionRay.fin * 0.0f;
+        emissiveRay.fin = emissiveRay.fin * 0.0f;
+        if (!skipping) ray.fin = ray.fin * 0.f;
+
+        if (R_ACTIVE(ray.bf) > 0 && !skipping) {
+            ray.fin = ray.fin * 0.0f;
+            {  // diffuse(), shadinglib.glsl:106-119
+                WRay& r = diffuseRay;
+                r.color = r.color * mk3(c_albedo[0], c_albedo[1], c_albedo[2]);
+                r.direct = normalize3(randomCosine(g, normal));
+                r.origin = fma3(r.direct, GAP, r.origin);
+                S_ACTIVE(r.bf, R_TYPE(r.bf) == 2 ? 0 : R_ACTIVE(r.bf));
+                S_BOUNCE(r.bf, R_BOUNCE(r.bf) < 2 ? R_BOUNCE(r.bf) : 2);
+                S_TYPE(r.bf, 1);
+                S_DL(r.bf, 0);
+            }
+            {  // reflection(), shadinglib.glsl:139-148
+                WRay& r = reflectionRay;
+                v3 col = mk3(pclamp(sc.x / spca, 0.0f, 1.0f), pclamp(sc.y / spca, 0.0f, 1.0f), pclamp(sc.z / spca, 0.0f, 1.0f));
+                float dn = dot3(normal, r.direct);
+                v3 refl = mk3(r.direct.x - 2.0f * dn * normal.x, r.direct.y - 2.0f * dn * normal.y, r.direct.z - 2.0f * dn * normal.z);
+                v3 rc = randomCosine(g, normal);
+                float al = pclamp(refly * g.next(), 0.0f, 1.0f);
+                r.direct = normalize3(mk3(mixf(refl.x, rc.x, al), mixf(refl.y, rc.y, al), mixf(refl.z, rc.z, al)));
+                r.color = r.color * col;
+                r.origin = fma3(r.direct, GAP, r.origin);
+                S_DL(r.bf, (R_TYPE(r.bf) == 1) ? 0 : 1);
+                S_TYPE(r.bf, 0);
+                S_BOUNCE(r.bf, R_BOUNCE(r.bf) < 3 ? R_BOUNCE(r.bf) : 3);
+                S_ACTIVE(r.bf, R_TYPE(r.bf) == 2 ? 0 : R_ACTIVE(r.bf));
+            }
+            {  // emissive(), shadinglib.glsl:127-137
+                WRay& r = emissiveRay;
+                r.fin = mk3(pmax(r.color.x * c_emission[0], 0.0f), pmax(r.color.y * c_emission[1], 0.0f), pmax(r.color.z * c_emission[2], 0.0f));
+                if (R_TYPE(r.bf) == 1) r.fin = mk3(0.f, 0.f, 0.f);
+                else r.fin = mk3(pmax(r.fin.x, 0.0f), pmax(r.fin.y, 0.0f), pmax(r.fin.z, 0.0f));
+                r.color = r.color * 0.0f;
+                r.direct = normalize3(randomCosine(g, normal));
+                r.origin = fma3(r.direct, GAP, r.origin);
+                S_BOUNCE(r.bf, 0);
+                S_ACTIVE(r.bf, 0);
+                S_DL(r.bf, 0);
+            }
+            // promised(), shadinglib.glsl:121-125
+            S_BOUNCE(ray.bf, R_BOUNCE(ray.bf) + 1);
+            ray.origin = fma3(ray.direct, GAP, ray.origin);
+            ray.color = ray.color * aprom;
+            ray.fin = ray.fin * aprom;
+        } else {
+            reflectionRay.color = reflectionRay.color * 0.0f;
+            emissiveRay.color = emissiveRay.color * 0.0f;
+            diffuseRay.color = diffuseRay.color * 0.0f;
+            diffuseRay.fin = diffuseRay.fin * 0.0f;
+        }
+        if (!skipping) {
+            float om = 1.0f - aprom;
+            diffuseRay.color = diffuseRay.color * om;
+            diffuseRay.fin = diffuseRay.fin * om;
+            reflectionRay.color = reflectionRay.color * om;
+            emissiveRay.fin = emissiveRay.fin * ((1.0f - aprom) * (1.0f - pclamp(spca, 0.0f, 1.0f)));
+        }
+        if (R_BASIS(ray.bf) == 1 && aprom < 0.1f) S_BASIS(ray.bf, 0);
+
+        // reclaim current ray, :235-251
+        {
+            int bounce = R_BOUNCE(ray.bf) - 1;
+            ray.fin = mk3(pmax(0.0f, ray.fin.x), pmax(0.0f, ray.fin.y), pmax(0.0f, ray.fin.z));
+            ray.color = mk3(pmax(0.0f, ray.color.x), pmax(0.0f, ray.color.y), pmax(0.0f, ray.color.z));
+            if (bounce < 0 || mlength3(ray.color) < 0.0001f || n == 0) S_ACTIVE(ray.bf, 0);
+            S_BOUNCE(ray.bf, bounce >= 0 ? bounce : 0);
+            if (mlength3(ray.fin) >= 0.0001f && R_ACTIVE(ray.bf) == 0) deposit(ray.fin, in_texel, a.t_sum, a.t_flag);
+            if (R_ACTIVE(ray.bf) == 1) {
+                OutRay& o = outs[nout++];
+                o.A = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, __int_as_float(in_texel));
+                o.B = make_float4(ray.direct.x, ray.direct.y, ray.direct.z, __int_as_float(ray.bf));
+                o.C = make_float4(ray.color.x, ray.color.y, ray.color.z, __uint_as_float(in_pkey));
+            }
+        }
+        // emit new rays, :263-275
+        if (!skipping) {
+            float coef = pclamp((g.next() < spca) ? 1.0f : 0.0f, 0.0f, 1.0f);
+            reflectionRay.color = reflectionRay.color * coef;
+            diffuseRay.color = diffuseRay.color * (1.0f - coef);
+            WRay shadowRay = diffuseRay;
+            {  // directLight(0, diffuseRay, 1, normal), shadinglib.glsl:75-93
+                WRay& r = shadowRay;
+                S_ACTIVE(r.bf, R_TYPE(r.bf) == 2 ? 0 : R_ACTIVE(r.bf));
+                S_DL(r.bf, 1);
+                S_TYPE(r.bf, 2);
+                S_TARGET(r.bf, 0);
+                S_BOUNCE(r.bf, R_BOUNCE(r.bf) < 1 ? R_BOUNCE(r.bf) : 1);
+                v3 ctr = lightCenter(a.lights[0]);
+                v3 sd = randomDirectionInSphere(g);
+                v3 sl = fma3(sd, a.lights[0].lightColor[3] - 0.0001f, ctr);
+                v3 ldirect = normalize3(sl - r.origin);
+                float dist = len3(ctr - r.origin);
+                float q = a.lights[0].lightColor[3] / dist;
+                float weight = 1.0f - sqrtf(1.0f - pclamp(dot3(ldirect, normal) * 2.f * (q * q), 0.f, 1.f));
+                r.origin = fma3(r.direct, -GAP, r.origin);
+                r.direct = ldirect;
+                r.color = r.color * (1.0f * weight);
+                r.fin = r.fin * 0.f;
+                r.origin = fma3(r.direct, GAP, r.origin);
+            }
+            if (create_ray(diffuseRay, in_texel, child_key(in_pkey, 1u), outs[nout], a.t_sum, a.t_flag)) nout++;
+            if (create_ray(reflectionRay, in_texel, child_key(in_pkey, 2u), outs[nout], a.t_sum, a.t_flag)) nout++;
+            {
+                float ce = pclamp(emis, 0.0f, 1.0f);
+                emissiveRay.color = emissiveRay.color * ce;
+                emissiveRay.fin = emissiveRay.fin * ce;
+                OutRay dummy;
+                (void)create_ray(emissiveRay, in_texel, child_key(in_pkey, 4u), dummy, a.t_sum, a.t_flag);  // never active
+            }
+            {  // applyLight, shadinglib.glsl:181-189
+                bool off = (R_TYPE(diffuseRay.bf) == 2) || (dot3(c_normal, shadowRay.direct) < 0.f);
+                S_ACTIVE(shadowRay.bf, off ? 0 : R_ACTIVE(shadowRay.bf));
+                if (create_ray(shadowRay, in_texel, child_key(in_pkey, 3u), outs[nout], a.t_sum, a.t_flag)) nout++;
+            }
+        }
+    }
+    // ordered block compaction into this block's staging segment
+    uint32_t total;
+    uint32_t base = block_scan_excl<SHADE_BLOCK>(nout, scan_tmp, &total);
+    size_t seg = (size_t)blockIdx.x * SHADE_SEG;
+    for (uint32_t k = 0; k < nout; k++) {
+        a.sA[seg + base + k] = outs[k].A;
+        a.sB[seg + base + k] = outs[k].B;
+        a.sC[seg + base + k] = outs[k].C;
+    }
+    if (threadIdx.x == 0) a.blockCounts[blockIdx.x] = total;
+}
+
+// reloadQueuedRays, Pipeline.inl:325-359: next count (clamped to currentRayLimit), pool cursor reset
+__global__ __launch_bounds__(1024) void rt_scan_blocks(uint32_t* __restrict__ g, uint32_t nb, uint32_t limit,
+                                                       uint32_t* __restrict__ cnt, DevCounters* __restrict__ ctr) {
+    __shared__ uint32_t tmp[32];
+    uint32_t tid = threadIdx.x;
+    uint32_t chunk = (nb + 1023u) / 1024u;
+    uint32_t s = min(tid * chunk, nb), e = min(s + chunk, nb);
+    uint32_t sum = 0;
+    for (uint32_t i = s; i < e; i++) sum += g[i];
+    uint32_t total;
+    uint32_t run = block_scan_excl<1024>(sum, tmp, &total);
+    for (uint32_t i = s; i < e; i++) {
+        uint32_t v = g[i];
+        g[nb + i] = run;  // bases stored after the counts
+        run += v;
+    }
+    if (tid == 0) {
+        uint32_t next = total < limit ? total : limit;
+        if (total > limit) atomicAdd(&ctr->ray_limit_drops, (unsigned long long)(total - limit));
+        cnt[1] = next;
+        cnt[0] = next;
+        cnt[2] = 0;
+    }
+}
+
+__global__ __launch_bounds__(SHADE_BLOCK) void rt_compact(const float4* __restrict__ sA, const float4* __restrict__ sB,
+                                                          const float4* __restrict__ sC,
+                                                          const uint32_t* __restrict__ blocks, uint32_t nb,
+                                                          uint32_t limit, float4* __restrict__ qA,
+                                                          float4* __restrict__ qB, float4* __restrict__ qC) {
+    uint32_t b = blockIdx.x;
+    uint32_t count = blocks[b], base = blocks[nb + b];
+    size_t seg = (size_t)b * SHADE_SEG;
+    for (uint32_t j = threadIdx.x; j < count; j += SHADE_BLOCK) {
+        uint32_t dst = base + j;
+        if (dst < limit) {  // canonical overflow rule: drop past currentRayLimit
+            qA[dst] = sA[seg + j];
+            qB[dst] = sB[seg + j];
+            qC[dst] = sC[seg + j];
+        }
+    }
+}
+
+// ---- sampler.comp:37-97 + deinterlace/filter copies ----------------------------------------------
+__global__ __launch_bounds__(256) void rt_sample(uint32_t w, uint32_t h, uint32_t dw, uint32_t dh,
+                                                 const float2* __restrict__ t_coord, const float4* __restrict__ t_sum,
+                                                 const int32_t* __restrict__ t_flag, float4* __restrict__ presampled,
+                                                 float4* __restrict__ filtered, int samples_lock) {
+    uint32_t it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= dw * dh) return;
+    int px = (int)(it % dw), py = (int)(it / dw);
+    float ax = (float)w / (float)dw, ay = (float)h / (float)dh;
+    int sclx = (int)ceilf(ax), scly = (int)ceilf(ay);
+    int bx = (int)((float)px * ax), by = (int)((float)py * ay);
+    int samplecount = 0;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int x = -1; x <= sclx; x++) {
+        for (int y = -1; y <= scly; y++) {
+            int cx = bx + x, cy = by + y;
+            if (cx >= 0 && cx < (int)w && cy >= 0 && cy < (int)h) {
+                int ts = cy * (int)w + cx;
+                if (!t_flag[ts]) continue;
+                float2 co = t_coord[ts];
+                float sx = co.x * (float)dw, sy = co.y * (float)dh;
+                float dx = (sx - (float)px) + 0.00001f, dy = (sy - (float)py) + 0.00001f;
+                if (dx >= 0.0f && dx < 1.0f && dy >= 0.0f && dy < 1.0f) {
+                    samplecount++;
+                    float4 s = t_sum[ts];
+                    n0 += s.x; n1 += s.y; n2 += s.z;
+                }
+            }
+        }
+    }
+    float4 xs = presampled[it];
+    if (samplecount > 0) {
+        float sc = (float)samplecount;
+        n0 = n0 / sc; n1 = n1 / sc; n2 = n2 / sc;
+        float next = xs.w + sc;
+        float prev = xs.w;
+        float divisor = prev / next;
+        xs.x = fmaf(xs.x, divisor, n0 * (1.0f - divisor));
+        xs.y = fmaf(xs.y, divisor, n1 * (1.0f - divisor));
+        xs.z = fmaf(xs.z, divisor, n2 * (1.0f - divisor));
+        xs.w = (samples_lock > 0) ? pmin(next, (float)(samples_lock - 1)) : next;
+        presampled[it] = xs;
+    }
+    filtered[it] = xs;
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------
+
+int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time) {
+    psm_ctx* c = r->ctx;
+    Mat16 ci, pi;
+    for (int i = 0; i < 16; i++) { ci.m[i] = cam_inv[i]; pi.m[i] = proj_inv[i]; }
+    uint32_t n = r->w * r->h;
+    TimedScope ts(c, CAT_CAMERA);
+    rt_camera<<<(n + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, r->y0, r->y1, r->qA[r->cur], r->qB[r->cur],
+                                                      r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt);
+    PSM_HIP(c, hipGetLastError());
+    r->ray_count = (r->y1 - r->y0) * r->w;
+    r->count_valid = true;
+    return PSM_OK;
+}
+
+int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
+    psm_ctx* c = r->ctx;
+    uint32_t n = r->ray_count;
+    if (n == 0) return PSM_OK;
+    uint32_t nb = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
+    ShadeArgs a;
+    a.qA = r->qA[r->cur]; a.qB = r->qB[r->cur]; a.qC = r->qC[r->cur];
+    a.hit0 = r->hit0; a.hitN = r->hitN; a.pool = r->pool;
+    a.tri48 = b->d_tri48; a.nrm = b->d_nrm; a.tri_mats = b->d_mats;
+    a.mats = r->d_mats; a.lights = r->d_lights;
+    a.sA = r->sA; a.sB = r->sB; a.sC = r->sC;
+    a.blockCounts = r->d_block;
+    a.t_sum = r->t_sum; a.t_flag = r->t_flag;
+    a.nrays = n; a.time = time;
+    a.mat_offset = r->mat_offset; a.mat_count = (int)r->mat_count; a.light_count = (int)r->light_count;
+    a.sky[0] = r->sky[0]; a.sky[1] = r->sky[1]; a.sky[2] = r->sky[2];
+    int nxt = r->cur ^ 1;
+    {
+        TimedScope ts(c, CAT_SHADE);
+        rt_shade<<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->d_cnt, c->d_counters);
+        rt_compact<<<nb, SHADE_BLOCK, 0, c->stream>>>(r->sA, r->sB, r->sC, r->d_block, nb, r->limit, r->qA[nxt], r->qB[nxt],
+                                                      r->qC[nxt]);
+    }
+    PSM_HIP(c, hipGetLastError());
+    r->cur = nxt;
+    r->count_valid = false;
+    c->rounds++;
+    return PSM_OK;
+}
+
+int launch_rt_sample(psm_rt* r) {
+    psm_ctx* c = r->ctx;
+    uint32_t n = r->dw * r->dh;
+    TimedScope ts(c, CAT_SAMPLE);
+    rt_sample<<<(n + 255) / 256, 256, 0, c->stream>>>(r->w, r->h, r->dw, r->dh, r->t_coord, r->t_sum, r->t_flag,
+                                                      r->presampled, r->filtered, r->samples_lock);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+}  // namespace psm

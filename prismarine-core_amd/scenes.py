@@ -1,0 +1,448 @@
+"""Synthetic scenes and OBJ/MTL io for the path-tracing core.
+
+The reference ships no scene that matches the BASELINE configs (sponza.obj is not in the
+repository and its viewer only loads glTF, Source/Examples/Viewer.cpp:66-69), so the
+benchmark scenes are procedural:
+
+  cornell()      S-cornell      32 triangles, extents [-1,1]^3 (closed box + 2 blocks)
+  sponza_like()  S-sponza-like  262 267 triangles, an atrium ~30 x 12 x 18 units
+  stress()       S-stress       ~10 M triangles, jittered blob instances on a grid
+
+A scene is a dict of numpy arrays:
+  tris     float32 [N,3,3]  world-space triangle soup (what loader.comp appends,
+                            ShadersSDK/vertex/loader.comp:115-135)
+  normals  float32 [N,3,3]  per-vertex normals as stored in the normal mosaic (normalised;
+                            face normal where the mesh has none, loader.comp:119-128)
+  mats     int32   [N]      per-triangle material id (loader.comp:121)
+  materials list of dict    diffuse / specular / emissive (VirtualMaterial, Structs.hpp:240-262)
+  eye, view float32 [3]     default camera
+"""
+import math
+import os
+
+import numpy as np
+
+SEED_SPONZA = 0x5EED5A
+SEED_STRESS = 0x5EED10
+SPONZA_TRIS = 262267
+
+
+def face_normals(tris):
+    e1 = tris[:, 1] - tris[:, 0]
+    e2 = tris[:, 2] - tris[:, 0]
+    n = np.cross(e1, e2).astype(np.float32)
+    ln = np.sqrt((n * n).sum(1, keepdims=True))
+    ln[ln == 0] = 1.0
+    return (n / ln).astype(np.float32)
+
+
+def prepare_normals(tris, normals=None):
+    """loader.comp:119-128: keep a supplied normal when it is non-trivial, else the face normal."""
+    fn = face_normals(tris)
+    out = np.repeat(fn[:, None, :], 3, axis=1).astype(np.float32)
+    if normals is not None:
+        normals = np.asarray(normals, np.float32)
+        ok = np.abs(normals).max(axis=2) >= 1e-4
+        ln = np.sqrt((normals * normals).sum(2, keepdims=True))
+        ln[ln == 0] = 1.0
+        nn = (normals / ln).astype(np.float32)
+        out = np.where(ok[:, :, None], nn, out).astype(np.float32)
+    return np.ascontiguousarray(out)
+
+
+def _quad(p0, p1, p2, p3):
+    return [[p0, p1, p2], [p0, p2, p3]]
+
+
+def _box(lo, hi, faces="xXyYzZ"):
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    t = []
+    if "x" in faces:
+        t += _quad((x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0))
+    if "X" in faces:
+        t += _quad((x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1))
+    if "y" in faces:
+        t += _quad((x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1))
+    if "Y" in faces:
+        t += _quad((x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0))
+    if "z" in faces:
+        t += _quad((x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0))
+    if "Z" in faces:
+        t += _quad((x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1))
+    return t
+
+
+def _material(diffuse, specular=(0.0, 0.9, 0.0), emissive=(0.0, 0.0, 0.0)):
+    # specular.y = roughness, specular.z = metallic (surface.comp:189)
+    return {"diffuse": tuple(diffuse) + (1.0,), "specular": (0.0,) + tuple(specular[1:]) + (0.0,),
+            "emissive": tuple(emissive) + (1.0,)}
+
+
+def cornell(open_top=False):
+    """32 triangles: box (12) + short block (10) + tall block (10); 4 materials."""
+    tris, mats = [], []
+    box = _box((-1, -1, -1), (1, 1, 1))
+    box_m = [1, 1, 2, 2, 0, 0, 3, 3, 0, 0, 0, 0]  # -x red, +x green, floor, ceiling(light), back, front
+    if open_top:
+        keep = [i for i in range(12) if i not in (6, 7, 10, 11)]
+        box = [box[i] for i in keep]
+        box_m = [box_m[i] for i in keep]
+    tris += box
+    mats += box_m
+    b1 = _box((-0.65, -1.0, -0.1), (-0.05, -0.4, 0.5), faces="xXYzZ")
+    b2 = _box((0.1, -1.0, -0.7), (0.7, 0.2, -0.1), faces="xXYzZ")
+    tris += b1 + b2
+    mats += [0] * 20
+    if open_top:
+        # keep the triangle count at 32 with a thin shelf
+        tris += _quad((-1, 0.2, -1), (-1, 0.2, -0.6), (-0.2, 0.2, -0.6), (-0.2, 0.2, -1))
+        tris += _quad((0.2, 0.5, -1), (0.2, 0.5, -0.7), (1, 0.5, -0.7), (1, 0.5, -1))
+        mats += [0, 0, 0, 0]
+    tris = np.asarray(tris, np.float32)
+    assert tris.shape[0] == 32
+    materials = [_material((0.73, 0.73, 0.73)), _material((0.65, 0.05, 0.05)),
+                 _material((0.12, 0.45, 0.15)), _material((0.78, 0.78, 0.78), emissive=(17, 12, 4))]
+    eye = (0.0, 0.0, 0.97) if not open_top else (0.0, 1.2, 3.2)
+    return {"name": "cornell", "tris": tris, "normals": prepare_normals(tris),
+            "mats": np.asarray(mats, np.int32), "materials": materials,
+            "eye": np.asarray(eye, np.float32), "view": np.asarray((0.0, -0.1, -1.0), np.float32)}
+
+
+def _grid_patch(origin, du, dv, nu, nv, height=None):
+    """nu x nv quads spanning origin + s*du + t*dv, optional height(s,t)->offset along normal."""
+    s = np.linspace(0.0, 1.0, nu + 1, dtype=np.float64)
+    t = np.linspace(0.0, 1.0, nv + 1, dtype=np.float64)
+    S, T = np.meshgrid(s, t, indexing="ij")
+    o = np.asarray(origin, np.float64)
+    du = np.asarray(du, np.float64)
+    dv = np.asarray(dv, np.float64)
+    P = o + S[..., None] * du + T[..., None] * dv
+    if height is not None:
+        n = np.cross(du, dv)
+        n /= np.linalg.norm(n)
+        P = P + height(S, T)[..., None] * n
+    p00, p10, p11, p01 = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = np.stack([p00, p10, p11], axis=2)
+    t2 = np.stack([p00, p11, p01], axis=2)
+    return np.concatenate([t1.reshape(-1, 3, 3), t2.reshape(-1, 3, 3)], 0).astype(np.float32)
+
+
+def _revolve(center, profile_r, profile_y, nseg, a0=0.0, a1=2 * math.pi, axis="y"):
+    """Surface of revolution: rings given by (radius, height) profile. Returns tris, normals."""
+    ang = np.linspace(a0, a1, nseg + 1)
+    r = np.asarray(profile_r, np.float64)[:, None]
+    y = np.asarray(profile_y, np.float64)[:, None]
+    X = r * np.cos(ang)[None, :]
+    Z = r * np.sin(ang)[None, :]
+    Y = np.broadcast_to(y, X.shape)
+    P = np.stack([X, Y, Z], -1)
+    dr = np.gradient(np.asarray(profile_r, np.float64))
+    dy = np.gradient(np.asarray(profile_y, np.float64))
+    nx = dy[:, None] * np.cos(ang)[None, :]
+    nz = dy[:, None] * np.sin(ang)[None, :]
+    ny = np.broadcast_to(-dr[:, None], nx.shape)
+    Nn = np.stack([nx, ny, nz], -1)
+    Nn /= np.maximum(np.linalg.norm(Nn, axis=-1, keepdims=True), 1e-12)
+    if axis == "x":
+        P = P[..., [1, 0, 2]]
+        Nn = Nn[..., [1, 0, 2]]
+    elif axis == "z":
+        P = P[..., [0, 2, 1]]
+        Nn = Nn[..., [0, 2, 1]]
+    P = P + np.asarray(center, np.float64)
+
+    def quads(A):
+        a00, a10, a11, a01 = A[:-1, :-1], A[1:, :-1], A[1:, 1:], A[:-1, 1:]
+        t1 = np.stack([a00, a11, a10], axis=2)
+        t2 = np.stack([a00, a01, a11], axis=2)
+        return np.concatenate([t1.reshape(-1, 3, 3), t2.reshape(-1, 3, 3)], 0)
+
+    return quads(P).astype(np.float32), quads(Nn).astype(np.float32)
+
+
+def sponza_like(n_tris=SPONZA_TRIS, seed=SEED_SPONZA):
+    """Procedural atrium: floor, two storeys of colonnades, arches, curtains, vases; open roof."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    T, Nr, Mt = [], [], []
+
+    def add(tris, mat, normals=None):
+        T.append(tris)
+        Nr.append(prepare_normals(tris, normals))
+        Mt.append(np.full(tris.shape[0], mat, np.int32))
+
+    LX, LZ, H1, H2 = 15.0, 9.0, 5.0, 10.0
+    # floor with slight tile relief, gallery floors, outer walls, roof rim (open centre)
+    add(_grid_patch((-LX, 0, -LZ), (2 * LX, 0, 0), (0, 0, 2 * LZ), 96, 60,
+                    height=lambda s, t: -0.01 * ((np.floor(s * 48) + np.floor(t * 30)) % 2)), 0)
+    for z0, z1 in ((-LZ, -LZ + 3.2), (LZ - 3.2, LZ)):
+        add(_grid_patch((-LX, H1, z0), (2 * LX, 0, 0), (0, 0, z1 - z0), 64, 8), 1)
+        add(_grid_patch((-LX, H1 - 0.3, z1 if z0 < 0 else z0), (2 * LX, 0, 0), (0, 0.3, 0), 64, 1), 1)
+        add(_grid_patch((-LX, H2, z0), (2 * LX, 0, 0), (0, 0, z1 - z0), 64, 8), 1)
+    add(_grid_patch((-LX, 0, -LZ), (0, H2 + 2, 0), (0, 0, 2 * LZ), 24, 36), 1)
+    add(_grid_patch((LX, 0, -LZ), (0, 0, 2 * LZ), (0, H2 + 2, 0), 36, 24), 1)
+    add(_grid_patch((-LX, 0, -LZ), (2 * LX, 0, 0), (0, H2 + 2, 0), 60, 24), 1)
+    add(_grid_patch((-LX, 0, LZ), (0, H2 + 2, 0), (2 * LX, 0, 0), 24, 60), 1)
+    # colonnades: 2 storeys x 2 rows x 12 columns, fluted profile
+    cols_x = np.linspace(-LX + 2.0, LX - 2.0, 12)
+    for storey, (yb, yt) in enumerate(((0.0, H1 - 0.3), (H1, H2 - 0.3))):
+        for zc in (-LZ + 3.2, LZ - 3.2):
+            for xc in cols_x:
+                ys = np.concatenate([[0, 0.15, 0.3], np.linspace(0.35, 0.9, 12), [0.93, 0.97, 1.0]])
+                rs = np.concatenate([[0.55, 0.55, 0.42], 0.36 - 0.05 * np.linspace(0, 1, 12), [0.42, 0.5, 0.5]])
+                t, n = _revolve((xc, yb, zc), rs, yb * 0 + ys * (yt - yb), 40)
+                add(t, 2, n)
+    # arches between neighbouring columns (half tori) on both storeys
+    for yb in (H1 - 0.3 - 1.2, H2 - 0.3 - 1.2):
+        for zc in (-LZ + 3.2, LZ - 3.2):
+            for xa, xb in zip(cols_x[:-1], cols_x[1:]):
+                R = 0.5 * (xb - xa) - 0.45
+                k = np.linspace(0, math.pi, 17)
+                # tube of radius 0.18 swept on a half circle in the x-y plane
+                ring = np.linspace(0, 2 * math.pi, 11)
+                cx = 0.5 * (xa + xb)
+                P = np.zeros((17, 11, 3))
+                Nn = np.zeros((17, 11, 3))
+                for i, a in enumerate(k):
+                    c = np.array([cx + R * math.cos(a), yb + 0.6 * R * math.sin(a), zc])
+                    e = np.array([math.cos(a), 0.6 * math.sin(a), 0.0])
+                    e /= np.linalg.norm(e)
+                    P[i] = c + 0.18 * (np.cos(ring)[:, None] * e + np.sin(ring)[:, None] * np.array([0, 0, 1.0]))
+                    Nn[i] = np.cos(ring)[:, None] * e + np.sin(ring)[:, None] * np.array([0, 0, 1.0])
+                a00, a10, a11, a01 = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+                n00, n10, n11, n01 = Nn[:-1, :-1], Nn[1:, :-1], Nn[1:, 1:], Nn[:-1, 1:]
+                tt = np.concatenate([np.stack([a00, a10, a11], 2).reshape(-1, 3, 3),
+                                     np.stack([a00, a11, a01], 2).reshape(-1, 3, 3)], 0).astype(np.float32)
+                nn = np.concatenate([np.stack([n00, n10, n11], 2).reshape(-1, 3, 3),
+                                     np.stack([n00, n11, n01], 2).reshape(-1, 3, 3)], 0).astype(np.float32)
+                add(tt, 2, nn)
+    # draped curtains (height-field patches hanging between the storeys)
+    for i in range(8):
+        x0 = -LX + 3.0 + i * 3.4
+        zc = (-LZ + 3.25) if i % 2 == 0 else (LZ - 3.25)
+        ph = rng.uniform(0, 6.28, 3)
+        amp = rng.uniform(0.08, 0.22)
+        add(_grid_patch((x0, H1 + 0.2, zc), (2.6, 0, 0), (0, 3.8, 0), 72, 56,
+                        height=lambda s, t, ph=ph, amp=amp: amp * (np.sin(18 * s + ph[0]) * (0.3 + 0.7 * (1 - t)) +
+                                                                   0.35 * np.sin(41 * s + 7 * t + ph[1]))), 3 + (i % 3))
+    # vases / spheres with fine tessellation (small triangles: 3 decades of sizes overall)
+    for i in range(14):
+        xc = rng.uniform(-LX + 2.5, LX - 2.5)
+        zc = rng.uniform(-LZ + 4.5, LZ - 4.5)
+        sc = rng.uniform(0.25, 0.7)
+        ys = np.linspace(0, 1, 33)
+        rs = 0.12 + 0.5 * np.sin(np.pi * ys) ** 0.8 * (1 - 0.35 * ys)
+        t, n = _revolve((xc, 0.0, zc), sc * rs, sc * 1.6 * ys, 48)
+        add(t, 6, n)
+    tris = np.concatenate(T, 0)
+    normals = np.concatenate(Nr, 0)
+    mats = np.concatenate(Mt, 0)
+    have = tris.shape[0]
+    if have > n_tris:
+        tris, normals, mats = tris[:n_tris], normals[:n_tris], mats[:n_tris]
+    elif have < n_tris:
+        # filler: a finely tessellated hanging banner strip with exactly the missing count
+        miss = n_tris - have
+        nu = max(1, int(math.sqrt(miss / 2)))
+        nv = max(1, (miss // 2) // nu)
+        f = _grid_patch((-6.0, H1 + 0.5, 0.0), (12.0, 0, 0), (0, 3.5, 0.4), nu, nv,
+                        height=lambda s, t: 0.15 * np.sin(9 * s + 3 * t))
+        extra = miss - f.shape[0]
+        if extra > 0:
+            g = _grid_patch((-6.0, H1 + 0.3, 0.3), (12.0, 0, 0), (0, 0.15, 0), extra, 1)[:extra]
+            f = np.concatenate([f, g], 0)
+        f = f[:miss]
+        tris = np.concatenate([tris, f], 0)
+        normals = np.concatenate([normals, prepare_normals(f)], 0)
+        mats = np.concatenate([mats, np.full(miss, 4, np.int32)], 0)
+    assert tris.shape[0] == n_tris, tris.shape
+    materials = [
+        _material((0.62, 0.58, 0.52), specular=(0, 0.7, 0.0)),   # floor stone
+        _material((0.70, 0.66, 0.58), specular=(0, 0.9, 0.0)),   # walls
+        _material((0.74, 0.72, 0.66), specular=(0, 0.6, 0.0)),   # columns / arches
+        _material((0.60, 0.08, 0.07), specular=(0, 0.95, 0.0)),  # red curtain
+        _material((0.08, 0.25, 0.50), specular=(0, 0.95, 0.0)),  # blue curtain
+        _material((0.10, 0.42, 0.12), specular=(0, 0.95, 0.0)),  # green curtain
+        _material((0.80, 0.62, 0.25), specular=(0, 0.25, 0.8)),  # brass vases
+    ]
+    return {"name": "sponza_like", "tris": np.ascontiguousarray(tris, np.float32),
+            "normals": np.ascontiguousarray(normals, np.float32),
+            "mats": np.ascontiguousarray(mats, np.int32), "materials": materials,
+            "eye": np.asarray((-12.5, 4.2, 0.6), np.float32), "view": np.asarray((6.0, 4.6, -0.4), np.float32)}
+
+
+def stress(n_tris=10_000_000, seed=SEED_STRESS):
+    """Jittered copies of a ~4k-triangle blob on a 50x50 grid plus a ground plane."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    ys = np.linspace(0, 1, 33)
+    rs = 0.05 + 0.5 * np.sin(np.pi * ys)
+    blob, bn = _revolve((0, 0, 0), rs, ys, 62)  # 32*62*2 = 3968 triangles
+    per = blob.shape[0]
+    ground = _grid_patch((-110, 0, -110), (220, 0, 0), (0, 0, 220), 64, 64)
+    copies = (n_tris - ground.shape[0]) // per
+    side = int(math.ceil(math.sqrt(copies)))
+    T, Nr = [ground], [prepare_normals(ground)]
+    for c in range(copies):
+        gx, gz = c % side, c // side
+        s = rng.uniform(0.8, 1.9)
+        a = rng.uniform(0, 6.28)
+        R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], np.float32)
+        off = np.array([(gx - side / 2) * 4.0 + rng.uniform(-0.8, 0.8), 0.0,
+                        (gz - side / 2) * 4.0 + rng.uniform(-0.8, 0.8)], np.float32)
+        T.append((blob @ R.T) * np.float32(s) + off)
+        Nr.append(bn @ R.T)
+    tris = np.concatenate(T, 0).astype(np.float32)
+    normals = prepare_normals(tris, np.concatenate(Nr, 0))
+    mats = (np.arange(tris.shape[0]) // per % 3).astype(np.int32)
+    materials = [_material((0.7, 0.7, 0.7)), _material((0.7, 0.3, 0.2)), _material((0.2, 0.4, 0.7))]
+    return {"name": "stress", "tris": np.ascontiguousarray(tris), "normals": normals, "mats": mats,
+            "materials": materials, "eye": np.asarray((-60, 35, 70), np.float32),
+            "view": np.asarray((0, 0, 0), np.float32)}
+
+
+# ---------------------------------------------------------------------------
+# OBJ / MTL io (f1: geometry ingestion; triangles only, v/vn/f, usemtl, Kd/Ks/Ke)
+# ---------------------------------------------------------------------------
+
+def write_obj(path, scene):
+    tris, normals, mats = scene["tris"], scene["normals"], scene["mats"]
+    mtl = os.path.splitext(path)[0] + ".mtl"
+    with open(mtl, "w") as f:
+        for i, m in enumerate(scene["materials"]):
+            f.write("newmtl m%d\nKd %.6f %.6f %.6f\nKs %.6f %.6f %.6f\nKe %.6f %.6f %.6f\n\n" % (
+                (i,) + tuple(m["diffuse"][:3]) + tuple(m["specular"][:3]) + tuple(m["emissive"][:3])))
+    with open(path, "w") as f:
+        f.write("mtllib %s\n" % os.path.basename(mtl))
+        for p in tris.reshape(-1, 3):
+            f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for p in normals.reshape(-1, 3):
+            f.write("vn %.9g %.9g %.9g\n" % tuple(p))
+        cur = -1
+        for t in range(tris.shape[0]):
+            if mats[t] != cur:
+                cur = int(mats[t])
+                f.write("usemtl m%d\n" % cur)
+            a = 3 * t + 1
+            f.write("f %d//%d %d//%d %d//%d\n" % (a, a, a + 1, a + 1, a + 2, a + 2))
+
+
+def read_mtl(path):
+    names, mats = {}, []
+    cur = None
+    if not os.path.exists(path):
+        return names, mats
+    for line in open(path):
+        p = line.split()
+        if not p or p[0].startswith("#"):
+            continue
+        if p[0] == "newmtl":
+            cur = _material((0.8, 0.8, 0.8))
+            names[p[1]] = len(mats)
+            mats.append(cur)
+        elif cur is not None and p[0] == "Kd":
+            cur["diffuse"] = tuple(map(float, p[1:4])) + (1.0,)
+        elif cur is not None and p[0] == "Ks":
+            cur["specular"] = tuple(map(float, p[1:4])) + (0.0,)
+        elif cur is not None and p[0] == "Ke":
+            cur["emissive"] = tuple(map(float, p[1:4])) + (1.0,)
+    return names, mats
+
+
+def read_obj(path):
+    """Triangles (fans for polygons), optional vn, usemtl. Returns a scene dict."""
+    V, VN, T, TN, M = [], [], [], [], []
+    names, materials = {}, []
+    cur = 0
+    base = os.path.dirname(path)
+    for line in open(path):
+        p = line.split()
+        if not p or p[0].startswith("#"):
+            continue
+        if p[0] == "v":
+            V.append(tuple(map(float, p[1:4])))
+        elif p[0] == "vn":
+            VN.append(tuple(map(float, p[1:4])))
+        elif p[0] == "mtllib":
+            names, materials = read_mtl(os.path.join(base, p[1]))
+        elif p[0] == "usemtl":
+            if p[1] not in names:
+                names[p[1]] = len(materials)
+                materials.append(_material((0.8, 0.8, 0.8)))
+            cur = names[p[1]]
+        elif p[0] == "f":
+            idx = []
+            for tok in p[1:]:
+                q = tok.split("/")
+                vi = int(q[0])
+                ni = int(q[2]) if len(q) > 2 and q[2] else 0
+                idx.append((vi - 1 if vi > 0 else len(V) + vi, (ni - 1 if ni > 0 else len(VN) + ni) if ni else -1))
+            for k in range(1, len(idx) - 1):
+                tri = (idx[0], idx[k], idx[k + 1])
+                T.append([V[a] for a, _ in tri])
+                TN.append([VN[b] if b >= 0 else (0.0, 0.0, 0.0) for _, b in tri])
+                M.append(cur)
+    if not materials:
+        materials = [_material((0.8, 0.8, 0.8))]
+    tris = np.asarray(T, np.float32).reshape(-1, 3, 3)
+    normals = prepare_normals(tris, np.asarray(TN, np.float32).reshape(-1, 3, 3))
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    c, ext = 0.5 * (lo + hi), float((hi - lo).max())
+    return {"name": os.path.basename(path), "tris": tris, "normals": normals,
+            "mats": np.asarray(M, np.int32), "materials": materials,
+            "eye": (c + np.asarray((0.0, 0.6 * ext, 1.4 * ext))).astype(np.float32),
+            "view": c.astype(np.float32)}
+
+
+def materials_array(materials):
+    """VirtualMaterial[count] as a structured numpy array (128 B each, Structs.hpp:240-262)."""
+    dt = np.dtype([("diffuse", "<f4", 4), ("specular", "<f4", 4), ("transmission", "<f4", 4),
+                   ("emissive", "<f4", 4), ("ior", "<f4"), ("roughness", "<f4"), ("alpharef", "<f4"),
+                   ("unk0f", "<f4"), ("diffusePart", "<u4"), ("specularPart", "<u4"),
+                   ("bumpPart", "<u4"), ("emissivePart", "<u4"), ("flags", "<i4"), ("alphafunc", "<i4"),
+                   ("binding", "<i4"), ("bitfield", "<i4"), ("iModifiers0", "<i4", 4)])
+    assert dt.itemsize == 128
+    a = np.zeros(len(materials), dt)
+    for i, m in enumerate(materials):
+        a[i]["diffuse"] = m["diffuse"]
+        a[i]["specular"] = m["specular"]
+        a[i]["emissive"] = m["emissive"]
+        a[i]["ior"] = 1.0
+        a[i]["roughness"] = 0.0001
+    return a
+
+
+# ---------------------------------------------------------------------------
+# camera matrices (Pipeline.inl:298-312: perspective(pi/3, aspect, 0.001, 1000) x lookAt)
+# ---------------------------------------------------------------------------
+
+def look_at(eye, center, up=(0.0, 1.0, 0.0)):
+    eye, center, up = (np.asarray(v, np.float32) for v in (eye, center, up))
+    f = center - eye
+    f = f / np.float32(np.sqrt((f * f).sum()))
+    s = np.cross(f, up).astype(np.float32)
+    s = s / np.float32(np.sqrt((s * s).sum()))
+    u = np.cross(s, f).astype(np.float32)
+    m = np.eye(4, dtype=np.float32)
+    m[0, :3], m[1, :3], m[2, :3] = s, u, -f
+    m[0, 3], m[1, 3], m[2, 3] = -np.dot(s, eye), -np.dot(u, eye), np.dot(f, eye)
+    return m
+
+
+def perspective(fovy, aspect, znear, zfar):
+    t = np.float32(math.tan(fovy / 2.0))
+    m = np.zeros((4, 4), np.float32)
+    m[0, 0] = 1.0 / (aspect * t)
+    m[1, 1] = 1.0 / t
+    m[2, 2] = -(zfar + znear) / (zfar - znear)
+    m[3, 2] = -1.0
+    m[2, 3] = -(2.0 * zfar * znear) / (zfar - znear)
+    return m
+
+
+def camera_matrices(eye, view, width, height):
+    """Row-major (camInv, projInv) = inverse(lookAt), inverse(perspective) as float32[16]."""
+    cam = look_at(eye, view)
+    proj = perspective(math.pi / 3.0, float(width) / float(height), 0.001, 1000.0)
+    cam_inv = np.linalg.inv(cam.astype(np.float64)).astype(np.float32)
+    proj_inv = np.linalg.inv(proj.astype(np.float64)).astype(np.float32)
+    return np.ascontiguousarray(cam_inv.reshape(16)), np.ascontiguousarray(proj_inv.reshape(16))

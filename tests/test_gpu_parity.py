@@ -1,0 +1,328 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bit-exact for Morton codes, sort order, BVH topology + boxes and hit chains; bit-exact for the ray
+queues the shading kernel emits; accumulated radiance within 1e-4 relative (the only GPU/CPU
+difference left is the order of the float atomic adds into a texel).
+"""
+import numpy as np
+import pytest
+
+from util import bits, canonical_nodes
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(psm, ctx, scene):
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(scene["tris"].shape[0])
+    th.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+    return th
+
+
+def _scene(scenes, name):
+    if name == "cornell":
+        return scenes.cornell()
+    if name == "cornell_open":
+        return scenes.cornell(open_top=True)
+    if name == "sponza_small":
+        return scenes.sponza_like(n_tris=20011)
+    if name == "sponza":
+        return scenes.sponza_like()
+    raise KeyError(name)
+
+
+# ---------------------------------------------------------------------------- sort
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 4097, 100003, 2 ** 21 + 77])
+def test_sort_matches_oracle(psm, ctx, oracle, n):
+    rng = np.random.RandomState(n + 1)
+    keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
+    if n > 10:
+        keys[rng.randint(0, n, n // 3)] = keys[rng.randint(0, n, n // 3)]  # ties: stability matters
+        keys[: n // 8] &= np.uint64(0xFFFF)                                # short keys
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = psm.RadixSort(ctx).sort_arrays(keys, vals)
+    ok, ov = oracle.radix_sort(keys, vals.astype(np.int32))
+    assert np.array_equal(gk, ok)
+    assert np.array_equal(gv, ov.astype(np.uint32))
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(gk, keys[order]) and np.array_equal(gv, vals[order])
+
+
+def test_sort_all_equal_and_sorted_inputs(psm, ctx):
+    rs = psm.RadixSort(ctx)
+    n = 5000
+    k = np.full(n, 0x123456789ABCDEF, np.uint64)
+    gk, gv = rs.sort_arrays(k, np.arange(n, dtype=np.uint32))
+    assert np.array_equal(gv, np.arange(n, dtype=np.uint32))
+    k = np.arange(n, dtype=np.uint64)[::-1].copy() << np.uint64(40)
+    gk, gv = rs.sort_arrays(k, np.arange(n, dtype=np.uint32))
+    assert np.array_equal(gk, np.sort(k)) and np.array_equal(gv, np.arange(n, dtype=np.uint32)[::-1])
+
+
+# ---------------------------------------------------------------------------- build
+def _check_build(psm, ctx, oracle, scene, opt=None):
+    tris = scene["tris"]
+    ob = oracle.build_scene(tris, opt)
+    th = _load(psm, ctx, scene)
+    th.stage("bounds", opt)
+    info = th.info()
+    assert np.array_equal(bits(np.array(info.bounds_min)), bits(ob["mn"]))
+    assert np.array_equal(bits(np.array(info.bounds_max)), bits(ob["mx"]))
+    assert np.array_equal(bits(np.array(info.transform)), bits(ob["M"]))
+    th.stage("morton")
+    info = th.info()
+    n = ob["count"]
+    assert info.leaf_count == n
+    assert np.array_equal(th.download(psm.BVH_KEYS, np.uint64, n), ob["keys_unsorted"])
+    assert np.array_equal(th.download(psm.BVH_INDICES, np.uint32, n), np.arange(n, dtype=np.uint32))
+    lb = th.download(psm.BVH_LEAF_BOX, np.uint32, 4 * n).reshape(n, 4)
+    assert np.array_equal(lb, ob["leafs"]["box"])
+    assert np.array_equal(th.download(psm.BVH_LEAF_TRI, np.int32, n), ob["leafs"]["pdata"][:, 3])
+    th.stage("sort")
+    assert np.array_equal(th.download(psm.BVH_KEYS, np.uint64, n), ob["keys"])
+    assert np.array_equal(th.download(psm.BVH_INDICES, np.uint32, n), ob["idx"].astype(np.uint32))
+    th.stage("emit")
+    info = th.info()
+    if n >= 2:
+        link = th.download(psm.BVH_LINK, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+        pb = th.download(psm.BVH_PAIR_BOX, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
+        rg = th.download(psm.BVH_RANGE, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+        assert info.root == oracle.find_split(ob["keys"], 0, n - 1)
+        nodes = canonical_nodes(info.root, link, pb, rg, oracle.NODE_DT)
+        assert nodes.shape == ob["nodes"].shape
+        assert np.array_equal(nodes["pdata"], ob["nodes"]["pdata"])   # topology, ranges, triangle ids
+        assert np.array_equal(nodes["box"], ob["nodes"]["box"])       # fp16 boxes after refit
+    else:
+        assert info.root == -1
+    th.close()
+    return ob
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza_small", "sponza"])
+def test_build_matches_oracle(psm, ctx, oracle, scenes, name):
+    _check_build(psm, ctx, oracle, _scene(scenes, name))
+
+
+def test_build_with_ties_degenerates_and_opt(psm, ctx, oracle, scenes):
+    rng = np.random.RandomState(7)
+    base = scenes.sponza_like(n_tris=3001)["tris"]
+    tris = np.concatenate([base, base[:700], base[100:400], base[100:400]], 0)  # duplicate triangles: Morton ties
+    tris[5] = tris[5][0]          # degenerate (all three vertices equal) -> skipped by aabbmaker.comp:160
+    tris[77] = tris[77][1]
+    tris = tris[rng.permutation(tris.shape[0])]
+    sc = {"tris": np.ascontiguousarray(tris), "normals": scenes.prepare_normals(tris),
+          "mats": np.zeros(tris.shape[0], np.int32)}
+    ob = _check_build(psm, ctx, oracle, sc)
+    assert ob["count"] == tris.shape[0] - 2
+    assert (ob["keys"][1:] == ob["keys"][:-1]).sum() > 500
+    a = 0.3
+    opt = np.array([[np.cos(a), 0, np.sin(a), 0.5], [0, 1.3, 0, -1.0], [-np.sin(a), 0, np.cos(a), 2.0], [0, 0, 0, 1]],
+                   np.float64).reshape(16)
+    _check_build(psm, ctx, oracle, sc, opt)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_build_tiny(psm, ctx, oracle, scenes, n):
+    tris = scenes.cornell()["tris"][:n]
+    sc = {"tris": tris, "normals": scenes.prepare_normals(tris), "mats": np.zeros(n, np.int32)}
+    _check_build(psm, ctx, oracle, sc)
+
+
+# ---------------------------------------------------------------------------- camera + traverse
+def _setup_frame(psm, ctx, scenes, scene, w, h):
+    th = _load(psm, ctx, scene)
+    th.build()
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
+    return th, rt, ms, cam
+
+
+def _rays_equal(g, o):
+    assert g.shape == o.shape
+    for f in ("origin", "direct", "color"):
+        assert np.array_equal(bits(g[f]), bits(o[f])), f
+    for f in ("bitfield", "texel", "pkey"):
+        assert np.array_equal(g[f], o[f]), f
+
+
+def _hits_equal(gh, gc, oh, oc):
+    assert np.array_equal(gc, oc)
+    for k in range(8):
+        m = oc > k
+        assert np.array_equal(gh["tri"][m, k], oh["tri"][m, k])
+        for f in ("u", "v", "t"):
+            assert np.array_equal(bits(gh[f][m, k]), bits(oh[f][m, k])), (f, k)
+
+
+@pytest.mark.parametrize("name,w,h", [("cornell", 1280, 720), ("sponza_small", 320, 180), ("sponza", 480, 270)])
+def test_primary_rays_and_hits_bit_exact(psm, ctx, oracle, scenes, name, w, h):
+    """BASELINE config 2 (cornell 1280x720 primary rays) and the Sponza-class scene."""
+    scene = _scene(scenes, name)
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    ob = oracle.build_scene(scene["tris"])
+    cfg = oracle.make_cfg(w, h, material_count=len(scene["materials"]))
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    rt.camera_matrices(cam[0], cam[1], time=4242)
+    orays, ocoord, osum, oflag = oracle.camera(cfg, cam[0], cam[1], 4242)
+    grays = rt.download_rays()
+    _rays_equal(grays, orays)
+    s, c, f = rt.download_texels()
+    assert np.array_equal(bits(c), bits(ocoord)) and np.array_equal(f, oflag)
+    assert rt.intersection(th) == 1
+    gh, gc = rt.download_hits(w * h)
+    oh, oc, octr = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], orays["origin"], orays["direct"], 8)
+    _hits_equal(gh, gc, oh, oc)
+    st = ctx.stats()
+    assert st.node_visits == octr.node_visits and st.tri_tests == octr.tri_tests
+    assert st.stack_drops == octr.stack_drops and st.iter_caps == octr.iter_caps
+    assert st.rays_traced == w * h
+    ctx.stats_enable(False, False)
+    rt.close()
+    th.close()
+
+
+def test_traverse_random_rays_with_chains(psm, ctx, oracle, scenes):
+    """Rays aimed at shared edges / duplicated triangles: equal-distance hit chains (directTraverse.comp:287-305)."""
+    rng = np.random.RandomState(3)
+    base = scenes.sponza_like(n_tris=6007)["tris"]
+    tris = np.ascontiguousarray(np.concatenate([base, base[:1500]], 0))   # coplanar duplicates -> chains of 2
+    sc = {"tris": tris, "normals": scenes.prepare_normals(tris), "mats": np.zeros(tris.shape[0], np.int32),
+          "materials": scenes.cornell()["materials"], "eye": np.zeros(3, np.float32), "view": np.ones(3, np.float32)}
+    th = _load(psm, ctx, sc)
+    th.build()
+    ob = oracle.build_scene(tris)
+    n = 20000
+    tid = rng.randint(0, tris.shape[0], n)
+    w = rng.dirichlet((1, 1, 1), n).astype(np.float32)
+    w[: n // 4, 2] = 0  # exactly on an edge
+    w[: n // 4] /= w[: n // 4].sum(1, keepdims=True)
+    target = (tris[tid] * w[:, :, None]).sum(1)
+    origin = (target + rng.normal(0, 1, (n, 3)) * 3.0 + np.array([0, 4, 0])).astype(np.float32)
+    direct = (target - origin).astype(np.float32)
+    rays = np.zeros(n, psm.RAY_DT)
+    rays["origin"], rays["direct"], rays["color"] = origin, direct, 1.0
+    rays["bitfield"] = 1 | (3 << 8)
+    rays["texel"] = np.arange(n) % 100
+    rays["pkey"] = np.arange(n)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(128, 128)
+    rt.upload_rays(rays)
+    assert rt.intersection(th) == 1
+    gh, gc = rt.download_hits(n)
+    oh, oc, _ = oracle.traverse(ob["nodes"], tris, ob["M"], origin, direct, 8)
+    assert (oc > 1).sum() > 100
+    _hits_equal(gh, gc, oh, oc)
+    rt.close()
+    th.close()
+
+
+# ---------------------------------------------------------------------------- shade + full frames
+@pytest.mark.parametrize("name,w,h", [("cornell_open", 96, 96), ("sponza_small", 160, 90)])
+def test_shade_rounds_bit_exact_queues(psm, ctx, oracle, scenes, name, w, h):
+    scene = _scene(scenes, name)
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    ob = oracle.build_scene(scene["tris"])
+    mats = scenes.materials_array(scene["materials"])
+    cfg = oracle.make_cfg(w, h, material_count=len(mats))
+    lights = oracle.default_lights(1)
+    rt.camera_matrices(cam[0], cam[1], time=99)
+    orays, ocoord, osum, oflag = oracle.camera(cfg, cam[0], cam[1], 99)
+    rt.applyMaterials(ms)
+    for rnd in range(6):
+        if orays.shape[0] < 32:
+            break
+        assert rt.getRayCount() == orays.shape[0]
+        rt.intersection(th)
+        oh, oc, _ = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], orays["origin"], orays["direct"], 8)
+        gh, gc = rt.download_hits(orays.shape[0])
+        _hits_equal(gh, gc, oh, oc)
+        t = 1000 + rnd
+        rt.shade(time=t)
+        orays = oracle.shade(cfg, lights, mats, scene["mats"], scene["tris"], scene["normals"], t, orays, oh, oc, osum, oflag)
+        assert rt.raycountCache == orays.shape[0], rnd
+        _rays_equal(rt.download_rays(), orays)
+        s, c, f = rt.download_texels()
+        np.testing.assert_allclose(s[:, :3], osum[:, :3], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(s[:, 3], osum[:, 3])  # deposit counts
+    assert rnd >= 2
+    rt.close()
+    th.close()
+
+
+@pytest.mark.parametrize("name,w,h,frames", [("cornell_open", 64, 64, 3), ("sponza_small", 128, 72, 2)])
+def test_accumulated_radiance(psm, ctx, oracle, scenes, name, w, h, frames):
+    """Viewer.cpp:296-312 call order, several frames; accumulated radiance within 1e-4 relative."""
+    scene = _scene(scenes, name)
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    rt.setSeed(31337)
+    for _ in range(frames):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    img = rt.snapHdr()
+    ref, stats = oracle.render_frames(scene, w, h, frames=frames, seed=31337, nthreads=8)
+    assert stats["rays"] > w * h * frames
+    assert ref[..., :3].max() > 0.1
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    rt.close()
+    th.close()
+
+
+def test_tile_sharding_equals_full_frame(psm, ctx, scenes):
+    """rendering row tiles separately (bounce loop in lock step on the global ray count)
+    and merging texel sums reproduces the unsharded frame."""
+    scene = scenes.cornell(open_top=True)
+    w, h = 80, 64
+    th, rt0, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+
+    def run(tiles):
+        pipes = []
+        for (y0, y1) in tiles:
+            rt = psm.Pipeline(ctx, seed=5)
+            rt.resizeBuffers(w, h)
+            rt.resize(w, h)
+            rt.setTile(y0, y1)
+            rt.camera_matrices(cam[0], cam[1])
+            pipes.append(rt)
+        gens = [psm.sharded_rounds(rt, th, ms) for rt in pipes]
+        local = [next(g) for g in gens]
+        alive = [True] * len(gens)
+        while any(alive):
+            total = sum(local)
+            for i, g in enumerate(gens):
+                if alive[i]:
+                    try:
+                        local[i] = g.send(total)
+                    except StopIteration:
+                        alive[i] = False
+        sums = np.zeros((w * h, 4), np.float32)
+        for rt, (y0, y1) in zip(pipes, tiles):
+            s, c, f = rt.download_texels()
+            sums[y0 * w:y1 * w] = s[y0 * w:y1 * w]
+            rt.close()
+        return sums
+
+    full = run([(0, h)])
+    tiled = run([(0, 13), (13, 40), (40, h)])
+    assert full[:, :3].max() > 0.1
+    np.testing.assert_allclose(tiled[:, :3], full[:, :3], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(tiled[:, 3], full[:, 3])
+    rt0.close()
+    th.close()
+
+
+def test_errors_are_reported(psm, ctx):
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(4)
+    with pytest.raises(psm.PsmError):
+        th.loadTriangles(np.zeros((5, 9), np.float32))  # exceeds allocate() capacity
+    rt = psm.Pipeline(ctx)
+    with pytest.raises(psm.PsmError):
+        ctx.check(psm.lib().psm_rt_traverse(rt._h, th._h), "traverse before build")
+    rt.close()
+    th.close()

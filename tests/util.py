@@ -1,0 +1,80 @@
+"""Helpers shared by the parity tests."""
+import numpy as np
+
+
+def half2_key(p):
+    """fp16 pair bits -> per-half sortable keys with -0 < +0 (vectorised, uint32 in/out)."""
+    p = p.astype(np.uint32)
+    s = p & np.uint32(0x80008000)
+    m = (s >> np.uint32(15)) * np.uint32(0xFFFF)
+    return p ^ (m | np.uint32(0x80008000))
+
+
+def key_half2(k):
+    k = k.astype(np.uint32)
+    s = (~k) & np.uint32(0x80008000)
+    m = (s >> np.uint32(15)) * np.uint32(0xFFFF)
+    return k ^ (m | np.uint32(0x80008000))
+
+
+def _min16(a, b):
+    lo = np.minimum(a & 0xFFFF, b & 0xFFFF)
+    hi = np.minimum(a >> 16, b >> 16)
+    return (lo | (hi << 16)).astype(np.uint32)
+
+
+def _max16(a, b):
+    lo = np.maximum(a & 0xFFFF, b & 0xFFFF)
+    hi = np.maximum(a >> 16, b >> 16)
+    return (lo | (hi << 16)).astype(np.uint32)
+
+
+def box_union(a, b):
+    """a, b: uint32[...,4] packed fp16 boxes (mn.xy, mn.zw, mx.xy, mx.zw)."""
+    ka, kb = half2_key(a), half2_key(b)
+    out = np.empty_like(ka)
+    out[..., 0] = _min16(ka[..., 0], kb[..., 0])
+    out[..., 1] = _min16(ka[..., 1], kb[..., 1])
+    out[..., 2] = _max16(ka[..., 2], kb[..., 2])
+    out[..., 3] = _max16(ka[..., 3], kb[..., 3])
+    return key_half2(out)
+
+
+def canonical_nodes(root, link, pairbox, rng, node_dt):
+    """Renumber the split-gap tree of the HIP builder into the canonical BFS HlbvhNode array
+    (SURVEY a-9): root 0, the i-th internal node of a level gets children base+2i, base+2i+1,
+    internal children enqueued left then right."""
+    n_leaf = link.shape[0] + 1
+    nodes = np.zeros(2 * n_leaf - 1, node_dt)
+    parent = np.full(2 * n_leaf - 1, -1, np.int64)
+    cur = np.array([root], np.int64)
+    ids = np.array([0], np.int64)
+    next_id = 1
+    while cur.size:
+        L, R = link[cur, 0].astype(np.int64), link[cur, 1].astype(np.int64)
+        lid = next_id + 2 * np.arange(cur.size, dtype=np.int64)
+        rid = lid + 1
+        next_id += 2 * cur.size
+        nodes["pdata"][ids, 0] = lid
+        nodes["pdata"][ids, 1] = rid
+        nodes["pdata"][ids, 3] = -1
+        nodes["box"][lid] = pairbox[cur, 0:4]
+        nodes["box"][rid] = pairbox[cur, 4:8]
+        parent[lid] = ids
+        parent[rid] = ids
+        for child, cid, pos in ((L, lid, rng[cur, 0]), (R, rid, rng[cur, 1])):
+            leaf = child < 0
+            nodes["pdata"][cid[leaf], 0] = pos[leaf]
+            nodes["pdata"][cid[leaf], 1] = pos[leaf]
+            nodes["pdata"][cid[leaf], 3] = ~child[leaf]
+        ch = np.stack([L, R], 1).reshape(-1)
+        ci = np.stack([lid, rid], 1).reshape(-1)
+        keep = ch >= 0
+        cur, ids = ch[keep], ci[keep]
+    nodes["pdata"][:, 2] = parent
+    nodes["box"][0] = box_union(nodes["box"][1], nodes["box"][2])
+    return nodes
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
