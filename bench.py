@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native path-tracing core.
+
+Metric (BASELINE.json): Mrays/s and ms/frame on the Sponza-class scene, 1920x1080, 4 spp,
+at 1/2/4/8 MI355X.  One STEP = one frame = one pass of the hot path over one batch of input:
+full BVH rebuild (bounds, Morton, radix sort, emit) + camera + the bounce loop
+(traverse -> surface/shade -> queue hand-off) + sample, exactly the call order of
+GltfViewer::process() (reference Source/Examples/Viewer.cpp:296-312).  4 spp = 4 steps.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Multi-GPU: the frame is sharded by screen rows; the BVH is rebuilt redundantly on every GPU; the
+per-texel radiance of each tile is gathered to rank 0 (RCCL over xGMI) which runs the sampler.
+Total work is fixed by the config, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `value` = rays traced by all ranks / wall time of the K timed frames
+(inputs resident in HBM).  `roofline` prices the traversal kernel: algorithmic bytes
+(R*44 + V*64 + T*36) over its HIP-event time; `cpu_baseline` times the CPU oracle's
+traversal (oracle/, scalar C + OpenMP) on a bounded sample of the same rays.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="sponza_like", choices=["sponza_like", "cornell", "stress"])
+    ap.add_argument("--depth", type=int, default=16)  # Application.hpp:237
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=int, default=3_000_000)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    return ap.parse_args()
+
+
+def tile_rows(rank, world, height):
+    """Contiguous row strips; the last ranks get the remainder."""
+    per = (height + world - 1) // world
+    y0 = min(rank * per, height)
+    return y0, min(y0 + per, height), per
+
+
+class Dist:
+    """torch.distributed plumbing (backend nccl = RCCL on ROCm); only imported when world > 1."""
+
+    def __init__(self, world):
+        self.world = world
+        self.rank = 0
+        self.local_rank = 0
+        self.torch = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            self.rank = int(os.environ.get("RANK", "0"))
+            self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+            self.backend = os.environ.get("PSM_DIST_BACKEND", "nccl")
+            ndev = torch.cuda.device_count()
+            self.device_index = self.local_rank % max(ndev, 1)
+            torch.cuda.set_device(self.device_index)
+            dist.init_process_group(backend=self.backend, rank=self.rank, world_size=world)
+            self.dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
+        else:
+            self.device_index = 0
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def sum_int(self, v):
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def max_float(self, v):
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+class Renderer:
+    def __init__(self, psm, scenes, scene, args, dist):
+        self.psm, self.dist, self.args = psm, dist, args
+        self.scene = scene
+        self.ctx = psm.Context(dist.device_index)
+        self.th = psm.TriangleHierarchy(self.ctx)
+        self.th.allocate(scene["tris"].shape[0])
+        self.th.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+        self.ms = psm.MaterialSet()
+        for m in scene["materials"]:
+            self.ms.addSubmat(m)
+        w, h = args.width, args.height
+        self.rt = psm.Pipeline(self.ctx, seed=1000)
+        self.rt.resizeBuffers(w, h)
+        self.rt.resize(w, h)
+        self.y0, self.y1, self.per = tile_rows(dist.rank, dist.world, h)
+        self.rt.setTile(self.y0, self.y1)
+        self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
+        if dist.world > 1:
+            torch = dist.torch
+            gdev = torch.device("cuda", dist.device_index)
+            self.tile_dev = torch.zeros(self.per * w * 4, dtype=torch.float32, device=gdev)
+            self.all_dev = torch.zeros(dist.world * self.per * w * 4, dtype=torch.float32, device=gdev) if dist.rank == 0 else None
+
+    def frame(self, record=None):
+        """GltfViewer::process(), Viewer.cpp:296-312 (display excluded)."""
+        psm, rt, th, ms, dist = self.psm, self.rt, self.th, self.ms, self.dist
+        ms.loadToVGA()
+        th.markDirty()
+        th.build()
+        rt.camera_matrices(self.cam[0], self.cam[1])
+        gen = psm.sharded_rounds(rt, th, ms, self.args.depth)
+        local = next(gen)
+        while True:
+            total = dist.sum_int(local)
+            if record is not None and total >= 32 and local > 0:
+                record.append(rt.download_rays())
+            try:
+                local = gen.send(total)
+            except StopIteration:
+                break
+        self._gather()
+        if dist.rank == 0:
+            rt.sample()
+
+    def _gather(self):
+        dist = self.dist
+        if dist.world == 1:
+            return
+        torch, w = dist.torch, self.args.width
+        rows = self.y1 - self.y0
+        if rows > 0:
+            self.rt.get_texels_dev(self.y0, self.y1, self.tile_dev.data_ptr())
+        self.ctx.sync()
+        if dist.backend == "nccl":
+            if dist.rank == 0:
+                outs = list(self.all_dev.split(self.per * w * 4))
+                dist.dist.gather(self.tile_dev, outs, dst=0)
+            else:
+                dist.dist.gather(self.tile_dev, None, dst=0)
+            torch.cuda.synchronize()
+        else:  # host-staged rehearsal path (gloo)
+            host = self.tile_dev.cpu()
+            outs = [torch.zeros_like(host) for _ in range(dist.world)] if dist.rank == 0 else None
+            dist.dist.gather(host, outs, dst=0)
+            if dist.rank == 0:
+                self.all_dev.copy_(torch.cat(outs))
+                torch.cuda.synchronize()
+        if dist.rank == 0:
+            for r in range(1, dist.world):
+                y0, y1, _ = tile_rows(r, dist.world, self.args.height)
+                if y1 > y0:
+                    off = r * self.per * w * 4 * 4
+                    self.rt.set_texels_dev(y0, y1, self.all_dev.data_ptr() + off)
+
+
+def cpu_baseline(scene, ray_sets, args):
+    """CPU oracle traversal (scalar C restatement, OpenMP) on a bounded sample of the GPU's ray set."""
+    from oracle import oracle as O
+    O.build()
+    rays = np.concatenate(ray_sets)
+    n = rays.shape[0]
+    if n > args.cpu_sample_rays:
+        stride = n // args.cpu_sample_rays + 1
+        rays = rays[::stride]
+    t0 = time.time()
+    ob = O.build_scene(scene["tris"])
+    build_s = time.time() - t0
+    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    origins = np.ascontiguousarray(rays["origin"])
+    directs = np.ascontiguousarray(rays["direct"])
+    O.traverse(ob["nodes"], scene["tris"], ob["M"], origins[:20000], directs[:20000], threads, want_hits=False)  # warm-up
+    best = None
+    for _ in range(2):
+        t0 = time.time()
+        O.traverse(ob["nodes"], scene["tris"], ob["M"], origins, directs, threads, want_hits=False)
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": rays.shape[0] / best / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d of the %d rays of frame 0 (all bounce rounds, every %d-th ray), oracle psmo_traverse_batch, "
+                      "best of 2; oracle BVH build %.2f s on 1 core" % (rays.shape[0], n, max(1, n // max(rays.shape[0], 1)), build_s)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
+    dist = Dist(world)
+    psm = importlib.import_module("prismarine-core_amd")
+    scenes = importlib.import_module("prismarine-core_amd.scenes")
+    scene = {"sponza_like": scenes.sponza_like, "cornell": scenes.cornell, "stress": scenes.stress}[args.scene]()
+    R = Renderer(psm, scenes, scene, args, dist)
+    ctx = R.ctx
+
+    # untimed: warm-up frames; frame 0 doubles as the counting pass (V, T are deterministic per seed)
+    for i in range(max(args.warmup, 0)):
+        R.frame()
+    ctx.sync()
+
+    # counting pass: same seeds as the timed frames, counters on, timing off
+    R.rt.setSeed(1000)
+    R.rt.clearSampler()
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    ray_sets = [] if (dist.rank == 0 and not args.no_cpu_baseline) else None
+    for i in range(args.steps):
+        R.frame(record=ray_sets if i == 0 else None)
+    cnt = ctx.stats()
+    V, T, Rr = cnt.node_visits, cnt.tri_tests, cnt.rays_traced
+
+    # timed region: exactly K frames, HIP events on the traversal launches
+    R.rt.setSeed(1000)
+    R.rt.clearSampler()
+    ctx.stats_enable(True, False)
+    ctx.stats_reset()
+    dist.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        R.frame()
+    ctx.sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = dist.max_float(elapsed)
+    st = ctx.stats()
+    assert st.rays_traced == Rr, (st.rays_traced, Rr)
+    total_rays = dist.sum_int(int(st.rays_traced))
+
+    if dist.rank == 0:
+        img = R.rt.snapHdr()
+        alg_bytes = Rr * 44 + V * 64 + T * 36
+        launches = max(st.traverse_launches, 1)
+        avg_ms = st.traverse_ms / launches
+        achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec + ms/frame, Sponza 1920x1080 4spp",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "S-sponza-like %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
+                                   "per frame + camera + <=%d bounce rounds + sample" % (
+                                       scene["tris"].shape[0], args.width, args.height, args.depth),
+                       "scene": args.scene, "width": args.width, "height": args.height,
+                       "parallelism": "tile%d" % world},
+            "rays_per_frame": total_rays / args.steps,
+            "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
+            "stage_ms_per_frame": {"build": st.build_ms / args.steps, "sort": st.sort_ms / args.steps,
+                                   "camera": st.camera_ms / args.steps, "traverse": st.traverse_ms / args.steps,
+                                   "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rt_traverse", "launches": int(st.traverse_launches), "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes / launches,
+                         "R": int(Rr), "V": int(V), "T": int(T), "rank": 0},
+            "image_mean": float(img[..., :3].mean()),
+        }
+        if ray_sets is not None and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, ray_sets, args)
+        print(json.dumps(out))
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()
