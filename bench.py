@@ -49,59 +49,6 @@ def parse():
     return ap.parse_args()
 
 
-def tile_rows(rank, world, height):
-    """Contiguous row strips; the last ranks get the remainder."""
-    per = (height + world - 1) // world
-    y0 = min(rank * per, height)
-    return y0, min(y0 + per, height), per
-
-
-class Dist:
-    """torch.distributed plumbing (backend nccl = RCCL on ROCm); only imported when world > 1."""
-
-    def __init__(self, world):
-        self.world = world
-        self.rank = 0
-        self.local_rank = 0
-        self.torch = None
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            self.torch, self.dist = torch, dist
-            self.rank = int(os.environ.get("RANK", "0"))
-            self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
-            self.backend = os.environ.get("PSM_DIST_BACKEND", "nccl")
-            ndev = torch.cuda.device_count()
-            self.device_index = self.local_rank % max(ndev, 1)
-            torch.cuda.set_device(self.device_index)
-            dist.init_process_group(backend=self.backend, rank=self.rank, world_size=world)
-            self.dev = torch.device("cuda", self.device_index) if self.backend == "nccl" else torch.device("cpu")
-        else:
-            self.device_index = 0
-
-    def barrier(self):
-        if self.world > 1:
-            self.dist.barrier()
-
-    def sum_int(self, v):
-        if self.world == 1:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.int64, device=self.dev)
-        self.dist.all_reduce(t)
-        return int(t.item())
-
-    def max_float(self, v):
-        if self.world == 1:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def close(self):
-        if self.world > 1:
-            self.dist.destroy_process_group()
-
-
 class Renderer:
     def __init__(self, psm, scenes, scene, args, dist):
         self.psm, self.dist, self.args = psm, dist, args
@@ -117,7 +64,8 @@ class Renderer:
         self.rt = psm.Pipeline(self.ctx, seed=1000)
         self.rt.resizeBuffers(w, h)
         self.rt.resize(w, h)
-        self.y0, self.y1, self.per = tile_rows(dist.rank, dist.world, h)
+        self.pdist = importlib.import_module("prismarine-core_amd.dist")
+        self.y0, self.y1, self.per = self.pdist.tile_rows(dist.rank, dist.world, h)
         self.rt.setTile(self.y0, self.y1)
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if dist.world > 1:
@@ -133,16 +81,8 @@ class Renderer:
         th.markDirty()
         th.build()
         rt.camera_matrices(self.cam[0], self.cam[1])
-        gen = psm.sharded_rounds(rt, th, ms, self.args.depth)
-        local = next(gen)
-        while True:
-            total = dist.sum_int(local)
-            if record is not None and total >= 32 and local > 0:
-                record.append(rt.download_rays())
-            try:
-                local = gen.send(total)
-            except StopIteration:
-                break
+        on_round = (lambda local: record.append(rt.download_rays()) if local > 0 else None) if record is not None else None
+        self.pdist.run_rounds(dist, rt, th, ms, self.args.depth, on_round)
         self._gather()
         if dist.rank == 0:
             rt.sample()
@@ -157,22 +97,16 @@ class Renderer:
             self.rt.get_texels_dev(self.y0, self.y1, self.tile_dev.data_ptr())
         self.ctx.sync()
         if dist.backend == "nccl":
-            if dist.rank == 0:
-                outs = list(self.all_dev.split(self.per * w * 4))
-                dist.dist.gather(self.tile_dev, outs, dst=0)
-            else:
-                dist.dist.gather(self.tile_dev, None, dst=0)
+            dist.gather_to_root(self.tile_dev, self.all_dev)
             torch.cuda.synchronize()
         else:  # host-staged rehearsal path (gloo)
-            host = self.tile_dev.cpu()
-            outs = [torch.zeros_like(host) for _ in range(dist.world)] if dist.rank == 0 else None
-            dist.dist.gather(host, outs, dst=0)
+            got = dist.gather_to_root(self.tile_dev.cpu())
             if dist.rank == 0:
-                self.all_dev.copy_(torch.cat(outs))
+                self.all_dev.copy_(got)
                 torch.cuda.synchronize()
         if dist.rank == 0:
             for r in range(1, dist.world):
-                y0, y1, _ = tile_rows(r, dist.world, self.args.height)
+                y0, y1, _ = self.pdist.tile_rows(r, dist.world, self.args.height)
                 if y1 > y0:
                     off = r * self.per * w * 4 * 4
                     self.rt.set_texels_dev(y0, y1, self.all_dev.data_ptr() + off)
@@ -208,8 +142,9 @@ def cpu_baseline(scene, ray_sets, args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
-    dist = Dist(world)
     psm = importlib.import_module("prismarine-core_amd")
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    dist = pdist.Comm(world)
     scenes = importlib.import_module("prismarine-core_amd.scenes")
     scene = {"sponza_like": scenes.sponza_like, "cornell": scenes.cornell, "stress": scenes.stress}[args.scene]()
     R = Renderer(psm, scenes, scene, args, dist)

@@ -6,8 +6,8 @@
 // block with eight 1-bit ballot splits; here every tile of 256*ITEMS keys is ranked with wave64
 // match-any ballots, staged through LDS in digit order and written out as coalesced runs.
 //
-// Per pass: radix_hist (LDS digit histogram per tile) -> radix_scan (digit-major exclusive scan,
-// one workgroup) -> radix_scatter (rank + LDS staging + coalesced bucket writes).
+// Per pass: radix_hist (LDS digit histogram per tile) -> radix_scan (one workgroup per digit scans
+// its row of tile counts) -> radix_scatter (rank + LDS staging + coalesced bucket writes).
 #include "psm_common.h"
 #include "psm_internal.h"
 
@@ -35,26 +35,31 @@ __global__ __launch_bounds__(256) void radix_hist(const uint64_t* __restrict__ k
     ghist[tid * numTiles + tile] = h[tid];
 }
 
-// exclusive scan of E entries in place, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void radix_scan(uint32_t* __restrict__ g, uint32_t E) {
-    __shared__ uint32_t tmp[32];
-    uint32_t tid = threadIdx.x;
-    uint32_t chunk = (E + 1023u) / 1024u;
-    uint32_t s = tid * chunk, e = min(s + chunk, E);
-    uint32_t sum = 0;
-    for (uint32_t i = s; i < e; i++) sum += g[i];
-    uint32_t run = block_scan_excl<1024>(sum, tmp, nullptr);
-    for (uint32_t i = s; i < e; i++) {
-        uint32_t v = g[i];
-        g[i] = run;
-        run += v;
+// One workgroup per digit: exclusive scan of that digit's row of per-tile counts in place
+// (row-major ghist[digit][tile]); the row total goes to totals[digit]. The cross-digit base is a
+// 256-wide scan that every scatter workgroup redoes from `totals` (pfx-work.comp:34-70 did both
+// scans in ONE workgroup for the whole grid).
+__global__ __launch_bounds__(256) void radix_scan(uint32_t* __restrict__ g, uint32_t numTiles,
+                                                  uint32_t* __restrict__ totals) {
+    __shared__ uint32_t tmp[8];
+    uint32_t* row = g + (size_t)blockIdx.x * numTiles;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < numTiles; base += 256) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < numTiles ? row[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_scan_excl<256>(v, tmp, &total);
+        if (i < numTiles) row[i] = carry + ex;
+        carry += total;
     }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 template <int ITEMS>
 __global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                      uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                     const uint32_t* __restrict__ gscan, uint32_t numTiles,
+                                                     const uint32_t* __restrict__ gscan,
+                                                     const uint32_t* __restrict__ totals, uint32_t numTiles,
                                                      uint32_t n_max, const uint32_t* __restrict__ d_n, int shift) {
     constexpr uint32_t TILE = 256 * ITEMS;
     __shared__ uint64_t sk[TILE];
@@ -113,7 +118,8 @@ __global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict_
         }
         uint32_t ts = block_scan_excl<256>(run, tmp, nullptr);
         tstart[tid] = ts;
-        gbase[tid] = gscan[tid * numTiles + tile];
+        uint32_t dbase = block_scan_excl<256>(totals[tid], tmp, nullptr);  // keys with a smaller digit
+        gbase[tid] = dbase + gscan[tid * numTiles + tile];
     }
     __syncthreads();
 #pragma unroll
@@ -145,7 +151,7 @@ template <int ITEMS>
 static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n) {
     constexpr uint32_t TILE = 256 * ITEMS;
     uint32_t numTiles = (uint32_t)((n_max + TILE - 1) / TILE);
-    size_t E = (size_t)256 * numTiles;
+    size_t E = (size_t)256 * numTiles + 256;  // per-tile counts + 256 digit totals
     if (c->sort_cap < n_max) {
         if (c->sort_keys_tmp) (void)hipFree(c->sort_keys_tmp);
         if (c->sort_vals_tmp) (void)hipFree(c->sort_vals_tmp);
@@ -165,8 +171,9 @@ static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
     for (int pass = 0; pass < 8; pass++) {  // Radix.hpp:57: 64-bit keys, 8 passes
         int shift = pass * 8;
         radix_hist<ITEMS><<<numTiles, 256, 0, c->stream>>>(kin, c->sort_hist, numTiles, (uint32_t)n_max, d_n, shift);
-        radix_scan<<<1, 1024, 0, c->stream>>>(c->sort_hist, (uint32_t)E);
-        radix_scatter<ITEMS><<<numTiles, 256, 0, c->stream>>>(kin, vin, kout, vout, c->sort_hist, numTiles,
+        uint32_t* totals = c->sort_hist + (size_t)256 * numTiles;
+        radix_scan<<<256, 256, 0, c->stream>>>(c->sort_hist, numTiles, totals);
+        radix_scatter<ITEMS><<<numTiles, 256, 0, c->stream>>>(kin, vin, kout, vout, c->sort_hist, totals, numTiles,
                                                               (uint32_t)n_max, d_n, shift);
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;

@@ -1,0 +1,101 @@
+"""Tile sharding of one frame across the GPUs of a node -- host plumbing only.
+
+The reference has no multi-GPU path.  Radiance is per texel and no stage mixes texels, so a frame
+shards by screen rows: rank r owns rows [y0,y1); the BVH is rebuilt redundantly on every GPU; the
+per-texel frame radiance (sum rgb + deposit count, 16 B/texel) of every tile is gathered to rank 0
+with ONE collective per frame (RCCL over xGMI: torch.distributed backend "nccl"), and rank 0 runs
+the sampler over the whole image.  One tiny all-reduce per bounce round carries the global ray
+count so the reference's `getRayCount() < 32 -> stop` rule (Pipeline.inl:459-461) is applied to the
+whole frame: the sharded image equals the unsharded one.
+
+torch is imported lazily and only when world > 1.
+"""
+import os
+
+
+def tile_rows(rank, world, height):
+    """Contiguous row strips of ceil(height/world) rows; returns (y0, y1, rows_per_rank)."""
+    per = (height + world - 1) // world
+    y0 = min(rank * per, height)
+    return y0, min(y0 + per, height), per
+
+
+class Comm:
+    def __init__(self, world=1, backend=None, init=True):
+        self.world = world
+        self.rank = 0
+        self.local_rank = 0
+        self.device_index = 0
+        self.backend = backend or os.environ.get("PSM_DIST_BACKEND", "nccl")
+        self.torch = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            self.rank = int(os.environ.get("RANK", "0"))
+            self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+            if self.backend == "nccl":
+                ndev = torch.cuda.device_count()
+                self.device_index = self.local_rank % max(ndev, 1)
+                torch.cuda.set_device(self.device_index)
+                self.dev = torch.device("cuda", self.device_index)
+            else:
+                ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+                self.device_index = self.local_rank % ndev if ndev else 0
+                self.dev = torch.device("cpu")
+            if init and not dist.is_initialized():
+                dist.init_process_group(backend=self.backend, rank=self.rank, world_size=world)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def sum_int(self, v):
+        if self.world == 1:
+            return int(v)
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def max_float(self, v):
+        if self.world == 1:
+            return float(v)
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_to_root(self, tile, root_out=None):
+        """Gather equally sized 1-D tensors to rank 0. Returns the concatenated tensor on rank 0
+        (root_out if given), None elsewhere. `tile` must live on self.dev."""
+        if self.world == 1:
+            return tile
+        n = tile.numel()
+        if self.rank == 0:
+            if root_out is None:
+                root_out = self.torch.empty(self.world * n, dtype=tile.dtype, device=tile.device)
+            self.dist.gather(tile, list(root_out.split(n)), dst=0)
+            return root_out
+        self.dist.gather(tile, None, dst=0)
+        return None
+
+    def close(self):
+        if self.world > 1 and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def run_rounds(comm, rays, intersector, materials, depth=16, on_round=None):
+    """Drive sharded_rounds() of this rank in lock step with the other ranks."""
+    from . import sharded_rounds
+    gen = sharded_rounds(rays, intersector, materials, depth)
+    local = next(gen)
+    rounds = 0
+    while True:
+        total = comm.sum_int(local)
+        if on_round is not None and total >= 32:
+            on_round(local)
+        try:
+            local = gen.send(total)
+            rounds += 1
+        except StopIteration:
+            break
+    return rounds

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the CPU oracle.
+
+The reference ships no fixtures, so these freeze the oracle's own output on the
+32-triangle Cornell scene: sorted Morton codes, canonical BFS node array, per-pixel hit triangle /
+distance at 64x64, and accumulated radiance at a fixed seed.  Re-run only when the canonical
+semantics in DESIGN.md change deliberately.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+scenes = importlib.import_module("prismarine-core_amd.scenes")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+sc = scenes.cornell()
+b = O.build_scene(sc["tris"])
+w = h = 64
+cam = scenes.camera_matrices(sc["eye"], sc["view"], w, h)
+rays, *_ = O.camera(O.make_cfg(w, h), cam[0], cam[1], 4242)
+hits, counts, _ = O.traverse(b["nodes"], sc["tris"], b["M"], rays["origin"], rays["direct"])
+np.savez_compressed(os.path.join(HERE, "cornell_32.npz"), tris=sc["tris"], M=b["M"], keys=b["keys"], idx=b["idx"],
+                    nodes_pdata=b["nodes"]["pdata"], nodes_box=b["nodes"]["box"], hit_counts=counts,
+                    hit_tri=hits[:, 0]["tri"], hit_t=hits[:, 0]["t"])
+
+sc = scenes.cornell(open_top=True)
+img, stats = O.render_frames(sc, 48, 48, frames=2, seed=31337)
+np.savez_compressed(os.path.join(HERE, "cornell_open_radiance.npz"), image=img, rays=np.int64(stats["rays"]))
+print("wrote fixtures; rays", stats["rays"], "hit fraction", float((counts > 0).mean()))
