@@ -401,15 +401,15 @@ static float intersectCubeSingle(const float o[3], const float ray[3], const flo
         float norig = -o[k] * dr;
         float tMin = fmaf(cmn[k], dr, norig);
         float tMax = fmaf(cmx[k], dr, norig);
-        t1[k] = pmin(tMin, tMax);
-        t2[k] = pmax(tMin, tMax);
+        t1[k] = smin(tMin, tMax);
+        t2[k] = smax(tMin, tMax);
     }
-    float tNear = pmax(pmax(t1[0], t1[1]), t1[2]);
-    float tFar = pmin(pmin(t2[0], t2[1]), t2[2]);
+    float tNear = smax(smax(t1[0], t1[1]), t1[2]);
+    float tFar = smin(smin(t2[0], t2[1]), t2[2]);
     int isCube = greaterEqualF(tFar, tNear) && greaterEqualF(tFar, 0.0f);
     float inf = PSMO_INFINITY;
-    *near = isCube ? pmin(tNear, tFar) : inf;
-    *far = isCube ? pmax(tNear, tFar) : inf;
+    *near = isCube ? smin(tNear, tFar) : inf;
+    *far = isCube ? smax(tNear, tFar) : inf;
     return isCube ? (lessF(*near, 0.0f) ? *far : *near) : inf;
 }
 
@@ -422,15 +422,15 @@ static float intersectCubeChild(const float o[3], const float dr[3], const float
         float norig = -o[k] * dr[k];
         float tMin = fmaf(cmn[k], dr[k], norig);
         float tMax = fmaf(cmx[k], dr[k], norig);
-        t1[k] = pmin(tMin, tMax);
-        t2[k] = pmax(tMin, tMax);
+        t1[k] = smin(tMin, tMax);
+        t2[k] = smax(tMin, tMax);
     }
-    float tNear = pmax(pmax(t1[0], t1[1]), t1[2]);
-    float tFar = pmin(pmin(t2[0], t2[1]), t2[2]);
+    float tNear = smax(smax(t1[0], t1[1]), t1[2]);
+    float tFar = smin(smin(t2[0], t2[1]), t2[2]);
     float inf = PSMO_INFINITY;
     int isCube = ((tFar + PSMO_PZERO) >= tNear) && ((tFar + PSMO_PZERO) >= 0.0f);
-    *near = isCube ? pmin(tNear, tFar) : inf;
-    *far = isCube ? pmax(tNear, tFar) : inf;
+    *near = isCube ? smin(tNear, tFar) : inf;
+    *far = isCube ? smax(tNear, tFar) : inf;
     return ((*near + PSMO_PZERO) <= 0.0f) ? *far : *near;
 }
 
@@ -574,7 +574,7 @@ int psmo_traverse(const psmo_node* nodes, const float* tris, const float M[16],
     const float cmn[3] = {-0.00001f, -0.00001f, -0.00001f};
     const float cmx[3] = {1.00001f, 1.00001f, 1.00001f};
     float d = intersectCubeSingle(torig4, dirproj, cmn, cmx, &near, &far);
-    float toffset = pmax(near, 0.f);
+    float toffset = smax(near, 0.f);
     float origined[3], divident[3];
     for (int k = 0; k < 3; k++) {
         origined[k] = torig4[k] + dirproj[k] * toffset;
@@ -654,9 +654,22 @@ int psmo_traverse(const psmo_node* nodes, const float* tris, const float M[16],
 #include <omp.h>
 #endif
 
+void psmo_traverse_batch_ex(const psmo_node* nodes, const float* tris, const float M[16],
+                            const float* origins, const float* directs, int nrays, psmo_hit* hits,
+                            int32_t* counts, psmo_counters* ctr, int nthreads, uint32_t* per_ray_visits,
+                            uint32_t* per_ray_tests);
+
 void psmo_traverse_batch(const psmo_node* nodes, const float* tris, const float M[16],
                          const float* origins, const float* directs, int nrays, psmo_hit* hits,
                          int32_t* counts, psmo_counters* ctr, int nthreads) {
+    psmo_traverse_batch_ex(nodes, tris, M, origins, directs, nrays, hits, counts, ctr, nthreads, NULL, NULL);
+}
+
+/* same, plus optional per-ray visit / triangle-test counts (divergence studies) */
+void psmo_traverse_batch_ex(const psmo_node* nodes, const float* tris, const float M[16],
+                            const float* origins, const float* directs, int nrays, psmo_hit* hits,
+                            int32_t* counts, psmo_counters* ctr, int nthreads, uint32_t* per_ray_visits,
+                            uint32_t* per_ray_tests) {
     psmo_counters total;
     memset(&total, 0, sizeof(total));
 #ifdef _OPENMP
@@ -671,8 +684,11 @@ void psmo_traverse_batch(const psmo_node* nodes, const float* tris, const float 
 #endif
         for (int r = 0; r < nrays; r++) {
             psmo_hit tmp[PSMO_BAKED_CAP];
+            uint64_t v0 = local.node_visits, t0 = local.tri_tests;
             int c = psmo_traverse(nodes, tris, M, &origins[3 * r], &directs[3 * r], tmp, &local);
             counts[r] = c;
+            if (per_ray_visits) per_ray_visits[r] = (uint32_t)(local.node_visits - v0);
+            if (per_ray_tests) per_ray_tests[r] = (uint32_t)(local.tri_tests - t0);
             if (hits) {
                 for (int k = 0; k < PSMO_BAKED_CAP; k++) {
                     if (k < c) hits[(size_t)r * PSMO_BAKED_CAP + k] = tmp[k];

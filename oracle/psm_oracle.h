@@ -84,6 +84,10 @@ void psmo_traverse_batch(const psmo_node* nodes, const float* tris, const float 
                          const float* origins, const float* directs, int nrays,
                          psmo_hit* hits /* nrays*8 */, int32_t* counts, psmo_counters* ctr,
                          int nthreads);
+void psmo_traverse_batch_ex(const psmo_node* nodes, const float* tris, const float M[16],
+                            const float* origins, const float* directs, int nrays, psmo_hit* hits,
+                            int32_t* counts, psmo_counters* ctr, int nthreads, uint32_t* per_ray_visits,
+                            uint32_t* per_ray_tests);
 int psmo_brute_force(const float* tris, int ntris, const float origin[3],
                      const float direct[3], psmo_hit* best);
 

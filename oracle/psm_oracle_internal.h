@@ -12,6 +12,20 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 /* GLSL min/max: min(x,y) = y<x ? y : x ; max(x,y) = x<y ? y : x */
 static inline float pmin(float x, float y) { return (y < x) ? y : x; }
 static inline float pmax(float x, float y) { return (x < y) ? y : x; }
+/* slab tests: IEEE-754 minNum / maxNum (a NaN operand is ignored) with -0 < +0 -- what the
+ * v_min_f32 / v_max_f32 of the reference's own target hardware compute (GLSL leaves NaN undefined) */
+static inline float smin(float x, float y) {
+    if (x != x) return y;
+    if (y != y) return x;
+    if (x == y) return signbit(x) ? x : y;
+    return (y < x) ? y : x;
+}
+static inline float smax(float x, float y) {
+    if (x != x) return y;
+    if (y != y) return x;
+    if (x == y) return signbit(x) ? y : x;
+    return (x < y) ? y : x;
+}
 static inline float pclamp(float x, float lo, float hi) { return pmin(pmax(x, lo), hi); }
 static inline float psign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }

@@ -159,8 +159,17 @@ int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float p
     int w = cfg->width;
     float invw = 1.0f / (float)cfg->width, invh = 1.0f / (float)cfg->height;
     int n = 0;
-    for (int idx = y0 * w; idx < y1 * w; idx++) {
-        int x = idx % w, y = idx / w;
+    /* canonical queue order: bands of 8 rows, 8-wide tiles left to right, row-major inside a tile */
+    for (int q = 0; q < (y1 - y0) * w; q++) {
+        int band = q / (8 * w), rem = q % (8 * w);
+        int by = y0 + band * 8;
+        int bh = (y1 - by) < 8 ? (y1 - by) : 8;
+        int tx = rem / (8 * bh);
+        if (tx * 8 >= w) tx = (w - 1) / 8;
+        int tw = (w - tx * 8) < 8 ? (w - tx * 8) : 8;
+        int r2 = rem - tx * 8 * bh;
+        int y = by + r2 / tw, x = tx * 8 + r2 % tw;
+        int idx = y * w + x;
         rng_t g = {(uint32_t)idx, 0u, time << 5};
         float rx = rng_next(&g);
         float ry = rng_next(&g);

@@ -209,7 +209,7 @@ int psm_bvh_destroy(psm_bvh* b) {
     dev_free(b->d_pos); dev_free(b->d_nrm); dev_free(b->d_mats); dev_free(b->d_tri48);
     dev_free(b->d_keys); dev_free(b->d_idx); dev_free(b->d_leafbox); dev_free(b->d_leaftri);
     dev_free(b->d_block); dev_free(b->d_small); dev_free(b->d_opt); dev_free(b->d_seg);
-    dev_free(b->d_sorted_tri); dev_free(b->d_pairbox); dev_free(b->d_link); dev_free(b->d_range);
+    dev_free(b->d_sorted_tri); dev_free(b->d_pairbox); dev_free(b->d_link); dev_free(b->d_range); dev_free(b->d_node32);
     delete b;
     return PSM_OK;
 }
@@ -239,7 +239,7 @@ int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
     A(dev_alloc(c, &b->d_block, (n + 255) / 256 + 1)); A(dev_alloc(c, &b->d_small, (size_t)SM_WORDS));
     A(dev_alloc(c, &b->d_opt, (size_t)16)); A(dev_alloc(c, &b->d_seg, off));
     A(dev_alloc(c, &b->d_sorted_tri, n)); A(dev_alloc(c, &b->d_pairbox, 2 * n)); A(dev_alloc(c, &b->d_link, n));
-    A(dev_alloc(c, &b->d_range, n));
+    A(dev_alloc(c, &b->d_range, n)); A(dev_alloc(c, &b->d_node32, 2 * n));
     if (rc != PSM_OK) { psm_bvh_destroy(b); return rc; }
     if (hipMemsetAsync(b->d_small, 0, SM_WORDS * 4, c->stream) != hipSuccess) { psm_bvh_destroy(b); return PSM_ERR_HIP; }
     *out = b;
@@ -372,7 +372,7 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
 // ---- Pipeline -----------------------------------------------------------------------------------
 static void rt_free_grid(psm_rt* r) {
     for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); }
-    dev_free(r->sA); dev_free(r->sB); dev_free(r->sC); dev_free(r->d_block);
+    dev_free(r->sA); dev_free(r->sB); dev_free(r->sC); dev_free(r->d_block); dev_free(r->qT);
     dev_free(r->hit0); dev_free(r->hitN); dev_free(r->pool);
     dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag);
 }
@@ -429,7 +429,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     auto A = [&](int x) { if (rc == PSM_OK) rc = x; };
     for (int q = 0; q < 2; q++) { A(dev_alloc(c, &r->qA[q], L)); A(dev_alloc(c, &r->qB[q], L)); A(dev_alloc(c, &r->qC[q], L)); }
     A(dev_alloc(c, &r->sA, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sB, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sC, nb * SHADE_BLOCK * 4));
-    A(dev_alloc(c, &r->d_block, 2 * nb + 2));
+    A(dev_alloc(c, &r->d_block, 2 * nb + 2)); A(dev_alloc(c, &r->qT, 4 * L));
     A(dev_alloc(c, &r->hit0, L)); A(dev_alloc(c, &r->hitN, L));
     r->pool_cap = (uint32_t)std::max<size_t>(L / 2, 1024);  // hits buffer = L/2 in the reference, Pipeline.inl:193
     A(dev_alloc(c, &r->pool, (size_t)r->pool_cap));

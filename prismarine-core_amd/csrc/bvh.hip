@@ -349,7 +349,8 @@ PSM_D int find_split(const uint64_t* __restrict__ keys, int first, int last) {
 //    of the reference tree and below it findSplit halves ranges at (first+last)>>1.
 __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ keys, const int32_t* __restrict__ sorted_tri,
                                                 SegTree st, uint32_t* __restrict__ sm, uint4* __restrict__ pairbox,
-                                                int2* __restrict__ link, int2* __restrict__ range) {
+                                                int2* __restrict__ link, int2* __restrict__ range,
+                                                uint4* __restrict__ node32) {
     int count = (int)sm[SM_COUNT];
     int s = blockIdx.x * 256 + threadIdx.x;
     if (s == 0) sm[SM_ROOT] = (uint32_t)(count >= 2 ? find_split(keys, 0, count - 1) : -1);
@@ -419,6 +420,10 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     pairbox[2 * (size_t)s + 1] = rb;
     link[s] = lk;
     range[s] = make_int2(f, l);
+    // traversal record (trace.hip): xyz of both child boxes (the w halves are never read by the
+    // slab test) + both links = 32 bytes, one aligned pair of 16-byte loads per visit
+    node32[2 * (size_t)s + 0] = make_uint4(lb.x, (lb.y & 0xffffu) | (lb.z << 16), (lb.z >> 16) | (lb.w << 16), rb.x);
+    node32[2 * (size_t)s + 1] = make_uint4((rb.y & 0xffffu) | (rb.z << 16), (rb.z >> 16) | (rb.w << 16), (uint32_t)lk.x, (uint32_t)lk.y);
 }
 
 // ---- launch wrappers ----------------------------------------------------------------------------
@@ -476,7 +481,7 @@ int launch_bvh_emit(psm_bvh* b) {
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
     uint32_t grid = (n + 255u) / 256u;
     bvh_emit<<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
-                                          b->d_range);
+                                          b->d_range, b->d_node32);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }

@@ -73,6 +73,7 @@ struct psm_bvh {
     uint4* d_pairbox = nullptr;   // 2 x uint4 per internal node (split gap)
     int2* d_link = nullptr;
     int2* d_range = nullptr;
+    uint4* d_node32 = nullptr;    // traversal record per internal node: 12 fp16 box coords + 2 links (32 B)
 };
 
 struct psm_rt {
@@ -85,11 +86,13 @@ struct psm_rt {
     float4* qA[2] = {nullptr, nullptr};  // origin.xyz, texel
     float4* qB[2] = {nullptr, nullptr};  // direct.xyz, bitfield
     float4* qC[2] = {nullptr, nullptr};  // color.xyz, pkey
+    float4* qT = nullptr;         // 4 x float4 per ray: projected traversal inputs (rt_project)
     float4* sA = nullptr;         // staging (4 outputs per input ray, block-compacted)
     float4* sB = nullptr;
     float4* sC = nullptr;
     uint32_t* d_block = nullptr;  // per-block output counts / bases
-    uint32_t* d_cnt = nullptr;    // [0] current count, [1] next count, [2] chain pool cursor
+    uint32_t* d_cnt = nullptr;    // [0] current count, [1] next count, [2] chain pool cursor, [3],[4] ray cursors
+    int cursor = 0;               // which ray cursor the next persistent traversal launch uses
     float4* hit0 = nullptr;       // head of chain per ray: u, v, t, tri
     uint32_t* hitN = nullptr;     // chain length | pool offset << 4
     float4* pool = nullptr;       // chain entries beyond the head

@@ -27,6 +27,9 @@ PSM_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 // GLSL min/max: min(x,y) = y<x ? y : x ; max(x,y) = x<y ? y : x
 PSM_HD float pmin(float x, float y) { return (y < x) ? y : x; }
 PSM_HD float pmax(float x, float y) { return (x < y) ? y : x; }
+// slab tests: IEEE-754 minNum / maxNum (a NaN operand is ignored) with -0 < +0 = v_min_f32 / v_max_f32
+__device__ __forceinline__ float sminf(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float smaxf(float a, float b) { return __builtin_fmaxf(a, b); }
 PSM_HD float pclamp(float x, float lo, float hi) { return pmin(pmax(x, lo), hi); }
 PSM_HD float psign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 PSM_HD float pabs(float x) { return u2f(f2u(x) & 0x7fffffffu); }

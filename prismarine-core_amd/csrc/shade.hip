@@ -80,7 +80,14 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
     int bf = 0;
     S_ACTIVE(bf, 1); S_TYPE(bf, 0); S_DL(bf, 0); S_BOUNCE(bf, 4); S_BASIS(bf, 1);
     S_BOUNCE(bf, R_BOUNCE(bf) - 1);  // createRayIdx -> createRayStrict, rayslib.glsl:130-156
-    uint32_t q = idx - y0 * w;
+    // queue order: bands of 8 rows, 8-wide tiles left to right, row-major inside a tile, so one wave
+    // of primary rays covers an 8x8 pixel tile (queue order never changes results: RNG is per pkey)
+    uint32_t band = (y - y0) >> 3;
+    uint32_t by = y0 + band * 8;
+    uint32_t bh = min(8u, y1 - by);
+    uint32_t tx = x >> 3;
+    uint32_t tw = min(8u, w - tx * 8);
+    uint32_t q = band * 8 * w + tx * 8 * bh + (y - by) * tw + (x - tx * 8);
     qA[q] = make_float4(orig[0], orig[1], orig[2], __int_as_float((int)idx));
     qB[q] = make_float4(dir.x, dir.y, dir.z, __int_as_float(bf));
     qC[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(idx));
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(1024) void rt_scan_blocks(uint32_t* __restrict__ g,
         if (total > limit) atomicAdd(&ctr->ray_limit_drops, (unsigned long long)(total - limit));
         cnt[1] = next;
         cnt[0] = next;
-        cnt[2] = 0;
+        cnt[2] = 0;  // chain pool cursor
     }
 }
 
