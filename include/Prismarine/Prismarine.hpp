@@ -1,0 +1,10 @@
+#pragma once
+// Prismarine/Prismarine.hpp -- umbrella include (reference Include/Prismarine/Prismarine.hpp:3-9)
+#include "Utils.hpp"
+#include "Structs.hpp"
+#include "Radix.hpp"
+#include "VertexInstance.hpp"
+#include "TextureSet.hpp"
+#include "MaterialSet.hpp"
+#include "TriangleHierarchy.hpp"
+#include "Pipeline.hpp"

@@ -1,0 +1,109 @@
+// psm_glm.hpp -- the few glm types/functions the Prismarine host API mentions in its signatures.
+// If a real glm is on the include path it is used; otherwise this minimal stand-in (column-major,
+// glm conventions: m[col][row], perspective/lookAt right-handed, depth -1..1) keeps the headers
+// self-contained.  Host-side convenience only: kernels never see these types.
+#pragma once
+#if defined(__has_include)
+#if __has_include(<glm/glm.hpp>) && !defined(PSM_NO_SYSTEM_GLM)
+#include <glm/glm.hpp>
+#include <glm/gtc/matrix_transform.hpp>
+#include <glm/gtc/type_ptr.hpp>
+#define PSM_HAVE_GLM 1
+#endif
+#endif
+
+#ifndef PSM_HAVE_GLM
+#include <cmath>
+#include <cstddef>
+
+namespace glm {
+
+template <typename T> struct tvec2 { T x, y; tvec2() : x(0), y(0) {} tvec2(T a, T b) : x(a), y(b) {} };
+template <typename T> struct tvec3 {
+    T x, y, z;
+    tvec3() : x(0), y(0), z(0) {}
+    explicit tvec3(T s) : x(s), y(s), z(s) {}
+    tvec3(T a, T b, T c) : x(a), y(b), z(c) {}
+    template <typename U> tvec3(const tvec3<U>& o) : x(T(o.x)), y(T(o.y)), z(T(o.z)) {}
+    T& operator[](int i) { return (&x)[i]; }
+    const T& operator[](int i) const { return (&x)[i]; }
+};
+template <typename T> struct tvec4 {
+    T x, y, z, w;
+    tvec4() : x(0), y(0), z(0), w(0) {}
+    explicit tvec4(T s) : x(s), y(s), z(s), w(s) {}
+    tvec4(T a, T b, T c, T d) : x(a), y(b), z(c), w(d) {}
+    tvec4(const tvec3<T>& v, T d) : x(v.x), y(v.y), z(v.z), w(d) {}
+    T& operator[](int i) { return (&x)[i]; }
+    const T& operator[](int i) const { return (&x)[i]; }
+};
+template <typename T> inline tvec3<T> operator+(const tvec3<T>& a, const tvec3<T>& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> inline tvec3<T> operator-(const tvec3<T>& a, const tvec3<T>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> inline tvec3<T> operator*(const tvec3<T>& a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> inline tvec3<T> operator/(const tvec3<T>& a, T s) { return {a.x / s, a.y / s, a.z / s}; }
+template <typename T> inline T dot(const tvec3<T>& a, const tvec3<T>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> inline tvec3<T> cross(const tvec3<T>& a, const tvec3<T>& b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+template <typename T> inline tvec3<T> normalize(const tvec3<T>& a) { return a * (T(1) / std::sqrt(dot(a, a))); }
+
+template <typename T> struct tmat4 {
+    tvec4<T> c[4];
+    tmat4() : tmat4(T(1)) {}
+    explicit tmat4(T d) { for (int i = 0; i < 4; i++) c[i] = tvec4<T>(T(0)); c[0].x = c[1].y = c[2].z = c[3].w = d; }
+    template <typename U> explicit tmat4(const tmat4<U>& o) { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) c[i][j] = T(o.c[i][j]); }
+    tvec4<T>& operator[](int i) { return c[i]; }
+    const tvec4<T>& operator[](int i) const { return c[i]; }
+};
+template <typename T> inline tmat4<T> operator*(const tmat4<T>& a, const tmat4<T>& b) {
+    tmat4<T> r(T(0));
+    for (int col = 0; col < 4; col++) for (int row = 0; row < 4; row++) { T s = 0; for (int k = 0; k < 4; k++) s += a[k][row] * b[col][k]; r[col][row] = s; }
+    return r;
+}
+template <typename T> inline tmat4<T>& operator*=(tmat4<T>& a, const tmat4<T>& b) { a = a * b; return a; }
+template <typename T> inline tmat4<T> transpose(const tmat4<T>& m) { tmat4<T> r(T(0)); for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r[i][j] = m[j][i]; return r; }
+template <typename T> inline tmat4<T> inverse(const tmat4<T>& m) {
+    // cofactor expansion on the row-major view a[r][c] = m[c][r]
+    T a[16]; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) a[4 * r + c] = m[c][r];
+    T b00 = a[0] * a[5] - a[1] * a[4], b01 = a[0] * a[6] - a[2] * a[4], b02 = a[0] * a[7] - a[3] * a[4];
+    T b03 = a[1] * a[6] - a[2] * a[5], b04 = a[1] * a[7] - a[3] * a[5], b05 = a[2] * a[7] - a[3] * a[6];
+    T b06 = a[8] * a[13] - a[9] * a[12], b07 = a[8] * a[14] - a[10] * a[12], b08 = a[8] * a[15] - a[11] * a[12];
+    T b09 = a[9] * a[14] - a[10] * a[13], b10 = a[9] * a[15] - a[11] * a[13], b11 = a[10] * a[15] - a[11] * a[14];
+    T id = T(1) / (b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06);
+    T o[16] = {(a[5] * b11 - a[6] * b10 + a[7] * b09) * id, (-a[1] * b11 + a[2] * b10 - a[3] * b09) * id,
+               (a[13] * b05 - a[14] * b04 + a[15] * b03) * id, (-a[9] * b05 + a[10] * b04 - a[11] * b03) * id,
+               (-a[4] * b11 + a[6] * b08 - a[7] * b07) * id, (a[0] * b11 - a[2] * b08 + a[3] * b07) * id,
+               (-a[12] * b05 + a[14] * b02 - a[15] * b01) * id, (a[8] * b05 - a[10] * b02 + a[11] * b01) * id,
+               (a[4] * b10 - a[5] * b08 + a[7] * b06) * id, (-a[0] * b10 + a[1] * b08 - a[3] * b06) * id,
+               (a[12] * b04 - a[13] * b02 + a[15] * b00) * id, (-a[8] * b04 + a[9] * b02 - a[11] * b00) * id,
+               (-a[4] * b09 + a[5] * b07 - a[6] * b06) * id, (a[0] * b09 - a[1] * b07 + a[2] * b06) * id,
+               (-a[12] * b03 + a[13] * b01 - a[14] * b00) * id, (a[8] * b03 - a[9] * b01 + a[10] * b00) * id};
+    tmat4<T> r(T(0)); for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) r[cc][rr] = o[4 * rr + cc];
+    return r;
+}
+template <typename T> inline tmat4<T> translate(const tvec3<T>& v) { tmat4<T> r(T(1)); r[3].x = v.x; r[3].y = v.y; r[3].z = v.z; return r; }
+template <typename T> inline tmat4<T> scale(const tvec3<T>& v) { tmat4<T> r(T(1)); r[0].x = v.x; r[1].y = v.y; r[2].z = v.z; return r; }
+template <typename T> inline tmat4<T> lookAt(const tvec3<T>& eye, const tvec3<T>& center, const tvec3<T>& up) {
+    tvec3<T> f = normalize(center - eye), s = normalize(cross(f, up)), u = cross(s, f);
+    tmat4<T> r(T(1));
+    r[0][0] = s.x; r[1][0] = s.y; r[2][0] = s.z;
+    r[0][1] = u.x; r[1][1] = u.y; r[2][1] = u.z;
+    r[0][2] = -f.x; r[1][2] = -f.y; r[2][2] = -f.z;
+    r[3][0] = -dot(s, eye); r[3][1] = -dot(u, eye); r[3][2] = dot(f, eye);
+    return r;
+}
+template <typename T> inline tmat4<T> perspective(T fovy, T aspect, T zn, T zf) {
+    T t = std::tan(fovy / T(2));
+    tmat4<T> r(T(0));
+    r[0][0] = T(1) / (aspect * t); r[1][1] = T(1) / t; r[2][2] = -(zf + zn) / (zf - zn); r[2][3] = -T(1);
+    r[3][2] = -(T(2) * zf * zn) / (zf - zn);
+    return r;
+}
+template <typename T> inline T pi() { return T(3.14159265358979323846264338327950288); }
+template <typename T> inline const T* value_ptr(const tmat4<T>& m) { return &m.c[0].x; }
+template <typename T> inline const T* value_ptr(const tvec4<T>& v) { return &v.x; }
+
+typedef tvec2<float> vec2; typedef tvec3<float> vec3; typedef tvec4<float> vec4;
+typedef tvec2<int> ivec2; typedef tvec4<int> ivec4; typedef tvec4<unsigned> uvec4;
+typedef tvec3<double> dvec3; typedef tmat4<float> mat4; typedef tmat4<double> dmat4;
+
+}  // namespace glm
+#endif  // !PSM_HAVE_GLM

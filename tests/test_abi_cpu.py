@@ -66,3 +66,13 @@ def test_product_does_not_use_the_oracle():
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     for b in banned:
                         assert b not in txt, "%s references %r" % (os.path.join(dirpath, f), b)
+
+
+def test_dropin_headers_compile_and_link(tmp_path):
+    """The GL-free Include/Prismarine look-alike compiles (with its own mini glm) and links against libpsm_hip.so."""
+    exe = str(tmp_path / "viewer_order")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-DPSM_NO_SYSTEM_GLM",
+                           os.path.join(ROOT, "tests", "cpp", "viewer_order.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "prismarine-core_amd"), "-lpsm_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "prismarine-core_amd")])
+    assert os.path.exists(exe)

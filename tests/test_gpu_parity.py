@@ -326,3 +326,39 @@ def test_errors_are_reported(psm, ctx):
         ctx.check(psm.lib().psm_rt_traverse(rt._h, th._h), "traverse before build")
     rt.close()
     th.close()
+
+
+def test_cpp_header_layer_viewer_call_order(psm, ctx, oracle, scenes, tmp_path):
+    """include/Prismarine drop-in headers: the GltfViewer::process() call order (Viewer.cpp:296-312) in C++
+    through psm::TriangleHierarchy / psm::Pipeline gives the oracle's image (camera matrices are computed
+    by the header layer's own float glm math, so agreement is statistical, not bitwise)."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "viewer_order")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), "-DPSM_NO_SYSTEM_GLM",
+                           os.path.join(root, "tests", "cpp", "viewer_order.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "prismarine-core_amd"), "-lpsm_hip",
+                           "-Wl,-rpath," + os.path.join(root, "prismarine-core_amd")])
+    sc = scenes.cornell(open_top=True)
+    w, h, frames = 64, 48, 2
+    inp, out = str(tmp_path / "scene.bin"), str(tmp_path / "img.bin")
+    with open(inp, "wb") as f:
+        n = sc["tris"].shape[0]
+        f.write(struct.pack("<i", n))
+        f.write(sc["tris"].astype("<f4").tobytes())
+        f.write(sc["normals"].astype("<f4").tobytes())
+        f.write(sc["mats"].astype("<i4").tobytes())
+        f.write(struct.pack("<i", len(sc["materials"])))
+        for m in sc["materials"]:
+            f.write(np.asarray(list(m["diffuse"]) + list(m["specular"]), "<f4").tobytes())
+        f.write(np.asarray(sc["eye"], "<f4").tobytes())
+        f.write(np.asarray(sc["view"], "<f4").tobytes())
+    subprocess.check_call([exe, inp, str(w), str(h), str(frames), out])
+    img = np.fromfile(out, np.float32).reshape(h, w, 4)
+    ref, _ = oracle.render_frames(sc, w, h, frames=frames, seed=31337)
+    assert img[..., :3].max() > 0.1
+    assert abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) < 0.02 * float(ref[..., :3].mean())
+    close = np.abs(img[..., :3] - ref[..., :3]).max(-1) < 2e-3 + 1e-2 * ref[..., :3].max(-1)
+    assert close.mean() > 0.9
