@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=3_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path even on 1 GPU (rehearsal)")
     return ap.parse_args()
 
 
@@ -53,7 +54,13 @@ class Renderer:
     def __init__(self, psm, scenes, scene, args, dist):
         self.psm, self.dist, self.args = psm, dist, args
         self.scene = scene
-        self.ctx = psm.Context(dist.device_index)
+        self.pdist = importlib.import_module("prismarine-core_amd.dist")
+        stream = None
+        if dist.active and dist.backend == "nccl":
+            # run the kernels on torch's stream: RCCL calls and kernels are ordered without host syncs
+            stream = dist.torch.cuda.current_stream().cuda_stream
+            dist.same_stream = True
+        self.ctx = psm.Context(dist.device_index, stream=stream)
         self.th = psm.TriangleHierarchy(self.ctx)
         self.th.allocate(scene["tris"].shape[0])
         self.th.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
@@ -64,19 +71,20 @@ class Renderer:
         self.rt = psm.Pipeline(self.ctx, seed=1000)
         self.rt.resizeBuffers(w, h)
         self.rt.resize(w, h)
-        self.pdist = importlib.import_module("prismarine-core_amd.dist")
-        self.y0, self.y1, self.per = self.pdist.tile_rows(dist.rank, dist.world, h)
-        self.rt.setTile(self.y0, self.y1)
+        if dist.active:
+            self.rt.setTileInterleaved(dist.rank, dist.world)  # 8-row bands dealt round-robin
+            dist.initial_total = w * h
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
-        if dist.world > 1:
+        if dist.active:
             torch = dist.torch
             gdev = torch.device("cuda", dist.device_index)
-            self.tile_dev = torch.zeros(self.per * w * 4, dtype=torch.float32, device=gdev)
-            self.all_dev = torch.zeros(dist.world * self.per * w * 4, dtype=torch.float32, device=gdev) if dist.rank == 0 else None
+            self.per = self.pdist.interleaved_texels(0, dist.world, w, h) * 4  # rank 0 owns the most bands
+            self.tile_dev = torch.zeros(self.per, dtype=torch.float32, device=gdev)
+            self.all_dev = torch.zeros(dist.world * self.per, dtype=torch.float32, device=gdev) if dist.rank == 0 else None
 
     def frame(self, record=None):
         """GltfViewer::process(), Viewer.cpp:296-312 (display excluded)."""
-        psm, rt, th, ms, dist = self.psm, self.rt, self.th, self.ms, self.dist
+        rt, th, ms, dist = self.rt, self.th, self.ms, self.dist
         ms.loadToVGA()
         th.markDirty()
         th.build()
@@ -88,28 +96,23 @@ class Renderer:
             rt.sample()
 
     def _gather(self):
+        """ONE collective per frame: per-texel radiance of every tile -> rank 0 (RCCL gather over xGMI)."""
         dist = self.dist
-        if dist.world == 1:
+        if not dist.active:
             return
-        torch, w = dist.torch, self.args.width
-        rows = self.y1 - self.y0
-        if rows > 0:
-            self.rt.get_texels_dev(self.y0, self.y1, self.tile_dev.data_ptr())
-        self.ctx.sync()
+        torch = dist.torch
+        self.rt.pack_texels_dev(self.tile_dev.data_ptr())
         if dist.backend == "nccl":
-            dist.gather_to_root(self.tile_dev, self.all_dev)
-            torch.cuda.synchronize()
+            dist.gather_to_root(self.tile_dev, self.all_dev)  # same stream as the kernels: no host sync
         else:  # host-staged rehearsal path (gloo)
+            self.ctx.sync()
             got = dist.gather_to_root(self.tile_dev.cpu())
             if dist.rank == 0:
                 self.all_dev.copy_(got)
                 torch.cuda.synchronize()
         if dist.rank == 0:
             for r in range(1, dist.world):
-                y0, y1, _ = self.pdist.tile_rows(r, dist.world, self.args.height)
-                if y1 > y0:
-                    off = r * self.per * w * 4 * 4
-                    self.rt.set_texels_dev(y0, y1, self.all_dev.data_ptr() + off)
+                self.rt.unpack_texels_dev(True, r, dist.world, self.all_dev.data_ptr() + r * self.per * 4)
 
 
 def cpu_baseline(scene, ray_sets, args):
@@ -144,7 +147,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
     psm = importlib.import_module("prismarine-core_amd")
     pdist = importlib.import_module("prismarine-core_amd.dist")
-    dist = pdist.Comm(world)
+    dist = pdist.Comm(world, force=args.force_dist)
     scenes = importlib.import_module("prismarine-core_amd.scenes")
     scene = {"sponza_like": scenes.sponza_like, "cornell": scenes.cornell, "stress": scenes.stress}[args.scene]()
     R = Renderer(psm, scenes, scene, args, dist)

@@ -72,6 +72,7 @@ def lib():
         _lib.psmo_traverse.restype = C.c_int
         _lib.psmo_brute_force.restype = C.c_int
         _lib.psmo_camera.restype = C.c_int
+        _lib.psmo_camera_interleaved.restype = C.c_int
         _lib.psmo_shade.restype = C.c_int
         _lib.psmo_rand_next.restype = C.c_uint32
     return _lib
@@ -231,6 +232,18 @@ def camera(cfg, cam_inv, proj_inv, time, y0=0, y1=None):
                           _p(np.ascontiguousarray(proj_inv, np.float32)), C.c_uint32(time),
                           C.c_int(y0), C.c_int(y1), _p(rays), _p(coord), _p(tsum), _p(flag))
     return rays[:n], coord, tsum, flag
+
+
+def camera_interleaved(cfg, cam_inv, proj_inv, time, rank, world):
+    wh = cfg.width * cfg.height
+    rays = np.zeros(wh, RAY_DT)
+    coord = np.zeros((wh, 2), np.float32)
+    tsum = np.zeros((wh, 4), np.float32)
+    flag = np.zeros(wh, np.int32)
+    n = lib().psmo_camera_interleaved(C.byref(cfg), _p(np.ascontiguousarray(cam_inv, np.float32)),
+                                      _p(np.ascontiguousarray(proj_inv, np.float32)), C.c_uint32(time),
+                                      C.c_int(rank), C.c_int(world), _p(rays), _p(coord), _p(tsum), _p(flag))
+    return rays[:n].copy(), coord, tsum, flag
 
 
 def shade(cfg, lights, materials, tri_mats, tris, normals, time, rays, hits, counts, tsum, flag):

@@ -132,6 +132,9 @@ typedef struct {
 int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
                 uint32_t time, int y0, int y1, psmo_ray* rays, float* texel_coord,
                 float* texel_sum, int32_t* texel_flag);
+int psmo_camera_interleaved(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                            uint32_t time, int rank, int world, psmo_ray* rays, float* texel_coord,
+                            float* texel_sum, int32_t* texel_flag);
 int psmo_shade(const psmo_frame_cfg* cfg, const psmo_light* lights, const psmo_material* mats,
                const int32_t* tri_mats, const float* tris, const float* normals, uint32_t time,
                const psmo_ray* rays, int nrays, const psmo_hit* hits, const int32_t* counts,

@@ -153,17 +153,17 @@ static inline float mixf(float x, float y, float a) { return x * (1.0f - a) + y 
 /* ------------------------------------------------------------------ */
 /* camera, raytracing/camera.comp:22-101                               */
 /* ------------------------------------------------------------------ */
-int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
-                uint32_t time, int y0, int y1, psmo_ray* rays, float* texel_coord,
-                float* texel_sum, int32_t* texel_flag) {
+/* camera over a list of row bands (band b covers rows band_y[b] .. band_y[b]+band_h[b]-1, height <= 8).
+ * canonical queue order: bands in list order, 8-wide tiles left to right, row-major inside a tile */
+static int camera_bands(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                        uint32_t time, const int* band_y, const int* band_h, int nbands, psmo_ray* rays,
+                        float* texel_coord, float* texel_sum, int32_t* texel_flag) {
     int w = cfg->width;
     float invw = 1.0f / (float)cfg->width, invh = 1.0f / (float)cfg->height;
     int n = 0;
-    /* canonical queue order: bands of 8 rows, 8-wide tiles left to right, row-major inside a tile */
-    for (int q = 0; q < (y1 - y0) * w; q++) {
-        int band = q / (8 * w), rem = q % (8 * w);
-        int by = y0 + band * 8;
-        int bh = (y1 - by) < 8 ? (y1 - by) : 8;
+    for (int b = 0; b < nbands; b++)
+    for (int rem = 0; rem < band_h[b] * w; rem++) {
+        int by = band_y[b], bh = band_h[b];
         int tx = rem / (8 * bh);
         if (tx * 8 >= w) tx = (w - 1) / 8;
         int tw = (w - tx * 8) < 8 ? (w - tx * 8) : 8;
@@ -202,6 +202,33 @@ int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float p
         r.pkey = (uint32_t)idx;
         rays[n++] = r;
     }
+    return n;
+}
+
+/* rows [y0,y1) in bands of 8 from y0 */
+int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                uint32_t time, int y0, int y1, psmo_ray* rays, float* texel_coord,
+                float* texel_sum, int32_t* texel_flag) {
+    int nb = (y1 - y0 + 7) / 8;
+    int* by = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
+    int* bh = (int*)malloc(sizeof(int) * (size_t)(nb + 1));
+    for (int b = 0; b < nb; b++) { by[b] = y0 + 8 * b; bh[b] = (y1 - by[b]) < 8 ? (y1 - by[b]) : 8; }
+    int n = camera_bands(cfg, camInv, projInv, time, by, bh, nb, rays, texel_coord, texel_sum, texel_flag);
+    free(by); free(bh);
+    return n;
+}
+
+/* interleaved sharding: rank owns the global 8-row bands g with g % world == rank */
+int psmo_camera_interleaved(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                            uint32_t time, int rank, int world, psmo_ray* rays, float* texel_coord,
+                            float* texel_sum, int32_t* texel_flag) {
+    int h = cfg->height;
+    int ng = (h + 7) / 8, nb = 0;
+    int* by = (int*)malloc(sizeof(int) * (size_t)(ng + 1));
+    int* bh = (int*)malloc(sizeof(int) * (size_t)(ng + 1));
+    for (int g = rank; g < ng; g += world) { by[nb] = 8 * g; bh[nb] = (h - 8 * g) < 8 ? (h - 8 * g) : 8; nb++; }
+    int n = camera_bands(cfg, camInv, projInv, time, by, bh, nb, rays, texel_coord, texel_sum, texel_flag);
+    free(by); free(bh);
     return n;
 }
 

@@ -20,16 +20,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpsm_hip.so")
 
 EXPORTS = [
-    "psm_device_count", "psm_ctx_create", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
+    "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev",
     "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_build",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
-    "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile",
+    "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
     "psm_rt_traverse", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
-    "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_download_rays", "psm_rt_download_hits",
+    "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
+    "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
 ]
@@ -87,9 +88,14 @@ def _p(a):
 class Context:
     """One GPU, one in-order stream (the reference's single GL context, Viewer.cpp:371)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """stream: an existing hipStream_t (int), e.g. torch.cuda.current_stream().cuda_stream, so kernels
+        and RCCL collectives are ordered on one stream without host synchronisation."""
         self._h = C.c_void_p()
-        rc = lib().psm_ctx_create(C.c_int(device), C.byref(self._h))
+        if stream is None:
+            rc = lib().psm_ctx_create(C.c_int(device), C.byref(self._h))
+        else:
+            rc = lib().psm_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h))
         if rc != 0:
             raise PsmError("psm_ctx_create(device=%d) failed with %d: a gfx950 (MI355X) device is required; "
                            "there is no CPU fallback" % (device, rc))
@@ -131,6 +137,11 @@ class Context:
 
     def buf_free(self, h):
         self.check(lib().psm_buf_free(self._h, C.c_uint32(h)), "psm_buf_free")
+
+    def buf_ptr(self, h):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.check(lib().psm_buf_ptr(self._h, C.c_uint32(h), C.byref(p), C.byref(n)), "psm_buf_ptr")
+        return p.value, n.value
 
     def buf_upload(self, h, arr, offset=0):
         arr = np.ascontiguousarray(arr)
@@ -318,6 +329,29 @@ class Pipeline:
     def setTile(self, y0, y1):
         self.ctx.check(lib().psm_rt_set_tile(self._h, C.c_uint32(y0), C.c_uint32(y1)), "psm_rt_set_tile")
 
+    def setTileInterleaved(self, rank, world):
+        self.ctx.check(lib().psm_rt_set_tile_interleaved(self._h, C.c_uint32(rank), C.c_uint32(world)),
+                       "psm_rt_set_tile_interleaved")
+
+    def tile_texels(self):
+        n = C.c_uint32()
+        self.ctx.check(lib().psm_rt_tile_texels(self._h, C.byref(n)), "psm_rt_tile_texels")
+        return n.value
+
+    def pack_texels_dev(self, dev_ptr):
+        self.ctx.check(lib().psm_rt_pack_texels_dev(self._h, C.c_void_p(dev_ptr)), "psm_rt_pack_texels_dev")
+
+    def unpack_texels_dev(self, interleaved, a, b, dev_ptr):
+        self.ctx.check(lib().psm_rt_unpack_texels_dev(self._h, C.c_int(int(interleaved)), C.c_uint32(a), C.c_uint32(b),
+                                                      C.c_void_p(dev_ptr)), "psm_rt_unpack_texels_dev")
+
+    def ray_count_dev(self, dev_ptr):
+        self.ctx.check(lib().psm_rt_ray_count_dev(self._h, C.c_void_p(dev_ptr)), "psm_rt_ray_count_dev")
+
+    def set_ray_count(self, n):
+        self.ctx.check(lib().psm_rt_set_ray_count(self._h, C.c_int32(n)), "psm_rt_set_ray_count")
+        self.raycountCache = n
+
     def setLights(self, lights):
         lights = np.ascontiguousarray(lights, LIGHT_DT)
         self.ctx.check(lib().psm_rt_set_lights(self._h, _p(lights), C.c_uint32(lights.shape[0])), "psm_rt_set_lights")
@@ -369,14 +403,17 @@ class Pipeline:
                                                       C.c_int32(mat.loadOffset)), "psm_rt_set_materials")
             self._mat_sig = sig
 
-    def shade(self, time=None, force=False):
+    def shade(self, time=None, force=False, reload=True):
+        """reload=False leaves raycountCache stale: the caller learns the count elsewhere (ray_count_dev +
+        an all-gather) and reports it with set_ray_count()."""
         if not force and self.getRayCount() <= 0:
             return
         t = self._rand() if time is None else time  # drawn every round so sharded ranks stay in step
         if self.raycountCache <= 0:
             return
         self.ctx.check(lib().psm_rt_shade(self._h, self._obj._h, C.c_uint32(t)), "psm_rt_shade")
-        self._reload()
+        if reload:
+            self._reload()
 
     def reclaim(self):
         pass  # Pipeline.inl:361-369 is a no-op

@@ -85,7 +85,12 @@ int psm_device_count(void) {
     return n;
 }
 
-int psm_ctx_create(int device, psm_ctx** out) {
+static int ctx_create(int device, void* ext_stream, bool use_ext, psm_ctx** out);
+
+int psm_ctx_create(int device, psm_ctx** out) { return ctx_create(device, nullptr, false, out); }
+int psm_ctx_create_on_stream(int device, void* hip_stream, psm_ctx** out) { return ctx_create(device, hip_stream, true, out); }
+
+static int ctx_create(int device, void* ext_stream, bool use_ext, psm_ctx** out) {
     if (!out) return PSM_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -100,7 +105,10 @@ int psm_ctx_create(int device, psm_ctx** out) {
     psm_ctx* c = new (std::nothrow) psm_ctx();
     if (!c) return PSM_ERR_INVALID;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    c->own_stream = !use_ext;
+    if (use_ext) c->stream = (hipStream_t)ext_stream;
+    if (hipSetDevice(device) != hipSuccess ||
+        (!use_ext && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
         hipMalloc((void**)&c->d_counters, sizeof(DevCounters)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream) != hipSuccess) {
         delete c;
@@ -121,7 +129,7 @@ int psm_ctx_destroy(psm_ctx* c) {
     dev_free(c->sort_vals_tmp);
     dev_free(c->sort_hist);
     dev_free(c->d_counters);
-    (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PSM_OK;
 }
@@ -419,7 +427,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     (void)hipSetDevice(c->device);
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     rt_free_grid(r);
-    r->w = w; r->h = h; r->y0 = 0; r->y1 = h;
+    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0;
     uint64_t wr = (uint64_t)w * h;
     uint64_t lim = std::min<uint64_t>(wr * 4, 4096ull * 4096ull);  // Pipeline.inl:187-189
     r->limit = (uint32_t)lim;
@@ -469,6 +477,41 @@ int psm_rt_clear_sampler(psm_rt* r) {
 int psm_rt_set_tile(psm_rt* r, uint32_t y0, uint32_t y1) {
     if (!r || y0 > y1 || y1 > r->h) return PSM_ERR_INVALID;
     r->y0 = y0; r->y1 = y1;
+    r->tile_mode = 0;
+    return PSM_OK;
+}
+int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) {
+    if (!r || world == 0 || rank >= world) return PSM_ERR_INVALID;
+    r->tile_mode = 1; r->tile_rank = rank; r->tile_world = world;
+    return PSM_OK;
+}
+int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {
+    if (!r || !count) return PSM_ERR_INVALID;
+    *count = tile_texel_count(r);
+    return PSM_OK;
+}
+int psm_rt_pack_texels_dev(psm_rt* r, float* d_dst) {
+    if (!r || !d_dst || !r->t_sum) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    return launch_rt_pack(r, d_dst, 0, r->tile_mode, r->tile_mode ? r->tile_rank : r->y0, r->tile_mode ? r->tile_world : r->y1);
+}
+int psm_rt_unpack_texels_dev(psm_rt* r, int interleaved, uint32_t a, uint32_t b, const float* d_src) {
+    if (!r || !d_src || !r->t_sum) return PSM_ERR_INVALID;
+    if (interleaved ? (b == 0 || a >= b) : (a > b || b > r->h)) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    return launch_rt_pack(r, const_cast<float*>(d_src), 1, interleaved ? 1u : 0u, a, b);
+}
+int psm_rt_ray_count_dev(psm_rt* r, int32_t* d_dst) {
+    if (!r || !d_dst) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipMemcpyAsync(d_dst, r->d_cnt, 4, hipMemcpyDeviceToDevice, c->stream));
+    return PSM_OK;
+}
+int psm_rt_set_ray_count(psm_rt* r, int32_t count) {
+    if (!r || count < 0 || (uint32_t)count > r->limit) return PSM_ERR_INVALID;
+    r->ray_count = (uint32_t)count;
+    r->count_valid = true;
     return PSM_OK;
 }
 

@@ -28,6 +28,7 @@ struct Buf {
 struct psm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     std::string err;
     std::vector<psm::Buf> bufs;  // handle = index+1
     bool timing = false, counting = false;
@@ -79,6 +80,7 @@ struct psm_bvh {
 struct psm_rt {
     psm_ctx* ctx = nullptr;
     uint32_t w = 0, h = 0, dw = 0, dh = 0, y0 = 0, y1 = 0;
+    uint32_t tile_mode = 0, tile_rank = 0, tile_world = 1;  // 0: rows [y0,y1); 1: 8-row bands g % world == rank
     uint32_t limit = 0;           // currentRayLimit
     int cur = 0;                  // current queue index
     uint32_t ray_count = 0;       // host mirror of the current queue length (valid after sync points)
@@ -138,5 +140,7 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
 int launch_rt_sample(psm_rt* r);
+int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b);
+uint32_t tile_texel_count(const psm_rt* r);
 
 }  // namespace psm

@@ -47,14 +47,41 @@ struct Mat16 {
     float m[16];
 };
 
+// tile = the texels a context owns. mode 0: rows [a, b) in bands of 8 from a; mode 1: global 8-row bands
+// g with g % b == a. local_row = index of the row among the owned rows.
+struct Tile {
+    uint32_t mode, a, b, h;
+};
+struct TileRow {
+    bool owned;
+    uint32_t by, bh, local_base;  // band start row, band height, owned rows before the band
+};
+PSM_HD TileRow tile_row(Tile t, uint32_t y) {
+    TileRow r;
+    if (t.mode == 0) {
+        r.owned = y >= t.a && y < t.b;
+        uint32_t band = r.owned ? ((y - t.a) >> 3) : 0;
+        r.by = t.a + band * 8;
+        r.bh = (t.b - r.by) < 8u ? (t.b - r.by) : 8u;
+        r.local_base = band * 8;
+    } else {
+        uint32_t g = y >> 3;
+        r.owned = (g % t.b) == t.a;
+        r.by = g * 8;
+        r.bh = (t.h - r.by) < 8u ? (t.h - r.by) : 8u;
+        r.local_base = (g / t.b) * 8;
+    }
+    return r;
+}
+
 // ---- camera, raytracing/camera.comp:22-101 ------------------------------------------------------
 __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, uint32_t time, uint32_t w, uint32_t h,
-                                                 uint32_t y0, uint32_t y1, float4* __restrict__ qA,
+                                                 Tile tile, uint32_t nrays, float4* __restrict__ qA,
                                                  float4* __restrict__ qB, float4* __restrict__ qC,
                                                  float2* __restrict__ t_coord, float4* __restrict__ t_sum,
                                                  int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt) {
     uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx == 0) { cnt[0] = (y1 - y0) * w; cnt[1] = 0; cnt[2] = 0; }
+    if (idx == 0) { cnt[0] = nrays; cnt[1] = 0; cnt[2] = 0; }
     if (idx >= w * h) return;
     uint32_t x = idx % w, y = idx / w;
     float invw = 1.0f / (float)w, invh = 1.0f / (float)h;
@@ -66,7 +93,8 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
     t_coord[idx] = make_float2(cx, cy);
     t_sum[idx] = make_float4(0.f, 0.f, 0.f, 1.f);  // pre-collected zero sample (:99)
     t_flag[idx] = 1;
-    if (y < y0 || y >= y1) return;
+    TileRow tr = tile_row(tile, y);
+    if (!tr.owned) return;
     float nx = cx * 2.0f - 1.0f, ny = cy * 2.0f - 1.0f;
     float t0[4], co[4], orig[4];
     mat_vec(projInv.m, nx, ny, 0.999f, 1.0f, t0);
@@ -82,12 +110,9 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
     S_BOUNCE(bf, R_BOUNCE(bf) - 1);  // createRayIdx -> createRayStrict, rayslib.glsl:130-156
     // queue order: bands of 8 rows, 8-wide tiles left to right, row-major inside a tile, so one wave
     // of primary rays covers an 8x8 pixel tile (queue order never changes results: RNG is per pkey)
-    uint32_t band = (y - y0) >> 3;
-    uint32_t by = y0 + band * 8;
-    uint32_t bh = min(8u, y1 - by);
     uint32_t tx = x >> 3;
     uint32_t tw = min(8u, w - tx * 8);
-    uint32_t q = band * 8 * w + tx * 8 * bh + (y - by) * tw + (x - tx * 8);
+    uint32_t q = tr.local_base * w + tx * 8 * tr.bh + (y - tr.by) * tw + (x - tx * 8);
     qA[q] = make_float4(orig[0], orig[1], orig[2], __int_as_float((int)idx));
     qB[q] = make_float4(dir.x, dir.y, dir.z, __int_as_float(bf));
     qC[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(idx));
@@ -582,7 +607,45 @@ __global__ __launch_bounds__(256) void rt_sample(uint32_t w, uint32_t h, uint32_
     filtered[it] = xs;
 }
 
+// dense <-> full-image copy of a tile's per-texel radiance (tile gather)
+__global__ __launch_bounds__(256) void rt_pack(float4* __restrict__ t_sum, float4* __restrict__ buf, uint32_t w, uint32_t h,
+                                               Tile tile, int unpack) {
+    uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= w * h) return;
+    uint32_t x = idx % w, y = idx / w;
+    TileRow tr = tile_row(tile, y);
+    if (!tr.owned) return;
+    size_t d = (size_t)(tr.local_base + (y - tr.by)) * w + x;
+    if (unpack) t_sum[idx] = buf[d];
+    else buf[d] = t_sum[idx];
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------
+static Tile make_tile(const psm_rt* r) {
+    Tile t;
+    t.mode = r->tile_mode;
+    t.a = r->tile_mode ? r->tile_rank : r->y0;
+    t.b = r->tile_mode ? r->tile_world : r->y1;
+    t.h = r->h;
+    return t;
+}
+
+uint32_t tile_texel_count(const psm_rt* r) {
+    if (r->tile_mode == 0) return (r->y1 - r->y0) * r->w;
+    uint32_t rows = 0;
+    for (uint32_t g = r->tile_rank; g * 8 < r->h; g += r->tile_world) rows += (r->h - g * 8) < 8u ? (r->h - g * 8) : 8u;
+    return rows * r->w;
+}
+
+int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b) {
+    psm_ctx* c = r->ctx;
+    Tile t;
+    t.mode = mode; t.a = a; t.b = b; t.h = r->h;
+    uint32_t n = r->w * r->h;
+    rt_pack<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (float4*)d_buf, r->w, r->h, t, unpack);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
 
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time) {
     psm_ctx* c = r->ctx;
@@ -590,10 +653,11 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
     for (int i = 0; i < 16; i++) { ci.m[i] = cam_inv[i]; pi.m[i] = proj_inv[i]; }
     uint32_t n = r->w * r->h;
     TimedScope ts(c, CAT_CAMERA);
-    rt_camera<<<(n + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, r->y0, r->y1, r->qA[r->cur], r->qB[r->cur],
+    uint32_t nrays = tile_texel_count(r);
+    rt_camera<<<(n + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, make_tile(r), nrays, r->qA[r->cur], r->qB[r->cur],
                                                       r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt);
     PSM_HIP(c, hipGetLastError());
-    r->ray_count = (r->y1 - r->y0) * r->w;
+    r->ray_count = nrays;
     r->count_valid = true;
     return PSM_OK;
 }

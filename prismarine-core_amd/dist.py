@@ -21,19 +21,24 @@ def tile_rows(rank, world, height):
 
 
 class Comm:
-    def __init__(self, world=1, backend=None, init=True):
+    def __init__(self, world=1, backend=None, init=True, force=False):
+        """force=True runs the distributed code path even for world == 1 (single-GPU rehearsal of the
+        RCCL plumbing)."""
         self.world = world
+        self.active = world > 1 or force
         self.rank = 0
         self.local_rank = 0
         self.device_index = 0
         self.backend = backend or os.environ.get("PSM_DIST_BACKEND", "nccl")
         self.torch = None
-        if world > 1:
+        if self.active:
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
             self.rank = int(os.environ.get("RANK", "0"))
             self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
             if self.backend == "nccl":
                 ndev = torch.cuda.device_count()
                 self.device_index = self.local_rank % max(ndev, 1)
@@ -47,18 +52,18 @@ class Comm:
                 dist.init_process_group(backend=self.backend, rank=self.rank, world_size=world)
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             self.dist.barrier()
 
     def sum_int(self, v):
-        if self.world == 1:
+        if not self.active:
             return int(v)
         t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.dev)
         self.dist.all_reduce(t)
         return int(t.item())
 
     def max_float(self, v):
-        if self.world == 1:
+        if not self.active:
             return float(v)
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -67,7 +72,7 @@ class Comm:
     def gather_to_root(self, tile, root_out=None):
         """Gather equally sized 1-D tensors to rank 0. Returns the concatenated tensor on rank 0
         (root_out if given), None elsewhere. `tile` must live on self.dev."""
-        if self.world == 1:
+        if not self.active:
             return tile
         n = tile.numel()
         if self.rank == 0:
@@ -79,23 +84,60 @@ class Comm:
         return None
 
     def close(self):
-        if self.world > 1 and self.dist.is_initialized():
+        if self.active and self.dist.is_initialized():
             self.dist.destroy_process_group()
 
 
+def interleaved_texels(rank, world, width, height):
+    """Texels owned by `rank` when 8-row bands are dealt round-robin (psm_rt_set_tile_interleaved)."""
+    rows = sum(min(8, height - 8 * g) for g in range(rank, (height + 7) // 8, world))
+    return rows * width
+
+
 def run_rounds(comm, rays, intersector, materials, depth=16, on_round=None):
-    """Drive sharded_rounds() of this rank in lock step with the other ranks."""
+    """The bounce loop of Viewer.cpp:304-310 for this rank's tile, in lock step with the other ranks:
+    the `getRayCount() < 32 -> stop` rule is applied to the GLOBAL ray count.
+
+    With backend nccl and a context created on torch's stream the per-round count exchange is
+    device-side: copy the count to a tensor, all-gather it, ONE host read per round (the single-GPU
+    loop also reads the count once per round). Otherwise (gloo / tests) counts go through the host."""
     from . import sharded_rounds
-    gen = sharded_rounds(rays, intersector, materials, depth)
-    local = next(gen)
+    device_exchange = (comm.active and comm.backend == "nccl" and getattr(comm, "same_stream", False))
+    if not device_exchange:
+        gen = sharded_rounds(rays, intersector, materials, depth)
+        local = next(gen)
+        rounds = 0
+        while True:
+            total = comm.sum_int(local)
+            if on_round is not None and total >= 32:
+                on_round(local)
+            try:
+                local = gen.send(total)
+                rounds += 1
+            except StopIteration:
+                break
+        return rounds
+    torch, dist = comm.torch, comm.dist
+    if not hasattr(comm, "_cnt"):
+        comm._cnt = torch.zeros(1, dtype=torch.int32, device=comm.dev)
+        comm._all = torch.zeros(comm.world, dtype=torch.int32, device=comm.dev)
+    rays.applyMaterials(materials)
+    local = rays.raycountCache
+    total = comm.initial_total if getattr(comm, "initial_total", None) is not None else comm.sum_int(local)
     rounds = 0
-    while True:
-        total = comm.sum_int(local)
-        if on_round is not None and total >= 32:
-            on_round(local)
-        try:
-            local = gen.send(total)
-            rounds += 1
-        except StopIteration:
+    for _ in range(depth):
+        if total < 32:
             break
+        if on_round is not None:
+            on_round(local)
+        rays.intersection(intersector, force=True)
+        rays.shade(force=True, reload=False)
+        rays.reclaim()
+        rays.ray_count_dev(comm._cnt.data_ptr())
+        dist.all_gather_into_tensor(comm._all, comm._cnt)
+        counts = comm._all.cpu()  # the one host synchronisation of the round
+        local = int(counts[comm.rank])
+        total = int(counts.sum())
+        rays.set_ray_count(local)
+        rounds += 1
     return rounds

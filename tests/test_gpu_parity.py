@@ -316,6 +316,65 @@ def test_tile_sharding_equals_full_frame(psm, ctx, scenes):
     th.close()
 
 
+def test_interleaved_tiles_camera_and_gather(psm, ctx, oracle, scenes):
+    """8-row bands dealt round-robin over 3 ranks: camera queue equals the oracle's, and packing each tile's
+    texel sums into a dense buffer + unpacking on the gathering pipeline reproduces the unsharded frame."""
+    scene = scenes.cornell(open_top=True)
+    w, h, world = 72, 52, 3  # 6.5 bands: a partial last band
+    th, rt0, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    cfg = oracle.make_cfg(w, h, material_count=len(scene["materials"]))
+    pdist = __import__("importlib").import_module("prismarine-core_amd.dist")
+
+    def lockstep(pipes):
+        gens = [psm.sharded_rounds(rt, th, ms) for rt in pipes]
+        local = [next(g) for g in gens]
+        alive = [True] * len(gens)
+        while any(alive):
+            total = sum(local)
+            for i, g in enumerate(gens):
+                if alive[i]:
+                    try:
+                        local[i] = g.send(total)
+                    except StopIteration:
+                        alive[i] = False
+
+    full = psm.Pipeline(ctx, seed=5)
+    full.resizeBuffers(w, h); full.resize(w, h)
+    full.camera_matrices(cam[0], cam[1])
+    lockstep([full])
+    want, _, _ = full.download_texels()
+
+    pipes = []
+    for r in range(world):
+        rt = psm.Pipeline(ctx, seed=5)
+        rt.resizeBuffers(w, h); rt.resize(w, h)
+        rt.setTileInterleaved(r, world)
+        assert rt.tile_texels() == pdist.interleaved_texels(r, world, w, h)
+        rt.camera_matrices(cam[0], cam[1], time=None)
+        pipes.append(rt)
+    # camera parity per tile (same seed => same `time` as the oracle draws)
+    t0, _ = oracle.rand_next(5)
+    for r, rt in enumerate(pipes):
+        orays, *_ = oracle.camera_interleaved(cfg, cam[0], cam[1], t0, r, world)
+        _rays_equal(rt.download_rays(), orays)
+    lockstep(pipes)
+    # gather: tiles 1,2 are packed and unpacked into pipeline 0 (the "root")
+    per = pdist.interleaved_texels(0, world, w, h) * 16
+    hb = ctx.buf_alloc(per)
+    ptr, _ = ctx.buf_ptr(hb)
+    for r in range(1, world):
+        pipes[r].pack_texels_dev(ptr)
+        pipes[0].unpack_texels_dev(True, r, world, ptr)
+    got, _, _ = pipes[0].download_texels()
+    assert want[:, :3].max() > 0.1
+    np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(got[:, 3], want[:, 3])
+    ctx.buf_free(hb)
+    for rt in pipes + [full, rt0]:
+        rt.close()
+    th.close()
+
+
 def test_errors_are_reported(psm, ctx):
     th = psm.TriangleHierarchy(ctx)
     th.allocate(4)
