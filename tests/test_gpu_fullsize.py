@@ -1,0 +1,133 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the oracle cannot
+finish these sizes in seconds): sortedness / stability / permutation checksums for the sort, structural
+invariants for the BVH, sampled bit-exact parity + determinism + conservation for a full 1080p frame.
+"""
+import numpy as np
+import pytest
+
+from util import box_union, canonical_nodes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sort_10m_keys_properties(psm, ctx):
+    """C5-scale key count (reference cap: 2 Mi keys, Radix.hpp:34-35)."""
+    n = 10_000_019
+    rng = np.random.RandomState(5)
+    keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
+    keys[rng.randint(0, n, n // 4)] &= np.uint64(0xFFFFF)  # many ties
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = psm.RadixSort(ctx).sort_arrays(keys, vals)
+    assert (gk[1:] >= gk[:-1]).all()                                  # sorted
+    ties = gk[1:] == gk[:-1]
+    assert (gv[1:][ties] > gv[:-1][ties]).all()                      # stable
+    assert np.array_equal(keys[gv], gk)                              # values still point at their keys
+    assert int(gv.astype(np.uint64).sum()) == n * (n - 1) // 2       # a permutation
+    assert np.bitwise_xor.reduce(gk) == np.bitwise_xor.reduce(keys)  # multiset checksum
+
+
+def _invariants(nodes, n, keys):
+    pd = nodes["pdata"]
+    leaf = pd[:, 0] == pd[:, 1]
+    assert leaf.sum() == n
+    assert np.array_equal(np.sort(pd[leaf, 0]), np.arange(n))        # every sorted leaf reachable exactly once
+    internal = np.nonzero(~leaf)[0]
+    L, R = pd[internal, 0], pd[internal, 1]
+    assert np.array_equal(R, L + 1)
+    assert np.array_equal(pd[L, 2], internal) and np.array_equal(pd[R, 2], internal)
+    assert np.array_equal(nodes["box"][internal], box_union(nodes["box"][L], nodes["box"][R]))  # refit
+
+
+def test_build_2m_triangles_invariants(psm, ctx, scenes):
+    """S-stress at 2 M triangles (the reference's own capacity limit is 2*allocate() = 4 Mi)."""
+    sc = scenes.stress(n_tris=2_000_000)
+    tris = sc["tris"]
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(tris.shape[0])
+    th.loadTriangles(tris, sc["normals"], sc["mats"])
+    th.build()
+    info = th.info()
+    n = info.leaf_count
+    assert 0.99 * tris.shape[0] < n <= tris.shape[0]
+    keys = th.download(psm.BVH_KEYS, np.uint64, n)
+    assert (keys[1:] >= keys[:-1]).all()
+    idx = th.download(psm.BVH_INDICES, np.uint32, n)
+    assert np.array_equal(np.sort(idx), np.arange(n, dtype=np.uint32))
+    link = th.download(psm.BVH_LINK, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+    pb = th.download(psm.BVH_PAIR_BOX, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
+    rg = th.download(psm.BVH_RANGE, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+    node_dt = np.dtype([("box", "<u4", 4), ("pdata", "<i4", 4)])
+    nodes = canonical_nodes(info.root, link, pb, rg, node_dt)
+    _invariants(nodes, n, keys)
+    # ranges: children partition the parent's range at the node's split gap
+    s = np.arange(n - 1)
+    assert (rg[:, 0] <= s).all() and (s < rg[:, 1]).all()
+    tri_sorted = th.download(psm.BVH_SORTED_TRI, np.int32, n)
+    leaf_tri = th.download(psm.BVH_LEAF_TRI, np.int32, n)
+    assert np.array_equal(tri_sorted, leaf_tri[idx])
+    th.close()
+
+
+def test_full_1080p_frame_sampled_parity_determinism_conservation(psm, ctx, oracle, scenes):
+    """BASELINE config 3: Sponza-class scene, 1920x1080, full rebuild + loop."""
+    sc = scenes.sponza_like()
+    w, h = 1920, 1080
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(sc["tris"].shape[0])
+    th.loadTriangles(sc["tris"], sc["normals"], sc["mats"])
+    ms = psm.MaterialSet()
+    for m in sc["materials"]:
+        ms.addSubmat(m)
+    rt = psm.Pipeline(ctx, seed=77)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    ob = oracle.build_scene(sc["tris"])
+
+    def frame(check):
+        rt.setSeed(77)
+        rt.clearSampler()
+        ctx.stats_enable(False, True)
+        ctx.stats_reset()
+        ms.loadToVGA()
+        th.markDirty()
+        th.build()
+        rt.camera(sc["eye"], sc["view"])
+        total, rounds = 0, 0
+        for _ in range(16):
+            n = rt.getRayCount()
+            if n <= 0:
+                break
+            total += n
+            rays = rt.download_rays() if check and rounds < 2 else None
+            rt.intersection(th)
+            if rays is not None:  # sampled bit-exact parity against the oracle on every 211th ray
+                sel = np.arange(rounds, n, 211)
+                gh, gc = rt.download_hits(n)
+                oh, oc, _ = oracle.traverse(ob["nodes"], sc["tris"], ob["M"], rays["origin"][sel], rays["direct"][sel], 8)
+                assert np.array_equal(gc[sel], oc)
+                m = oc > 0
+                assert np.array_equal(gh["tri"][sel][m, 0], oh["tri"][m, 0])
+                assert np.array_equal(gh["t"][sel][m, 0].view(np.uint32), oh["t"][m, 0].view(np.uint32))
+            rt.applyMaterials(ms)
+            rt.shade()
+            rounds += 1
+        rt.sample()
+        st = ctx.stats()
+        s, c, f = rt.download_texels()
+        return rt.snapHdr(), st, total, rounds, s
+
+    img1, st1, total1, rounds1, s1 = frame(True)
+    img2, st2, total2, rounds2, s2 = frame(False)
+    # conservation / sanity
+    assert st1.rays_traced == total1 and rounds1 >= 3
+    # the reference's 16-entry stack silently drops far children (directTraverse.comp:459): a handful per frame
+    assert st1.stack_drops < 1e-5 * total1 and st1.iter_caps == 0 and st1.ray_limit_drops == 0
+    assert np.isfinite(img1).all() and (img1[..., :3] >= 0).all() and img1[..., :3].mean() > 0.05
+    assert (s1[:, 3] >= 1).all()                       # every texel got its pre-collected sample (camera.comp:99)
+    # determinism: ray counts, algorithmic counters and deposit counts repeat exactly; radiance to float-atomic order
+    assert (total1, rounds1, st1.node_visits, st1.tri_tests) == (total2, rounds2, st2.node_visits, st2.tri_tests)
+    assert np.array_equal(s1[:, 3], s2[:, 3]) and st1.stack_drops == st2.stack_drops
+    np.testing.assert_allclose(img1[..., :3], img2[..., :3], rtol=1e-5, atol=1e-6)
+    ctx.stats_enable(False, False)
+    rt.close()
+    th.close()
