@@ -142,6 +142,19 @@ def cpu_baseline(scene, ray_sets, args):
                       "best of 2; oracle BVH build %.2f s on 1 core" % (rays.shape[0], n, max(1, n // max(rays.shape[0], 1)), build_s)}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/collect.sh):
+    bench.py cannot run the profiler on itself, so the figure comes from the last collected profile."""
+    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    try:
+        d = json.load(open(path))
+        if d.get("kernel") == kernel:
+            return float(d["traffic_bytes_per_launch"]), d.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
@@ -191,6 +204,8 @@ def main():
         img = R.rt.snapHdr()
         alg_bytes = Rr * 44 + V * 64 + T * 36
         launches = max(st.traverse_launches, 1)
+        traffic, traffic_src = pmc_traffic("rt_traverse") if (world == 1 and args.scene == "sponza_like" and
+                                                                (args.width, args.height) == (1920, 1080)) else (None, None)
         avg_ms = st.traverse_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -215,7 +230,7 @@ def main():
                                    "camera": st.camera_ms / args.steps, "traverse": st.traverse_ms / args.steps,
                                    "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rt_traverse", "launches": int(st.traverse_launches), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "R": int(Rr), "V": int(V), "T": int(T), "rank": 0},

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun):
+#   kernel trace + stats of the default bench, and separate PMC passes for FETCH_SIZE / WRITE_SIZE
+#   (gfx950: 4 TCC slots, FETCH_SIZE costs 3, WRITE_SIZE 2 -> separate passes; MI355X_MICROARCH.md).
+# usage: profiles/collect.sh <tag>     -> gpurun_out/<tag>_{kt,fetch,write}/ ; summarise with summarize.py
+set -e
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/${TAG}_kt -- python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/${TAG}_kt_bench.json 2> $REPO/gpurun_out/${TAG}_kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/${TAG}_fetch -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/${TAG}_write -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+echo collected $TAG
