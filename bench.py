@@ -219,9 +219,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "S-sponza-like %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
+            "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
                                    "per frame + camera + <=%d bounce rounds + sample" % (
-                                       scene["tris"].shape[0], args.width, args.height, args.depth),
+                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth),
                        "scene": args.scene, "width": args.width, "height": args.height,
                        "parallelism": "tile%d" % world},
             "rays_per_frame": total_rays / args.steps,

@@ -82,6 +82,34 @@ int psm_bvh_clear(psm_bvh* bvh);
  * triangle material id (NULL -> material_id for all). Host pointers. */
 int psm_bvh_load_triangles(psm_bvh* bvh, const float* positions, const float* normals,
                            const int32_t* mats, size_t n, int32_t material_id);
+/* loadMesh() proper: the accessor / buffer-view virtualisation of
+ * Include/Prismarine/VertexInstance.{hpp,inl} + ShadersSDK/vertex/loader.comp:32-152 as one HIP gather
+ * kernel: de-index (32- or packed 16-bit indices), read by accessor, transform, normal fallback to the
+ * face normal, quads -> two triangles; appended at the current triangle count. */
+typedef struct {
+    int32_t offset4;      /* VirtualAccessor.offset4 (in floats) */
+    int32_t components;   /* VirtualAccessor.components: 0..3 = 1..4 floats (structs.glsl:245-254) */
+    int32_t buffer_view;  /* VirtualAccessor.bufferView */
+} psm_accessor;
+typedef struct {
+    int32_t offset4, stride4;  /* VirtualBufferView (structs.glsl:229-232); stride4 <= 0 -> components+1 */
+} psm_buffer_view;
+typedef struct {
+    const float* d_vertices;       /* device pointer: the float pool every accessor indexes (binding 1) */
+    size_t vertex_floats;
+    const uint32_t* d_indices;     /* device pointer or NULL (binding 2); 16-bit indices packed two per word */
+    size_t index_words;
+    const psm_accessor* accessors; /* host arrays, copied */
+    uint32_t accessor_count;
+    const psm_buffer_view* views;
+    uint32_t view_count;
+    int32_t vertex_accessor, normal_accessor, texcoord_accessor, modifier_accessor; /* -1 = absent */
+    float transform[16];           /* row-major t (setTransform, VertexInstance.inl:54-58) */
+    float transform_inv[16];       /* row-major inverse(t) */
+    int32_t material_id, is_indexed, index16, node_count, primitive_type /* 1 = quads */, loading_offset;
+} psm_mesh_desc;
+int psm_bvh_load_mesh(psm_bvh* bvh, const psm_mesh_desc* mesh);
+
 /* build(optimization), TriangleHierarchy.inl:206-329: bounds -> fit transform -> Morton+leaves
  * -> radix sort -> emit -> boxes. opt may be NULL (identity). No host synchronisation. */
 int psm_bvh_build(psm_bvh* bvh, const double* opt);
@@ -111,7 +139,10 @@ enum {
     PSM_BVH_PAIR_BOX = 4,  /* uint32[8][leaf_count-1] child boxes of internal node (split gap) s: left, right */
     PSM_BVH_LINK = 5,      /* int32[2][leaf_count-1]  child links: >=0 internal gap id, <0 leaf: ~triangle */
     PSM_BVH_RANGE = 6,     /* int32[2][leaf_count-1]  sorted-leaf range [first,last] of internal node s */
-    PSM_BVH_SORTED_TRI = 7 /* int32[leaf_count]    triangle id of the k-th sorted leaf */
+    PSM_BVH_SORTED_TRI = 7,/* int32[leaf_count]    triangle id of the k-th sorted leaf */
+    PSM_BVH_POSITIONS = 8, /* float[9][triangle_count] world-space triangle soup as loaded */
+    PSM_BVH_NORMALS = 9,   /* float[9][triangle_count] per-vertex normals as loaded */
+    PSM_BVH_MATERIALS = 10 /* int32[triangle_count] */
 };
 int psm_bvh_download(psm_bvh* bvh, int what, void* dst, size_t bytes);
 

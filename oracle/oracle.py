@@ -195,6 +195,53 @@ def brute_force(tris, origin, direct):
     return bool(found), best[0]
 
 
+class OAccessor(C.Structure):
+    _fields_ = [("offset4", C.c_int32), ("components", C.c_int32), ("buffer_view", C.c_int32)]
+
+
+class OBufferView(C.Structure):
+    _fields_ = [("offset4", C.c_int32), ("stride4", C.c_int32)]
+
+
+class OMeshDesc(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertex_floats", C.c_size_t), ("indices", C.c_void_p),
+                ("index_words", C.c_size_t), ("accessors", C.c_void_p), ("accessor_count", C.c_uint32),
+                ("views", C.c_void_p), ("view_count", C.c_uint32), ("vertex_accessor", C.c_int32),
+                ("normal_accessor", C.c_int32), ("texcoord_accessor", C.c_int32), ("modifier_accessor", C.c_int32),
+                ("transform", C.c_float * 16), ("transform_inv", C.c_float * 16), ("material_id", C.c_int32),
+                ("is_indexed", C.c_int32), ("index16", C.c_int32), ("node_count", C.c_int32),
+                ("primitive_type", C.c_int32), ("loading_offset", C.c_int32)]
+
+
+def load_mesh(mesh):
+    """mesh: dict as built by prismarine-core_amd.make_mesh_desc (host arrays). Returns (pos, nrm, mats)."""
+    d = OMeshDesc()
+    verts = np.ascontiguousarray(mesh["vertices"], np.float32)
+    idx = None if mesh.get("indices") is None else np.ascontiguousarray(mesh["indices"], np.uint32)
+    acc = (OAccessor * len(mesh["accessors"]))(*[OAccessor(*a) for a in mesh["accessors"]])
+    views = (OBufferView * len(mesh["views"]))(*[OBufferView(*v) for v in mesh["views"]])
+    d.vertices, d.vertex_floats = verts.ctypes.data, verts.size
+    d.indices, d.index_words = (idx.ctypes.data if idx is not None else None), (idx.size if idx is not None else 0)
+    d.accessors, d.accessor_count = C.cast(acc, C.c_void_p), len(mesh["accessors"])
+    d.views, d.view_count = C.cast(views, C.c_void_p), len(mesh["views"])
+    d.vertex_accessor, d.normal_accessor = mesh["vertex_accessor"], mesh.get("normal_accessor", -1)
+    d.texcoord_accessor, d.modifier_accessor = -1, -1
+    t = np.ascontiguousarray(mesh["transform"], np.float32).reshape(16)
+    ti = np.ascontiguousarray(mesh["transform_inv"], np.float32).reshape(16)
+    for k in range(16):
+        d.transform[k], d.transform_inv[k] = t[k], ti[k]
+    d.material_id, d.is_indexed, d.index16 = mesh.get("material_id", 0), int(idx is not None), int(mesh.get("index16", 0))
+    d.node_count, d.primitive_type, d.loading_offset = mesh["node_count"], mesh.get("primitive_type", 0), mesh.get("loading_offset", 0)
+    n = mesh["node_count"] * (2 if mesh.get("primitive_type", 0) == 1 else 1)
+    pos = np.zeros((n, 9), np.float32)
+    nrm = np.zeros((n, 9), np.float32)
+    mats = np.zeros(n, np.int32)
+    lib().psmo_load_mesh.restype = C.c_int
+    got = lib().psmo_load_mesh(C.byref(d), C.c_int(0), _p(pos), _p(nrm), _p(mats))
+    assert got == n
+    return pos, nrm, mats
+
+
 def make_cfg(width, height, display=None, lights=1, material_count=1, material_offset=0,
              sky=(0.5, 0.7, 1.0), ray_limit=None, samples_lock=4):
     cfg = FrameCfg()

@@ -389,6 +389,60 @@ int psmo_build(const float* tris, int n, const double opt[16], float M[16], uint
 }
 
 /* ------------------------------------------------------------------ */
+/* geometry ingestion, vertex/loader.comp:32-152                       */
+/* ------------------------------------------------------------------ */
+static void read_by_accessor(const psmo_mesh_desc* d, int accessorID, uint32_t idx, float out[4]) { /* :32-54 */
+    const psmo_accessor* ac = &d->accessors[accessorID];
+    const psmo_buffer_view* bv = &d->views[ac->buffer_view];
+    uint32_t cmps = (uint32_t)ac->components & 3u;
+    uint32_t stride4 = bv->stride4 > 0 ? (uint32_t)bv->stride4 : (cmps + 1u);
+    uint32_t off = idx * stride4 + (uint32_t)bv->offset4 + (uint32_t)ac->offset4;
+    for (uint32_t k = 0; k < 4; k++) out[k] = (k <= cmps && off + k < d->vertex_floats) ? d->vertices[off + k] : 0.f;
+}
+
+int psmo_load_mesh(const psmo_mesh_desc* d, int storing_offset, float* pos, float* nrm, int32_t* mats) {
+    int trp = d->primitive_type == 1 ? 4 : 3;
+    int istride = d->primitive_type == 1 ? 2 : 1;
+    for (int ct = 0; ct < d->node_count; ct++) {
+        float vertice[4][3], normal[4][3];
+        for (int i = 0; i < trp; i++) {
+            uint32_t ptri = (uint32_t)d->loading_offset + (uint32_t)(ct * trp + i);
+            uint32_t vi = ptri;
+            if (d->is_indexed != 0) {
+                if (d->index16) { uint32_t wd = (ptri >> 1) < d->index_words ? d->indices[ptri >> 1] : 0u; vi = (wd >> (16u * (ptri & 1u))) & 0xFFFFu; }
+                else vi = ptri < d->index_words ? d->indices[ptri] : 0u;
+            }
+            float p[4], n[4] = {0.f, 0.f, 0.f, 0.f};
+            read_by_accessor(d, d->vertex_accessor, vi, p);
+            if (d->normal_accessor != -1) read_by_accessor(d, d->normal_accessor, vi, n);
+            float pv[4] = {p[0], p[1], p[2], 1.0f}, nv[4] = {n[0], n[1], n[2], 0.0f}, po[4], no[4];
+            mat_vec(d->transform, pv, po);       /* :101 */
+            matT_vec(d->transform_inv, nv, no);  /* :100 */
+            for (int k = 0; k < 3; k++) { vertice[i][k] = po[k] / po[3]; normal[i][k] = no[k]; }
+        }
+        float e1[3] = {vertice[1][0] - vertice[0][0], vertice[1][1] - vertice[0][1], vertice[1][2] - vertice[0][2]};
+        float e2[3] = {vertice[2][0] - vertice[0][0], vertice[2][1] - vertice[0][1], vertice[2][2] - vertice[0][2]};
+        float cr[3], offsetnormal[3];
+        cross3(e1, e2, cr);
+        normalize3(cr, offsetnormal); /* :119 */
+        for (int q = 0; q < istride; q++) {
+            int tidc = storing_offset + ct * istride + q;
+            const int m[3] = {q == 0 ? 0 : 3, q == 0 ? 1 : 0, 2}; /* :56 */
+            mats[tidc] = d->material_id;
+            for (int i = 0; i < 3; i++) {
+                const float* nn = normal[m[i]];
+                float an[3] = {fabsf(nn[0]), fabsf(nn[1]), fabsf(nn[2])};
+                float use[3];
+                if (pmax(an[0], pmax(an[1], an[2])) >= 0.0001f && d->normal_accessor != -1) normalize3(nn, use);
+                else normalize3(offsetnormal, use); /* :124-128 */
+                for (int k = 0; k < 3; k++) { pos[9 * tidc + 3 * i + k] = vertice[m[i]][k]; nrm[9 * tidc + 3 * i + k] = use[k]; }
+            }
+        }
+    }
+    return d->node_count * istride;
+}
+
+/* ------------------------------------------------------------------ */
 /* traversal, raytracing/directTraverse.comp                           */
 /* ------------------------------------------------------------------ */
 

@@ -21,6 +21,7 @@
  */
 #ifndef PSM_ORACLE_H
 #define PSM_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -75,6 +76,21 @@ int psmo_build_nodes(const uint64_t* keys, const int32_t* idx, psmo_node* leafs,
 /* whole TriangleHierarchy::build; returns leaf count; nodes sized 2*n */
 int psmo_build(const float* tris, int n, const double opt[16], float M[16], uint64_t* keys,
                int32_t* idx, psmo_node* leafs, psmo_node* nodes);
+
+/* ---- geometry ingestion: vertex/loader.comp:32-152 ---- */
+typedef struct { int32_t offset4, components, buffer_view; } psmo_accessor;
+typedef struct { int32_t offset4, stride4; } psmo_buffer_view;
+typedef struct {
+    const float* vertices; size_t vertex_floats;
+    const uint32_t* indices; size_t index_words;
+    const psmo_accessor* accessors; uint32_t accessor_count;
+    const psmo_buffer_view* views; uint32_t view_count;
+    int32_t vertex_accessor, normal_accessor, texcoord_accessor, modifier_accessor;
+    float transform[16], transform_inv[16];
+    int32_t material_id, is_indexed, index16, node_count, primitive_type, loading_offset;
+} psmo_mesh_desc;
+/* appends to pos/nrm (9 floats per triangle) and mats starting at triangle `storing_offset`; returns triangles written */
+int psmo_load_mesh(const psmo_mesh_desc* d, int storing_offset, float* pos, float* nrm, int32_t* mats);
 
 /* ---- trace ---- */
 int psmo_traverse(const psmo_node* nodes, const float* tris, const float M[16],

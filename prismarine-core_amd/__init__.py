@@ -23,7 +23,7 @@ EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev",
-    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_build",
+    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_load_mesh", "psm_bvh_build",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
@@ -36,7 +36,7 @@ EXPORTS = [
 ]
 
 (BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
- BVH_SORTED_TRI) = range(8)
+ BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS) = range(11)
 
 RAY_DT = np.dtype([("origin", "<f4", 3), ("direct", "<f4", 3), ("color", "<f4", 3),
                    ("bitfield", "<i4"), ("texel", "<i4"), ("pkey", "<u4")])
@@ -52,6 +52,24 @@ class PsmError(RuntimeError):
 class BvhInfo(C.Structure):
     _fields_ = [("triangle_count", C.c_uint32), ("leaf_count", C.c_uint32), ("root", C.c_int32),
                 ("transform", C.c_float * 16), ("bounds_min", C.c_float * 4), ("bounds_max", C.c_float * 4)]
+
+
+class Accessor(C.Structure):
+    _fields_ = [("offset4", C.c_int32), ("components", C.c_int32), ("buffer_view", C.c_int32)]
+
+
+class BufferView(C.Structure):
+    _fields_ = [("offset4", C.c_int32), ("stride4", C.c_int32)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("d_vertices", C.c_void_p), ("vertex_floats", C.c_size_t), ("d_indices", C.c_void_p),
+                ("index_words", C.c_size_t), ("accessors", C.c_void_p), ("accessor_count", C.c_uint32),
+                ("views", C.c_void_p), ("view_count", C.c_uint32), ("vertex_accessor", C.c_int32),
+                ("normal_accessor", C.c_int32), ("texcoord_accessor", C.c_int32), ("modifier_accessor", C.c_int32),
+                ("transform", C.c_float * 16), ("transform_inv", C.c_float * 16), ("material_id", C.c_int32),
+                ("is_indexed", C.c_int32), ("index16", C.c_int32), ("node_count", C.c_int32),
+                ("primitive_type", C.c_int32), ("loading_offset", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -222,6 +240,45 @@ class TriangleHierarchy:
                                                     C.c_int32(self.materialID)), "psm_bvh_load_triangles")
         self.triangleCount += n
         self.markDirty()
+
+    def loadMesh(self, mesh):
+        """loadMesh(TriangleArrayInstance*) (TriangleHierarchy.inl:173-192): `mesh` is a dict with the
+        fields of VertexInstance.hpp -- vertices (float pool), indices (uint32 words or None), accessors
+        [(offset4, components, bufferView)], views [(offset4, stride4)], vertex_accessor, normal_accessor,
+        transform / transform_inv (row-major 4x4), material_id, index16, node_count, primitive_type,
+        loading_offset. The pools are uploaded to device buffers and resolved by the HIP gather kernel."""
+        verts = np.ascontiguousarray(mesh["vertices"], np.float32)
+        idx = None if mesh.get("indices") is None else np.ascontiguousarray(mesh["indices"], np.uint32)
+        hv = self.ctx.buf_alloc(max(verts.nbytes, 4))
+        self.ctx.buf_upload(hv, verts)
+        hi = None
+        if idx is not None:
+            hi = self.ctx.buf_alloc(max(idx.nbytes, 4))
+            self.ctx.buf_upload(hi, idx)
+        try:
+            acc = (Accessor * len(mesh["accessors"]))(*[Accessor(*a) for a in mesh["accessors"]])
+            views = (BufferView * len(mesh["views"]))(*[BufferView(*v) for v in mesh["views"]])
+            d = MeshDesc()
+            d.d_vertices, d.vertex_floats = self.ctx.buf_ptr(hv)[0], verts.size
+            d.d_indices, d.index_words = (self.ctx.buf_ptr(hi)[0] if hi is not None else None), (idx.size if idx is not None else 0)
+            d.accessors, d.accessor_count = C.cast(acc, C.c_void_p), len(mesh["accessors"])
+            d.views, d.view_count = C.cast(views, C.c_void_p), len(mesh["views"])
+            d.vertex_accessor, d.normal_accessor = mesh["vertex_accessor"], mesh.get("normal_accessor", -1)
+            d.texcoord_accessor, d.modifier_accessor = -1, -1
+            t = np.ascontiguousarray(mesh["transform"], np.float32).reshape(16)
+            ti = np.ascontiguousarray(mesh["transform_inv"], np.float32).reshape(16)
+            for k in range(16):
+                d.transform[k], d.transform_inv[k] = t[k], ti[k]
+            d.material_id, d.is_indexed, d.index16 = mesh.get("material_id", self.materialID), int(idx is not None), int(mesh.get("index16", 0))
+            d.node_count, d.primitive_type = mesh["node_count"], mesh.get("primitive_type", 0)
+            d.loading_offset = mesh.get("loading_offset", 0)
+            self.ctx.check(lib().psm_bvh_load_mesh(self._h, C.byref(d)), "psm_bvh_load_mesh")
+            self.triangleCount += mesh["node_count"] * (2 if mesh.get("primitive_type", 0) == 1 else 1)
+            self.markDirty()
+        finally:
+            self.ctx.buf_free(hv)
+            if hi is not None:
+                self.ctx.buf_free(hi)
 
     def isDirty(self):
         return self._dirty

@@ -292,6 +292,39 @@ int psm_bvh_load_triangles(psm_bvh* b, const float* positions, const float* norm
     return launch_bvh_prepare_tris(b, first, (uint32_t)n);
 }
 
+int psm_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d) {
+    if (!b || !d) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    if (d->node_count <= 0) return PSM_OK;  // TriangleHierarchy.inl:174
+    if (!d->d_vertices || !d->accessors || !d->views || d->vertex_accessor < 0 ||
+        (uint32_t)d->vertex_accessor >= d->accessor_count || d->normal_accessor >= (int32_t)d->accessor_count ||
+        (d->is_indexed && !d->d_indices))
+        return set_err(c, PSM_ERR_INVALID, "psm_bvh_load_mesh: bad mesh description");
+    for (uint32_t i = 0; i < d->accessor_count; i++)
+        if (d->accessors[i].buffer_view < 0 || (uint32_t)d->accessors[i].buffer_view >= d->view_count)
+            return set_err(c, PSM_ERR_INVALID, "psm_bvh_load_mesh: accessor refers to a missing buffer view");
+    size_t tris = (size_t)d->node_count * (d->primitive_type == 1 ? 2 : 1);
+    if (b->tri_count + tris > b->cap) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_load_mesh: exceeds allocate() capacity");
+    psm_accessor* d_acc = nullptr;
+    psm_buffer_view* d_views = nullptr;
+    PSM_HIP(c, hipMalloc((void**)&d_acc, d->accessor_count * sizeof(psm_accessor)));
+    if (hipMalloc((void**)&d_views, d->view_count * sizeof(psm_buffer_view)) != hipSuccess) { (void)hipFree(d_acc); return set_err(c, PSM_ERR_HIP, "hipMalloc"); }
+    int rc = PSM_OK;
+    if (hipMemcpyAsync(d_acc, d->accessors, d->accessor_count * sizeof(psm_accessor), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_views, d->views, d->view_count * sizeof(psm_buffer_view), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = set_err(c, PSM_ERR_HIP, "psm_bvh_load_mesh: upload of the accessor tables failed");
+    if (rc == PSM_OK) rc = launch_bvh_load_mesh(b, d, d_acc, d_views);
+    (void)hipStreamSynchronize(c->stream);  // the tables are temporaries
+    (void)hipFree(d_acc);
+    (void)hipFree(d_views);
+    if (rc == PSM_OK) {
+        b->tri_count += (uint32_t)tris;
+        b->built = b->bounds_done = b->morton_done = b->sort_done = false;
+    }
+    return rc;
+}
+
 int psm_bvh_stage_bounds(psm_bvh* b, const double* opt) {
     if (!b) return PSM_ERR_INVALID;
     psm_ctx* c = b->ctx;
@@ -369,6 +402,9 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
         case PSM_BVH_LINK: src = b->d_link; elem = 8; break;
         case PSM_BVH_RANGE: src = b->d_range; elem = 8; break;
         case PSM_BVH_SORTED_TRI: src = b->d_sorted_tri; elem = 4; break;
+        case PSM_BVH_POSITIONS: src = b->d_pos; elem = 36; break;
+        case PSM_BVH_NORMALS: src = b->d_nrm; elem = 36; break;
+        case PSM_BVH_MATERIALS: src = b->d_mats; elem = 4; break;
         default: return set_err(c, PSM_ERR_INVALID, "psm_bvh_download: unknown item");
     }
     if (bytes > b->cap * elem) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_download: too many bytes");

@@ -126,6 +126,91 @@ __global__ __launch_bounds__(256) void bvh_prepare_tris(const float* __restrict_
     tri48[(size_t)3 * t + 2] = e2;
 }
 
+// ---- geometry ingestion: vertex/loader.comp:32-152 ----------------------------------
+struct MeshArgs {
+    const float* iverts;
+    uint32_t vertex_floats;
+    const uint32_t* vindics;
+    uint32_t index_words;
+    const psm_accessor* accessors;
+    const psm_buffer_view* views;
+    int vertexAccessor, normalAccessor;
+    float T[16], Ti[16];
+    int materialID, isIndexed, index16, nodeCount, primitiveType, loadingOffset;
+    uint32_t storingOffset;
+};
+
+// readByAccessor, loader.comp:32-54 (reads beyond the pool return 0 instead of faulting)
+PSM_D void read_by_accessor(const MeshArgs& a, int accessorID, uint32_t idx, float out[4]) {
+    psm_accessor ac = a.accessors[accessorID];
+    psm_buffer_view bv = a.views[ac.buffer_view];
+    uint32_t cmps = (uint32_t)ac.components & 3u;
+    uint32_t stride4 = bv.stride4 > 0 ? (uint32_t)bv.stride4 : (cmps + 1u);
+    uint32_t off = idx * stride4 + (uint32_t)bv.offset4 + (uint32_t)ac.offset4;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) out[k] = (k <= cmps && off + k < a.vertex_floats) ? a.iverts[off + k] : 0.f;
+}
+
+__global__ __launch_bounds__(128) void bvh_load_mesh(MeshArgs a, float* __restrict__ pos, float* __restrict__ nrm,
+                                                     int32_t* __restrict__ mats, float4* __restrict__ tri48) {
+    int ct = blockIdx.x * 128 + threadIdx.x;
+    if (ct >= a.nodeCount) return;
+    int trp = a.primitiveType == 1 ? 4 : 3;
+    v3 vertice[4], normal[4];
+    for (int i = 0; i < trp; i++) {
+        uint32_t ptri = (uint32_t)a.loadingOffset + (uint32_t)(ct * trp + i);
+        uint32_t vi = ptri;
+        if (a.isIndexed != 0) {
+            if (a.index16) { uint32_t wd = (ptri >> 1) < a.index_words ? a.vindics[ptri >> 1] : 0u; vi = (wd >> (16u * (ptri & 1u))) & 0xFFFFu; }  // vertex.glsl:199
+            else vi = ptri < a.index_words ? a.vindics[ptri] : 0u;
+        }
+        float p[4], n[4] = {0.f, 0.f, 0.f, 0.f};
+        read_by_accessor(a, a.vertexAccessor, vi, p);
+        if (a.normalAccessor != -1) read_by_accessor(a, a.normalAccessor, vi, n);
+        float po[4], no[4];
+        mat_vec(a.T, p[0], p[1], p[2], 1.0f, po);     // mult4(meshUniform.transform, vec4(vpos, 1)), :101
+        matT_vec(a.Ti, n[0], n[1], n[2], 0.0f, no);   // mult4(meshUniform.transformInv, vec4(vnorm, 0)), :100
+        vertice[i] = mk3(po[0] / po[3], po[1] / po[3], po[2] / po[3]);
+        normal[i] = mk3(no[0], no[1], no[2]);
+    }
+    v3 offsetnormal = normalize3(cross3(vertice[1] - vertice[0], vertice[2] - vertice[0]));  // :119
+    int istride = a.primitiveType == 1 ? 2 : 1;
+    uint32_t tidc = a.storingOffset + (uint32_t)(ct * istride);
+    for (int q = 0; q < istride; q++, tidc++) {
+        const int m[3] = {q == 0 ? 0 : 3, q == 0 ? 1 : 0, 2};  // :56, quads: (0,1,2) and (3,0,2)
+        mats[tidc] = a.materialID;
+        v3 vv[3];
+        for (int i = 0; i < 3; i++) {
+            v3 nn = normal[m[i]];
+            v3 an = mk3(pabs(nn.x), pabs(nn.y), pabs(nn.z));
+            v3 use = (mlength3(an) >= 0.0001f && a.normalAccessor != -1) ? normalize3(nn) : normalize3(offsetnormal);  // :124-128
+            vv[i] = vertice[m[i]];
+            float* pp = pos + (size_t)9 * tidc + 3 * i;
+            float* np = nrm + (size_t)9 * tidc + 3 * i;
+            pp[0] = vv[i].x; pp[1] = vv[i].y; pp[2] = vv[i].z;
+            np[0] = use.x; np[1] = use.y; np[2] = use.z;
+        }
+        tri48[(size_t)3 * tidc + 0] = make_float4(vv[0].x, vv[0].y, vv[0].z, 1.0f);
+        tri48[(size_t)3 * tidc + 1] = make_float4(vv[1].x - vv[0].x, vv[1].y - vv[0].y, vv[1].z - vv[0].z, 0.0f);
+        tri48[(size_t)3 * tidc + 2] = make_float4(vv[2].x - vv[0].x, vv[2].y - vv[0].y, vv[2].z - vv[0].z, 0.0f);
+    }
+}
+
+int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views) {
+    MeshArgs a;
+    a.iverts = d->d_vertices; a.vertex_floats = (uint32_t)d->vertex_floats;
+    a.vindics = d->d_indices; a.index_words = (uint32_t)d->index_words;
+    a.accessors = d_acc; a.views = d_views;
+    a.vertexAccessor = d->vertex_accessor; a.normalAccessor = d->normal_accessor;
+    for (int i = 0; i < 16; i++) { a.T[i] = d->transform[i]; a.Ti[i] = d->transform_inv[i]; }
+    a.materialID = d->material_id; a.isIndexed = d->is_indexed; a.index16 = d->index16; a.nodeCount = d->node_count;
+    a.primitiveType = d->primitive_type; a.loadingOffset = d->loading_offset;
+    a.storingOffset = b->tri_count;
+    bvh_load_mesh<<<(d->node_count + 127) / 128, 128, 0, b->ctx->stream>>>(a, b->d_pos, b->d_nrm, b->d_mats, b->d_tri48);
+    PSM_HIP(b->ctx, hipGetLastError());
+    return PSM_OK;
+}
+
 // ---- stage: Morton + leaf records (hlbvh/aabbmaker.comp:142-232, splitLimit = 0) --------------
 
 struct LeafCalc {

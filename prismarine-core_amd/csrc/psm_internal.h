@@ -136,6 +136,7 @@ int launch_bvh_bounds(psm_bvh* b);
 int launch_bvh_morton(psm_bvh* b);
 int launch_bvh_emit(psm_bvh* b);
 int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
+int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views);
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);

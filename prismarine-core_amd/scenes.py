@@ -446,3 +446,45 @@ def camera_matrices(eye, view, width, height):
     cam_inv = np.linalg.inv(cam.astype(np.float64)).astype(np.float32)
     proj_inv = np.linalg.inv(proj.astype(np.float64)).astype(np.float32)
     return np.ascontiguousarray(cam_inv.reshape(16)), np.ascontiguousarray(proj_inv.reshape(16))
+
+
+# ---------------------------------------------------------------------------
+# glTF-style mesh descriptions (accessors / buffer views), the input of loadMesh
+# ---------------------------------------------------------------------------
+
+def make_indexed_mesh(tris, normals=None, interleaved=True, index16=False, quads=False, transform=None, material_id=0):
+    """Turn a triangle soup into an indexed, accessor-described mesh (welds identical vertices).
+    interleaved: one buffer view with stride 6 holding position|normal per vertex; else two planar views.
+    quads: pair consecutive triangles (a,b,c),(d,a,c) into 4-index primitives where possible (tests only)."""
+    tris = np.asarray(tris, np.float32).reshape(-1, 3, 3)
+    n = tris.shape[0]
+    nr = np.zeros_like(tris) if normals is None else np.asarray(normals, np.float32).reshape(-1, 3, 3)
+    rec = np.concatenate([tris.reshape(-1, 3), nr.reshape(-1, 3)], 1)
+    uniq, inv = np.unique(rec, axis=0, return_inverse=True)
+    inv = inv.reshape(-1).astype(np.uint32)
+    if interleaved:
+        verts = uniq.reshape(-1).astype(np.float32)
+        views = [(0, 6)]
+        accessors = [(0, 2, 0), (3, 2, 0)]
+    else:
+        verts = np.concatenate([uniq[:, :3].reshape(-1), uniq[:, 3:].reshape(-1)]).astype(np.float32)
+        views = [(0, 3), (uniq.shape[0] * 3, 0)]  # stride 0 -> components + 1
+        accessors = [(0, 2, 0), (0, 2, 1)]
+    node_count, prim = n, 0
+    idx = inv
+    if quads:
+        assert n % 2 == 0
+        q = inv.reshape(-1, 2, 3)
+        # primitive (i0,i1,i2,i3) expands to triangles (i0,i1,i2) and (i3,i0,i2)  (loader.comp:56)
+        idx = np.stack([q[:, 0, 0], q[:, 0, 1], q[:, 0, 2], q[:, 1, 0]], 1).reshape(-1).astype(np.uint32)
+        node_count, prim = n // 2, 1
+    if index16:
+        assert uniq.shape[0] < 65536
+        pad = np.concatenate([idx, np.zeros(idx.size % 2, np.uint32)])
+        idx = (pad[0::2] | (pad[1::2] << np.uint32(16))).astype(np.uint32)
+    t = np.eye(4, dtype=np.float32) if transform is None else np.asarray(transform, np.float32).reshape(4, 4)
+    ti = np.linalg.inv(t.astype(np.float64)).astype(np.float32)
+    return {"vertices": verts, "indices": idx, "accessors": accessors, "views": views, "vertex_accessor": 0,
+            "normal_accessor": -1 if normals is None else 1, "transform": t.reshape(16), "transform_inv": ti.reshape(16),
+            "material_id": material_id, "index16": int(index16), "node_count": node_count, "primitive_type": prim,
+            "loading_offset": 0}

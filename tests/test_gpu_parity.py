@@ -375,6 +375,43 @@ def test_interleaved_tiles_camera_and_gather(psm, ctx, oracle, scenes):
     th.close()
 
 
+@pytest.mark.parametrize("kw", [{}, {"interleaved": False}, {"index16": True}, {"normals": False},
+                                {"quads": True}, {"xform": True}])
+def test_load_mesh_matches_oracle(psm, ctx, oracle, scenes, kw):
+    """the HIP gather kernel behind loadMesh vs the oracle's loader.comp restatement, bit-exact."""
+    kw = dict(kw)
+    sc = scenes.sponza_like(n_tris=4000)
+    tris = sc["tris"]
+    normals = None if kw.pop("normals", True) is False else sc["normals"]
+    t = None
+    if kw.pop("xform", False):
+        a = 0.4
+        t = np.array([[np.cos(a), 0, np.sin(a), 0.3], [0, 1.7, 0, -2.0], [-np.sin(a), 0, np.cos(a), 1.0], [0, 0, 0, 1]], np.float32)
+    mesh = scenes.make_indexed_mesh(tris, normals, transform=t, material_id=3, **kw)
+    opos, onrm, omats = oracle.load_mesh(mesh)
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(tris.shape[0] + 16)
+    th.loadTriangles(tris[:5], sc["normals"][:5], sc["mats"][:5])  # the mesh is appended after existing triangles
+    th.loadMesh(mesh)
+    n = opos.shape[0]
+    assert th.triangleCount == n + 5
+    gp = th.download(psm.BVH_POSITIONS, np.float32, 9 * (n + 5)).reshape(-1, 9)
+    gn = th.download(psm.BVH_NORMALS, np.float32, 9 * (n + 5)).reshape(-1, 9)
+    gm = th.download(psm.BVH_MATERIALS, np.int32, n + 5)
+    assert np.array_equal(bits(gp[5:]), bits(opos)) and np.array_equal(bits(gn[5:]), bits(onrm))
+    assert np.array_equal(gm[5:], omats) and np.array_equal(bits(gp[:5]), bits(tris[:5].reshape(5, 9)))
+    # and the loaded geometry builds and traces like the soup it came from
+    if not kw and t is None and normals is not None:
+        th2 = psm.TriangleHierarchy(ctx)
+        th2.allocate(n)
+        th2.loadMesh(mesh)
+        th2.build()
+        ob = oracle.build_scene(tris)
+        assert np.array_equal(th2.download(psm.BVH_KEYS, np.uint64, ob["count"]), ob["keys"])
+        th2.close()
+    th.close()
+
+
 def test_errors_are_reported(psm, ctx):
     th = psm.TriangleHierarchy(ctx)
     th.allocate(4)
