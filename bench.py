@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=3_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--emulate-tile", default=None, help="R/W: render only the tile of rank R of W on one GPU, no communication (Amdahl study)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path even on 1 GPU (rehearsal)")
     return ap.parse_args()
 
@@ -74,6 +75,9 @@ class Renderer:
         if dist.active:
             self.rt.setTileInterleaved(dist.rank, dist.world)  # 8-row bands dealt round-robin
             dist.initial_total = w * h
+        elif args.emulate_tile:
+            r_, w_ = (int(v) for v in args.emulate_tile.split("/"))
+            self.rt.setTileInterleaved(r_, w_)
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if dist.active:
             torch = dist.torch

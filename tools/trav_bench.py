@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Traversal micro-benchmark: primary + second-round rays of one Sponza-class frame, traversal only."""
 import importlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 psm = importlib.import_module("prismarine-core_amd")
 scenes = importlib.import_module("prismarine-core_amd.scenes")
@@ -48,4 +48,28 @@ if os.environ.get("SORT_EXP"):
         for _ in range(reps): rt.intersection(th, force=True)
         st = ctx.stats(); ms_ = st.traverse_ms / reps
         print("%s round2 sorted by %s: %.3f ms  %.1f Mrays/s" % (os.environ.get("TAG", ""), name, ms_, len(rays) / ms_ / 1e3))
+        ctx.stats_enable(False, False)
+
+if os.environ.get("SIZE_EXP"):
+    rays = sets[1]
+    for frac in (1, 2, 4, 8, 16, 32, 64, 256):
+        sub = rays[: len(rays) // frac]
+        rt.upload_rays(sub)
+        rt.intersection(th, force=True); ctx.sync()
+        ctx.stats_enable(True, False); ctx.stats_reset()
+        for _ in range(reps): rt.intersection(th, force=True)
+        st = ctx.stats(); ms_ = st.traverse_ms / reps
+        print("%s round2 first 1/%d (%d rays): %.3f ms  %.1f Mrays/s" % (os.environ.get("TAG", ""), frac, len(sub), ms_, len(sub) / ms_ / 1e3))
+        ctx.stats_enable(False, False)
+
+if os.environ.get("TINY_EXP"):
+    rays = sets[1]
+    for cnt_ in (64, 1024, 8192):
+        sub = rays[:cnt_]
+        rt.upload_rays(sub)
+        rt.intersection(th, force=True); ctx.sync()
+        ctx.stats_enable(True, False); ctx.stats_reset()
+        for _ in range(20): rt.intersection(th, force=True)
+        st = ctx.stats(); ms_ = st.traverse_ms / 20
+        print("%s tiny %d rays: %.4f ms" % (os.environ.get("TAG", ""), cnt_, ms_))
         ctx.stats_enable(False, False)
