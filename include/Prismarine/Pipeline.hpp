@@ -30,7 +30,9 @@ namespace NSM {
         uint32_t displayWidth = 256;
         uint32_t displayHeight = 256;
 
-        void setSkybox(GLuint skb) { skybox = skb; }   // equirect lookup: SURVEY f3; constant sky until then
+        void setSkybox(GLuint skb) { skybox = skb; }   // kept for source compatibility; the image comes through setSkyboxImage
+        // equirect RGBA8 image (public/environment.glsl:23-26; Application.hpp:46-54 upload)
+        void setSkyboxImage(const uint8_t * rgba8, uint32_t w, uint32_t h) { check(psm_rt_set_skybox(rt, rgba8, w, h), "Pipeline::setSkyboxImage"); }
 
         void switchMode();
         void resize(const uint32_t & w, const uint32_t & h);

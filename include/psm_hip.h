@@ -177,8 +177,12 @@ int psm_rt_set_tile(psm_rt* rt, uint32_t y0, uint32_t y1);
 int psm_rt_set_tile_interleaved(psm_rt* rt, uint32_t rank, uint32_t world);
 /* lightColor/lightVector/lightOffset/lightAmbient + setLightCount, Pipeline.hpp:103-121 */
 int psm_rt_set_lights(psm_rt* rt, const psm_light* lights, uint32_t count);
-/* environment: constant colour (the equirect skybox of setSkybox() is a later row) */
+/* environment: constant colour ... */
 int psm_rt_set_sky(psm_rt* rt, const float rgba[4]);
+/* ... or setSkybox(), Pipeline.hpp:93 + public/environment.glsl:23-26: an equirect RGBA8 image
+ * (host pointer, width*height*4 bytes, row 0 first) sampled with GL_LINEAR / clamp-to-edge as the app's
+ * loadCubemap() sets it up (Application.hpp:46-54). NULL restores the constant colour. */
+int psm_rt_set_skybox(psm_rt* rt, const uint8_t* rgba8, uint32_t width, uint32_t height);
 /* MaterialSet::loadToVGA + bindWithContext, MaterialSet.inl:13-23 (host pointer, copied) */
 int psm_rt_set_materials(psm_rt* rt, const psm_material* mats, uint32_t count, int32_t load_offset);
 /* camera(persp, frontSide), Pipeline.inl:279-296 -> camera.comp. camInv/projInv are the inverse

@@ -33,7 +33,7 @@ class FrameCfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("display_width", C.c_int),
                 ("display_height", C.c_int), ("light_count", C.c_int), ("material_offset", C.c_int),
                 ("material_count", C.c_int), ("sky", C.c_float * 4), ("ray_limit", C.c_int),
-                ("samples_lock", C.c_int)]
+                ("samples_lock", C.c_int), ("sky_tex", C.c_void_p), ("sky_w", C.c_int), ("sky_h", C.c_int)]
 
 
 def build(force=False):
@@ -65,6 +65,10 @@ def lib():
             getattr(_lib, f).argtypes = [C.c_float]
         _lib.psmo_powf.restype = C.c_float
         _lib.psmo_powf.argtypes = [C.c_float, C.c_float]
+        _lib.psmo_atan2f.restype = C.c_float
+        _lib.psmo_atan2f.argtypes = [C.c_float, C.c_float]
+        _lib.psmo_asinf.restype = C.c_float
+        _lib.psmo_asinf.argtypes = [C.c_float]
         _lib.psmo_find_split.restype = C.c_int
         _lib.psmo_build_nodes.restype = C.c_int
         _lib.psmo_morton_leaves.restype = C.c_int
@@ -254,6 +258,15 @@ def make_cfg(width, height, display=None, lights=1, material_count=1, material_o
     cfg.sky[3] = 1.0
     cfg.ray_limit = ray_limit if ray_limit is not None else min(4 * width * height, 4096 * 4096)
     cfg.samples_lock = samples_lock
+    cfg.sky_tex, cfg.sky_w, cfg.sky_h = None, 0, 0
+    return cfg
+
+
+def set_skybox(cfg, rgba8):
+    """rgba8: uint8 [h,w,4] equirect image; keep the array alive while cfg is used."""
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    cfg._sky_keep = rgba8
+    cfg.sky_tex, cfg.sky_h, cfg.sky_w = rgba8.ctypes.data, rgba8.shape[0], rgba8.shape[1]
     return cfg
 
 
@@ -316,7 +329,7 @@ def rand_next(state):
 
 
 def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, built=None,
-                  cam=None, rows=None, record=None):
+                  cam=None, rows=None, record=None, skybox=None):
     """Viewer.cpp:296-312 call order on the oracle: build, camera, <=depth x (traverse, shade), sample.
     Returns (filtered image [h,w,4], stats)."""
     from importlib import import_module
@@ -326,6 +339,8 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
         built = build_scene(tris)
     mats = scenes.materials_array(scene["materials"])
     cfg = make_cfg(width, height, material_count=len(mats))
+    if skybox is not None:
+        set_skybox(cfg, skybox)
     lights = default_lights(1)
     cam_inv, proj_inv = cam if cam else scenes.camera_matrices(scene["eye"], scene["view"], width, height)
     presampled = np.zeros((width * height, 4), np.float32)

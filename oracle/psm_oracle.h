@@ -61,6 +61,8 @@ uint32_t psmo_hash(uint32_t x);
 float psmo_sinf(float x);
 float psmo_cosf(float x);
 float psmo_powf(float x, float y);
+float psmo_atan2f(float y, float x);
+float psmo_asinf(float x);
 
 /* ---- build ---- */
 void psmo_minmax(const float* tris, int n, const float M[16], float mn[4], float mx[4]);
@@ -143,6 +145,8 @@ typedef struct {
     float sky[4];                  /* constant environment colour */
     int ray_limit;                 /* currentRayLimit, Pipeline.inl:187-189 */
     int samples_lock;              /* SAMPLES_LOCK, constants.glsl:35 (4) */
+    const uint8_t* sky_tex;        /* optional equirect RGBA8 skybox (NULL = constant sky) */
+    int sky_w, sky_h;
 } psmo_frame_cfg;
 
 int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],

@@ -101,6 +101,56 @@ float psmo_powf(float x, float y) {
     return exp2_pinned(y * log2_pinned(x));
 }
 
+static float atan_pos(float x) {
+    float y0 = 0.0f;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = p * z + -1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z + -3.33329491539e-1f;
+    return y0 + (p * z * x + x);
+}
+float psmo_atan2f(float y, float x) {
+    const float PI_F = 3.14159265358979323846f;
+    if (x == 0.0f && y == 0.0f) return 0.0f;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a = (ax == 0.0f) ? 1.5707963267948966f : atan_pos(ay / ax);
+    if (x < 0.0f) a = PI_F - a;
+    return (y < 0.0f) ? -a : a;
+}
+float psmo_asinf(float x) {
+    float c = pclamp(x, -1.0f, 1.0f);
+    return psmo_atan2f(c, sqrtf((1.0f - c) * (1.0f + c)));
+}
+
+/* public/environment.glsl:23-26 readEnv: equirect lookup, RGBA8 texture, GL_LINEAR, clamp to edge
+ * (Source/Examples/Application.hpp:46-54). Canonical bilinear filter: fp32 weights. */
+static void read_env(const psmo_frame_cfg* cfg, const float* r, float out[3]) {
+    if (!cfg->sky_tex || cfg->sky_w <= 0 || cfg->sky_h <= 0) { out[0] = cfg->sky[0]; out[1] = cfg->sky[1]; out[2] = cfg->sky[2]; return; }
+    const float PI_F = 3.14159265358979323846f;
+    float nr[3];
+    normalize3(r, nr);
+    float u = fmaf(psmo_atan2f(nr[2], nr[0]) / PI_F, 0.5f, 0.5f);
+    float v = fmaf((psmo_asinf(nr[1]) * 2.0f) / PI_F, 0.5f, 0.5f);
+    float x = u * (float)cfg->sky_w - 0.5f, y = v * (float)cfg->sky_h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float a = x - fx, b = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > cfg->sky_w - 1 ? cfg->sky_w - 1 : x0);
+    x1 = x1 < 0 ? 0 : (x1 > cfg->sky_w - 1 ? cfg->sky_w - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > cfg->sky_h - 1 ? cfg->sky_h - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > cfg->sky_h - 1 ? cfg->sky_h - 1 : y1);
+    const uint8_t* t = cfg->sky_tex;
+    for (int c = 0; c < 3; c++) {
+        float t00 = (float)t[4 * (y0 * cfg->sky_w + x0) + c] / 255.0f, t10 = (float)t[4 * (y0 * cfg->sky_w + x1) + c] / 255.0f;
+        float t01 = (float)t[4 * (y1 * cfg->sky_w + x0) + c] / 255.0f, t11 = (float)t[4 * (y1 * cfg->sky_w + x1) + c] / 255.0f;
+        float top = t00 * (1.0f - a) + t10 * a, bot = t01 * (1.0f - a) + t11 * a;
+        out[c] = top * (1.0f - b) + bot * b;
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* RNG, include/random.glsl:11-46                                      */
 /* ------------------------------------------------------------------ */
@@ -443,7 +493,9 @@ int psmo_shade(const psmo_frame_cfg* cfg, const psmo_light* lights, const psmo_m
         }
         /* background, :141-152 (constant sky) */
         if (greaterEqualF(uvt_t, PSMO_INFINITY) && type != 2 && !skipping) {
-            for (int k = 0; k < 3; k++) { ray.final[k] = ray.color[k] * cfg->sky[k]; ray.color[k] = ray.color[k] * 0.0f; }
+            float envc[3];
+            read_env(cfg, ray.direct, envc);
+            for (int k = 0; k < 3; k++) { ray.final[k] = ray.color[k] * envc[k]; ray.color[k] = ray.color[k] * 0.0f; }
             S_ACTIVE(ray.bf, 0);
             skipping = 1;
         }

@@ -27,7 +27,7 @@ EXPORTS = [
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
-    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
+    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
     "psm_rt_traverse", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
@@ -417,8 +417,15 @@ class Pipeline:
         a = np.asarray(list(rgb)[:3] + [1.0], np.float32)
         self.ctx.check(lib().psm_rt_set_sky(self._h, _p(a)), "psm_rt_set_sky")
 
-    def setSkybox(self, handle):
-        self._skybox = handle  # equirect lookup is a later row; constant sky until then
+    def setSkybox(self, image):
+        """setSkybox(GLuint) (Pipeline.hpp:93): here the equirect image itself, uint8 [h,w,4] RGBA (None =
+        constant sky colour). Sampled as public/environment.glsl:23-26 does (GL_LINEAR, clamp to edge)."""
+        if image is None:
+            self.ctx.check(lib().psm_rt_set_skybox(self._h, None, C.c_uint32(0), C.c_uint32(0)), "psm_rt_set_skybox")
+            return
+        img = np.ascontiguousarray(image, np.uint8)
+        self.ctx.check(lib().psm_rt_set_skybox(self._h, _p(img), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0])),
+                       "psm_rt_set_skybox")
 
     def clearSampler(self):
         self.ctx.check(lib().psm_rt_clear_sampler(self._h), "psm_rt_clear_sampler")
@@ -528,6 +535,24 @@ class Pipeline:
         if self._h:
             lib().psm_rt_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def write_pfm(path, image):
+    """Save an HDR snapshot (snapHdr(); the app writes EXR on key L, Application.hpp:324-343) as a PFM file:
+    'PF', width height, scale -1.0 (little endian), rows bottom to top, RGB float32."""
+    img = np.ascontiguousarray(image[..., :3], np.float32)
+    with open(path, "wb") as f:
+        f.write(("PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0])).encode())
+        f.write(img[::-1].astype("<f4").tobytes())
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), "<f4" if scale < 0 else ">f4").reshape(h, w, 3)
+    return data[::-1].copy()
 
 
 def sharded_rounds(rays, intersector, materials, depth=16):

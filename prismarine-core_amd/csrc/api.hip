@@ -426,7 +426,7 @@ int psm_rt_destroy(psm_rt* r) {
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     rt_free_grid(r);
-    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt);
+    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky);
     delete r;
     return PSM_OK;
 }
@@ -564,6 +564,22 @@ int psm_rt_set_lights(psm_rt* r, const psm_light* lights, uint32_t count) {
 int psm_rt_set_sky(psm_rt* r, const float rgba[4]) {
     if (!r || !rgba) return PSM_ERR_INVALID;
     for (int k = 0; k < 4; k++) r->sky[k] = rgba[k];
+    return PSM_OK;
+}
+
+int psm_rt_set_skybox(psm_rt* r, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!r) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    dev_free(r->d_sky);
+    r->sky_w = r->sky_h = 0;
+    if (!rgba8 || width == 0 || height == 0) return PSM_OK;
+    int rc = dev_alloc(c, &r->d_sky, (size_t)width * height);
+    if (rc != PSM_OK) return rc;
+    PSM_HIP(c, hipMemcpyAsync(r->d_sky, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    r->sky_w = width; r->sky_h = height;
     return PSM_OK;
 }
 

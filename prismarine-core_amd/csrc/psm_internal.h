@@ -110,6 +110,8 @@ struct psm_rt {
     uint32_t mat_count = 0;
     int32_t mat_offset = 0;
     float sky[4] = {0.5f, 0.7f, 1.0f, 1.0f};
+    uint32_t* d_sky = nullptr;    // equirect RGBA8 skybox (one texel per word) or null
+    uint32_t sky_w = 0, sky_h = 0;
     int samples_lock = 4;         // SAMPLES_LOCK, constants.glsl:35
 };
 

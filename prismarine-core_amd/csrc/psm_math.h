@@ -203,6 +203,31 @@ PSM_HD float ppow(float x, float y) {
     return pexp2(y * plog2(x));
 }
 
+// atan / atan2 / asin for the equirect sky lookup (public/environment.glsl:23-26)
+PSM_HD float patan_pos(float x) {  // x >= 0
+    float y0 = 0.0f;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = p * z + -1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z + -3.33329491539e-1f;
+    return y0 + (p * z * x + x);
+}
+PSM_HD float patan2(float y, float x) {
+    const float PI_F = 3.14159265358979323846f;
+    if (x == 0.0f && y == 0.0f) return 0.0f;
+    float ax = pabs(x), ay = pabs(y);
+    float a = (ax == 0.0f) ? 1.5707963267948966f : patan_pos(ay / ax);
+    if (x < 0.0f) a = PI_F - a;
+    return (y < 0.0f) ? -a : a;
+}
+PSM_HD float pasin(float x) {
+    float c = pclamp(x, -1.0f, 1.0f);
+    return patan2(c, sqrtf((1.0f - c) * (1.0f + c)));
+}
+
 // ---- double 4x4 helpers for the fit transform (TriangleHierarchy.inl:257-267) ---------------
 PSM_HD void inverse4d(const double* m, double* o) {
     double a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3];

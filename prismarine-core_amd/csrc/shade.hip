@@ -211,6 +211,32 @@ PSM_D float intersectSphere(v3 origin, v3 ray, v3 c, float radius) {
     return t;
 }
 
+// readEnv, public/environment.glsl:23-26: equirect RGBA8, GL_LINEAR, clamp to edge (fp32 weights)
+PSM_D v3 read_env(const uint32_t* __restrict__ sky, int sw, int sh, v3 r) {
+    const float PI_F = 3.14159265358979323846f;
+    v3 nr = normalize3(r);
+    float u = fmaf(patan2(nr.z, nr.x) / PI_F, 0.5f, 0.5f);
+    float v = fmaf((pasin(nr.y) * 2.0f) / PI_F, 0.5f, 0.5f);
+    float x = u * (float)sw - 0.5f, y = v * (float)sh - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float a = x - fx, b = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > sw - 1 ? sw - 1 : x0);
+    x1 = x1 < 0 ? 0 : (x1 > sw - 1 ? sw - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > sh - 1 ? sh - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > sh - 1 ? sh - 1 : y1);
+    uint32_t p00 = sky[y0 * sw + x0], p10 = sky[y0 * sw + x1], p01 = sky[y1 * sw + x0], p11 = sky[y1 * sw + x1];
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float t00 = (float)((p00 >> (8 * c)) & 255u) / 255.0f, t10 = (float)((p10 >> (8 * c)) & 255u) / 255.0f;
+        float t01 = (float)((p01 >> (8 * c)) & 255u) / 255.0f, t11 = (float)((p11 >> (8 * c)) & 255u) / 255.0f;
+        float top = t00 * (1.0f - a) + t10 * a, bot = t01 * (1.0f - a) + t11 * a;
+        o[c] = top * (1.0f - b) + bot * b;
+    }
+    return mk3(o[0], o[1], o[2]);
+}
+
 struct WRay {
     v3 origin, direct, color, fin;
     int bf;
@@ -266,6 +292,8 @@ struct ShadeArgs {
     uint32_t time;
     int mat_offset, mat_count, light_count;
     float sky[3];
+    const uint32_t* sky_tex;
+    int sky_w, sky_h;
 };
 
 // surface.comp + rayshading.comp:48-278
@@ -358,7 +386,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
         }
         // background, :141-152 (constant sky)
         if (greaterEqualF(uvt_t, INF) && type != 2 && !skipping) {
-            ray.fin = mk3(ray.color.x * a.sky[0], ray.color.y * a.sky[1], ray.color.z * a.sky[2]);
+            v3 envc = a.sky_tex ? read_env(a.sky_tex, a.sky_w, a.sky_h, ray.direct) : mk3(a.sky[0], a.sky[1], a.sky[2]);
+            ray.fin = mk3(ray.color.x * envc.x, ray.color.y * envc.y, ray.color.z * envc.z);
             ray.color = ray.color * 0.0f;
             S_ACTIVE(ray.bf, 0);
             skipping = true;
@@ -678,6 +707,7 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     a.nrays = n; a.time = time;
     a.mat_offset = r->mat_offset; a.mat_count = (int)r->mat_count; a.light_count = (int)r->light_count;
     a.sky[0] = r->sky[0]; a.sky[1] = r->sky[1]; a.sky[2] = r->sky[2];
+    a.sky_tex = r->d_sky; a.sky_w = (int)r->sky_w; a.sky_h = (int)r->sky_h;
     int nxt = r->cur ^ 1;
     {
         TimedScope ts(c, CAT_SHADE);

@@ -412,6 +412,39 @@ def test_load_mesh_matches_oracle(psm, ctx, oracle, scenes, kw):
     th.close()
 
 
+def _sky_image(w=64, h=32):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0] = (40 + 200 * xx / (w - 1)).astype(np.uint8)
+    img[..., 1] = (255 * yy / (h - 1)).astype(np.uint8)
+    img[..., 2] = ((xx * 7 + yy * 13) % 256).astype(np.uint8)
+    img[..., 3] = 255
+    return img
+
+
+def test_equirect_skybox_radiance(psm, ctx, oracle, scenes, tmp_path):
+    """setSkybox -- equirect RGBA8 lookup (environment.glsl:23-26) + HDR snapshot to PFM."""
+    scene = scenes.cornell(open_top=True)
+    w, h, frames = 72, 56, 2
+    sky = _sky_image()
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    rt.setSkybox(sky)
+    rt.setSeed(99)
+    for _ in range(frames):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    img = rt.snapHdr()
+    ref, _ = oracle.render_frames(scene, w, h, frames=frames, seed=99, skybox=sky)
+    const, _ = oracle.render_frames(scene, w, h, frames=frames, seed=99)
+    assert np.abs(ref[..., :3] - const[..., :3]).max() > 0.05      # the texture really changes the image
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    path = str(tmp_path / "snap.pfm")
+    psm.write_pfm(path, img)
+    assert np.array_equal(psm.read_pfm(path), img[..., :3])
+    rt.setSkybox(None)
+    rt.close()
+    th.close()
+
+
 def test_errors_are_reported(psm, ctx):
     th = psm.TriangleHierarchy(ctx)
     th.allocate(4)
