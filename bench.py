@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="sponza_like", choices=["sponza_like", "cornell", "stress"])
+    ap.add_argument("--textured", action="store_true",
+                    help="not the headline workload: add texcoords + the procedural texture table (SURVEY f2)")
     ap.add_argument("--depth", type=int, default=16)  # Application.hpp:237
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=3_000_000)
@@ -64,10 +66,15 @@ class Renderer:
         self.ctx = psm.Context(dist.device_index, stream=stream)
         self.th = psm.TriangleHierarchy(self.ctx)
         self.th.allocate(scene["tris"].shape[0])
-        self.th.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+        self.th.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
         self.ms = psm.MaterialSet()
         for m in scene["materials"]:
             self.ms.addSubmat(m)
+        if scene.get("textures"):
+            ts = psm.TextureSet()
+            for slot in sorted(scene["textures"]):
+                assert ts.loadTexture(scene["textures"][slot]) == slot
+            self.ms.setTextureSet(ts)
         w, h = args.width, args.height
         self.rt = psm.Pipeline(self.ctx, seed=1000)
         self.rt.resizeBuffers(w, h)
@@ -167,6 +174,8 @@ def main():
     dist = pdist.Comm(world, force=args.force_dist)
     scenes = importlib.import_module("prismarine-core_amd.scenes")
     scene = {"sponza_like": scenes.sponza_like, "cornell": scenes.cornell, "stress": scenes.stress}[args.scene]()
+    if args.textured:
+        scene = scenes.textured(scene)
     R = Renderer(psm, scenes, scene, args, dist)
     ctx = R.ctx
 
@@ -226,7 +235,7 @@ def main():
             "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
                                    "per frame + camera + <=%d bounce rounds + sample" % (
                                        args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth),
-                       "scene": args.scene, "width": args.width, "height": args.height,
+                       "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
                        "parallelism": "tile%d" % world},
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,

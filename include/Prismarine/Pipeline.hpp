@@ -16,6 +16,8 @@ namespace NSM {
         TriangleHierarchy * lastObj = nullptr;
         uint64_t matRevision = 0;
         const MaterialSet * matOwner = nullptr;
+        uint64_t texRevision = 0;
+        const TextureSet * texOwner = nullptr;
         uint32_t randState = 1;       // host rand() of Pipeline.inl:282,426 (MSVC CRT LCG), see setSeed
         uint32_t lightcount = 1;
         void init();

@@ -100,6 +100,19 @@ namespace NSM {
             check(psm_rt_set_materials(rt, mat->submats.data(), (uint32_t)mat->submats.size(), mat->loadOffset), "Pipeline::applyMaterials");
             matOwner = mat; matRevision = mat->revision;
         }
+        TextureSet * ts = mat->texset;   // MaterialSet::bindWithContext -> TextureSet::bindWithContext, MaterialSet.inl:20-23
+        if (ts && (ts != texOwner || ts->revision != texRevision)) {
+            for (uint32_t i = 1; i < 32; i++) {
+                GLuint name = i < ts->textures.size() ? ts->textures[i] : GLuint(-1);
+                if (name != GLuint(-1) && name < hostTextures().size()) {
+                    const HostTexture & h = hostTextures()[name];
+                    check(psm_rt_set_texture(rt, i, h.rgba8.data(), h.width, h.height), "Pipeline::applyMaterials(texture)");
+                } else {
+                    check(psm_rt_set_texture(rt, i, nullptr, 0, 0), "Pipeline::applyMaterials(texture)");
+                }
+            }
+            texOwner = ts; texRevision = ts->revision;
+        }
     }
 
     inline void Pipeline::shade() {   // :423-436

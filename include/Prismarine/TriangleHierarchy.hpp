@@ -34,7 +34,7 @@ namespace NSM {
         void clearTribuffer();
         void loadMesh(TriangleArrayInstance * gobject);
         // direct ingestion of a world-space triangle soup (9 floats per triangle; normals / material ids optional)
-        void loadTriangles(const float * positions, const float * normals, const int32_t * materials, size_t count);
+        void loadTriangles(const float * positions, const float * normals, const int32_t * materials, size_t count, const float * texcoords = nullptr);
         bool isDirty() const;
         void markDirty();
         void resolve();

@@ -33,10 +33,11 @@ namespace NSM {
 
     inline void TriangleHierarchy::configureIntersection(bool clearDepth) { (void)clearDepth; }  // ignored by the reference's shaders too
 
-    inline void TriangleHierarchy::loadTriangles(const float * positions, const float * normals, const int32_t * materials, size_t count) {
+    inline void TriangleHierarchy::loadTriangles(const float * positions, const float * normals, const int32_t * materials, size_t count, const float * texcoords) {
         if (!bvh || count == 0) return;
         int rc = psm_bvh_load_triangles(bvh, positions, normals, materials, count, materialID);
         check(rc, "TriangleHierarchy::loadTriangles");
+        if (rc == PSM_OK && texcoords) check(psm_bvh_set_texcoords(bvh, triangleCount, texcoords, count), "TriangleHierarchy::loadTriangles(texcoords)");
         if (rc == PSM_OK) triangleCount += count;
         markDirty();
     }

@@ -82,6 +82,9 @@ int psm_bvh_clear(psm_bvh* bvh);
  * triangle material id (NULL -> material_id for all). Host pointers. */
 int psm_bvh_load_triangles(psm_bvh* bvh, const float* positions, const float* normals,
                            const int32_t* mats, size_t n, int32_t material_id);
+/* per-vertex texture coordinates (texcoords mosaic, loader.comp:131): 6 floats per triangle (u,v of the
+ * three vertices) for triangles [first, first+n); host pointer. Triangles never given any read as (0,0). */
+int psm_bvh_set_texcoords(psm_bvh* bvh, size_t first, const float* uv, size_t n);
 /* loadMesh() proper: the accessor / buffer-view virtualisation of
  * Include/Prismarine/VertexInstance.{hpp,inl} + ShadersSDK/vertex/loader.comp:32-152 as one HIP gather
  * kernel: de-index (32- or packed 16-bit indices), read by accessor, transform, normal fallback to the
@@ -142,7 +145,8 @@ enum {
     PSM_BVH_SORTED_TRI = 7,/* int32[leaf_count]    triangle id of the k-th sorted leaf */
     PSM_BVH_POSITIONS = 8, /* float[9][triangle_count] world-space triangle soup as loaded */
     PSM_BVH_NORMALS = 9,   /* float[9][triangle_count] per-vertex normals as loaded */
-    PSM_BVH_MATERIALS = 10 /* int32[triangle_count] */
+    PSM_BVH_MATERIALS = 10,/* int32[triangle_count] */
+    PSM_BVH_TEXCOORDS = 11 /* float[6][triangle_count] u,v per vertex */
 };
 int psm_bvh_download(psm_bvh* bvh, int what, void* dst, size_t bytes);
 
@@ -183,6 +187,11 @@ int psm_rt_set_sky(psm_rt* rt, const float rgba[4]);
  * (host pointer, width*height*4 bytes, row 0 first) sampled with GL_LINEAR / clamp-to-edge as the app's
  * loadCubemap() sets it up (Application.hpp:46-54). NULL restores the constant colour. */
 int psm_rt_set_skybox(psm_rt* rt, const uint8_t* rgba8, uint32_t width, uint32_t height);
+/* TextureSet (TextureSet.inl:15-35,88-122): slot 1..31 of the sampler table
+ * surface.comp indexes with diffusePart / specularPart / bumpPart / emissivePart (slot 0 = none,
+ * MAX_TEXTURES = 32, surface.comp:46). RGBA8, GL_LINEAR, GL_REPEAT as TextureSet::loadTexture sets them;
+ * host pointer, width*height*4 bytes. rgba8 == NULL frees the slot. */
+int psm_rt_set_texture(psm_rt* rt, uint32_t slot, const uint8_t* rgba8, uint32_t width, uint32_t height);
 /* MaterialSet::loadToVGA + bindWithContext, MaterialSet.inl:13-23 (host pointer, copied) */
 int psm_rt_set_materials(psm_rt* rt, const psm_material* mats, uint32_t count, int32_t load_offset);
 /* camera(persp, frontSide), Pipeline.inl:279-296 -> camera.comp. camInv/projInv are the inverse

@@ -29,11 +29,16 @@ class Counters(C.Structure):
                 ("iter_caps", C.c_uint64), ("baked_drops", C.c_uint64)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("w", C.c_int), ("h", C.c_int)]
+
+
 class FrameCfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("display_width", C.c_int),
                 ("display_height", C.c_int), ("light_count", C.c_int), ("material_offset", C.c_int),
                 ("material_count", C.c_int), ("sky", C.c_float * 4), ("ray_limit", C.c_int),
-                ("samples_lock", C.c_int), ("sky_tex", C.c_void_p), ("sky_w", C.c_int), ("sky_h", C.c_int)]
+                ("samples_lock", C.c_int), ("sky_tex", C.c_void_p), ("sky_w", C.c_int), ("sky_h", C.c_int),
+                ("texcoords", C.c_void_p), ("textures", Texture * 32)]
 
 
 def build(force=False):
@@ -217,8 +222,9 @@ class OMeshDesc(C.Structure):
                 ("primitive_type", C.c_int32), ("loading_offset", C.c_int32)]
 
 
-def load_mesh(mesh):
-    """mesh: dict as built by prismarine-core_amd.make_mesh_desc (host arrays). Returns (pos, nrm, mats)."""
+def load_mesh(mesh, with_tex=False):
+    """mesh: dict as built by prismarine-core_amd.make_mesh_desc (host arrays). Returns (pos, nrm, mats) or,
+    with_tex, (pos, nrm, mats, tex[n,6])."""
     d = OMeshDesc()
     verts = np.ascontiguousarray(mesh["vertices"], np.float32)
     idx = None if mesh.get("indices") is None else np.ascontiguousarray(mesh["indices"], np.uint32)
@@ -229,7 +235,7 @@ def load_mesh(mesh):
     d.accessors, d.accessor_count = C.cast(acc, C.c_void_p), len(mesh["accessors"])
     d.views, d.view_count = C.cast(views, C.c_void_p), len(mesh["views"])
     d.vertex_accessor, d.normal_accessor = mesh["vertex_accessor"], mesh.get("normal_accessor", -1)
-    d.texcoord_accessor, d.modifier_accessor = -1, -1
+    d.texcoord_accessor, d.modifier_accessor = mesh.get("texcoord_accessor", -1), -1
     t = np.ascontiguousarray(mesh["transform"], np.float32).reshape(16)
     ti = np.ascontiguousarray(mesh["transform_inv"], np.float32).reshape(16)
     for k in range(16):
@@ -240,10 +246,11 @@ def load_mesh(mesh):
     pos = np.zeros((n, 9), np.float32)
     nrm = np.zeros((n, 9), np.float32)
     mats = np.zeros(n, np.int32)
-    lib().psmo_load_mesh.restype = C.c_int
-    got = lib().psmo_load_mesh(C.byref(d), C.c_int(0), _p(pos), _p(nrm), _p(mats))
+    tex = np.zeros((n, 6), np.float32)
+    lib().psmo_load_mesh_tex.restype = C.c_int
+    got = lib().psmo_load_mesh_tex(C.byref(d), C.c_int(0), _p(pos), _p(nrm), _p(mats), _p(tex))
     assert got == n
-    return pos, nrm, mats
+    return (pos, nrm, mats, tex) if with_tex else (pos, nrm, mats)
 
 
 def make_cfg(width, height, display=None, lights=1, material_count=1, material_offset=0,
@@ -267,6 +274,26 @@ def set_skybox(cfg, rgba8):
     rgba8 = np.ascontiguousarray(rgba8, np.uint8)
     cfg._sky_keep = rgba8
     cfg.sky_tex, cfg.sky_h, cfg.sky_w = rgba8.ctypes.data, rgba8.shape[0], rgba8.shape[1]
+    return cfg
+
+
+def set_textures(cfg, texcoords=None, textures=None):
+    """texcoords: float32 [n_tris,3,2]; textures: {slot(1..31): uint8 [h,w,4]} (row 0 = v 0). Arrays are kept
+    alive on cfg."""
+    cfg._tex_keep = []
+    if texcoords is not None:
+        tc = np.ascontiguousarray(texcoords, np.float32)
+        cfg._tex_keep.append(tc)
+        cfg.texcoords = tc.ctypes.data
+    else:
+        cfg.texcoords = None
+    for i in range(32):
+        cfg.textures[i].rgba8, cfg.textures[i].w, cfg.textures[i].h = None, 0, 0
+    for slot, img in (textures or {}).items():
+        assert 0 < slot < 32
+        img = np.ascontiguousarray(img, np.uint8)
+        cfg._tex_keep.append(img)
+        cfg.textures[slot].rgba8, cfg.textures[slot].h, cfg.textures[slot].w = img.ctypes.data, img.shape[0], img.shape[1]
     return cfg
 
 
@@ -341,6 +368,8 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
     cfg = make_cfg(width, height, material_count=len(mats))
     if skybox is not None:
         set_skybox(cfg, skybox)
+    if scene.get("texcoords") is not None or scene.get("textures"):
+        set_textures(cfg, scene.get("texcoords"), scene.get("textures"))
     lights = default_lights(1)
     cam_inv, proj_inv = cam if cam else scenes.camera_matrices(scene["eye"], scene["view"], width, height)
     presampled = np.zeros((width * height, 4), np.float32)

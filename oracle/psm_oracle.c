@@ -401,10 +401,14 @@ static void read_by_accessor(const psmo_mesh_desc* d, int accessorID, uint32_t i
 }
 
 int psmo_load_mesh(const psmo_mesh_desc* d, int storing_offset, float* pos, float* nrm, int32_t* mats) {
+    return psmo_load_mesh_tex(d, storing_offset, pos, nrm, mats, NULL);
+}
+
+int psmo_load_mesh_tex(const psmo_mesh_desc* d, int storing_offset, float* pos, float* nrm, int32_t* mats, float* tex) {
     int trp = d->primitive_type == 1 ? 4 : 3;
     int istride = d->primitive_type == 1 ? 2 : 1;
     for (int ct = 0; ct < d->node_count; ct++) {
-        float vertice[4][3], normal[4][3];
+        float vertice[4][3], normal[4][3], tuv[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         for (int i = 0; i < trp; i++) {
             uint32_t ptri = (uint32_t)d->loading_offset + (uint32_t)(ct * trp + i);
             uint32_t vi = ptri;
@@ -415,6 +419,8 @@ int psmo_load_mesh(const psmo_mesh_desc* d, int storing_offset, float* pos, floa
             float p[4], n[4] = {0.f, 0.f, 0.f, 0.f};
             read_by_accessor(d, d->vertex_accessor, vi, p);
             if (d->normal_accessor != -1) read_by_accessor(d, d->normal_accessor, vi, n);
+            if (d->texcoord_accessor != -1) { float t4[4]; read_by_accessor(d, d->texcoord_accessor, vi, t4); tuv[i][0] = t4[0]; tuv[i][1] = t4[1]; } /* :94-96 */
+            tuv[i][1] = 1.0f - tuv[i][1]; /* INVERT_TX_Y, :97-99 (build-spv-new.bat:31-32) */
             float pv[4] = {p[0], p[1], p[2], 1.0f}, nv[4] = {n[0], n[1], n[2], 0.0f}, po[4], no[4];
             mat_vec(d->transform, pv, po);       /* :101 */
             matT_vec(d->transform_inv, nv, no);  /* :100 */
@@ -436,6 +442,7 @@ int psmo_load_mesh(const psmo_mesh_desc* d, int storing_offset, float* pos, floa
                 if (pmax(an[0], pmax(an[1], an[2])) >= 0.0001f && d->normal_accessor != -1) normalize3(nn, use);
                 else normalize3(offsetnormal, use); /* :124-128 */
                 for (int k = 0; k < 3; k++) { pos[9 * tidc + 3 * i + k] = vertice[m[i]][k]; nrm[9 * tidc + 3 * i + k] = use[k]; }
+                if (tex) { tex[6 * tidc + 2 * i] = tuv[m[i]][0]; tex[6 * tidc + 2 * i + 1] = tuv[m[i]][1]; }
             }
         }
     }

@@ -93,6 +93,8 @@ typedef struct {
 } psmo_mesh_desc;
 /* appends to pos/nrm (9 floats per triangle) and mats starting at triangle `storing_offset`; returns triangles written */
 int psmo_load_mesh(const psmo_mesh_desc* d, int storing_offset, float* pos, float* nrm, int32_t* mats);
+/* same, also writing the texcoord mosaic (6 floats per triangle: u,v per vertex; v stored as 1 - v) */
+int psmo_load_mesh_tex(const psmo_mesh_desc* d, int storing_offset, float* pos, float* nrm, int32_t* mats, float* tex);
 
 /* ---- trace ---- */
 int psmo_traverse(const psmo_node* nodes, const float* tris, const float M[16],
@@ -138,6 +140,11 @@ typedef struct {
 } psmo_light; /* LightUniformStruct, Structs.hpp:165-170 */
 
 typedef struct {
+    const uint8_t* rgba8;          /* NULL = empty slot */
+    int w, h;
+} psmo_texture; /* RGBA8, GL_LINEAR, GL_REPEAT (TextureSet.inl:113-118) */
+
+typedef struct {
     int width, height;             /* ray grid (sceneRes) */
     int display_width, display_height;
     int light_count;
@@ -147,6 +154,8 @@ typedef struct {
     int samples_lock;              /* SAMPLES_LOCK, constants.glsl:35 (4) */
     const uint8_t* sky_tex;        /* optional equirect RGBA8 skybox (NULL = constant sky) */
     int sky_w, sky_h;
+    const float* texcoords;        /* optional, 6 floats / triangle (u,v per vertex); NULL = all (0,0) */
+    psmo_texture textures[32];     /* sampler table, surface.comp:46-52; slot 0 unused */
 } psmo_frame_cfg;
 
 int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],

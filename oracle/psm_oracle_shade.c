@@ -293,6 +293,34 @@ typedef struct {
     int active;           /* HitActived */
 } surf_t;
 
+/* validateTexture, surface.comp:81-83 */
+static int valid_tex(const psmo_frame_cfg* cfg, uint32_t binding) {
+    return binding != 0u && binding != 0xFFFFFFFFu && binding < 32u && cfg->textures[binding].rgba8 &&
+           cfg->textures[binding].w > 0;
+}
+
+/* fetchTexture, surface.comp:85-95: RGBA8 unorm, GL_LINEAR + GL_REPEAT, fp32 weights; non-finite reads 0 */
+static void fetch_tex(const psmo_texture* t, float u, float v, int ox, int oy, float* o) {
+    float uu = u + (float)ox / (float)t->w, vv = v + (float)oy / (float)t->h;
+    if (!(fabsf(uu) < INFINITY) || !(fabsf(vv) < INFINITY)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    uu = uu - floorf(uu); vv = vv - floorf(vv);
+    float x = uu * (float)t->w - 0.5f, y = vv * (float)t->h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float a = x - fx, b = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? x0 + t->w : x0; y0 = y0 < 0 ? y0 + t->h : y0;
+    x1 = x1 >= t->w ? x1 - t->w : x1; y1 = y1 >= t->h ? y1 - t->h : y1;
+    x0 = x0 >= t->w ? x0 - t->w : x0; y0 = y0 >= t->h ? y0 - t->h : y0;
+    const uint8_t* p00 = t->rgba8 + 4 * ((size_t)y0 * t->w + x0), *p10 = t->rgba8 + 4 * ((size_t)y0 * t->w + x1);
+    const uint8_t* p01 = t->rgba8 + 4 * ((size_t)y1 * t->w + x0), *p11 = t->rgba8 + 4 * ((size_t)y1 * t->w + x1);
+    for (int c = 0; c < 4; c++) {
+        float t00 = (float)p00[c] / 255.0f, t10 = (float)p10[c] / 255.0f;
+        float t01 = (float)p01[c] / 255.0f, t11 = (float)p11[c] / 255.0f;
+        float top = t00 * (1.0f - a) + t10 * a, bot = t01 * (1.0f - a) + t11 * a;
+        o[c] = top * (1.0f - b) + bot * b;
+    }
+}
+
 static void surface_eval(const psmo_frame_cfg* cfg, const psmo_material* mats, const int32_t* tri_mats,
                          const float* tris, const float* normals, const psmo_hit* h, surf_t* s) {
     int tri = h->tri;
@@ -318,13 +346,65 @@ static void surface_eval(const psmo_frame_cfg* cfg, const psmo_material* mats, c
     for (int k = 0; k < 4; k++) { s->albedo[k] = 0.f; s->emission[k] = 0.f; s->mr[k] = 0.f; }
     if (s->active) {
         const psmo_material* m = &mats[matID];
+        static const float zero_tc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* tc = cfg->texcoords ? cfg->texcoords + (size_t)6 * tri : zero_tc;
+        float tu = (vs[0] * tc[0] + vs[1] * tc[2]) + vs[2] * tc[4];
+        float tv = (vs[0] * tc[1] + vs[1] * tc[3]) + vs[2] * tc[5];
         float diff[4] = {pmax(m->diffuse[0], 0.f), pmax(m->diffuse[1], 0.f), pmax(m->diffuse[2], 0.f), 1.0f};
-        float emis[4] = {0.f * 2.f, 0.f * 2.f, 0.f * 2.f, 1.0f}; /* fetchEmissive: textures only */
-        float spc[4] = {m->specular[1], m->specular[2], 0.f, 0.f};
+        float emis[4] = {0.f, 0.f, 0.f, 0.f}; /* fetchEmissive: textures only (:110-116) */
+        float spc[4] = {m->specular[0], m->specular[1], m->specular[2], m->specular[3]};
+        if (valid_tex(cfg, m->diffusePart)) fetch_tex(&cfg->textures[m->diffusePart], tu, tv, 0, 0, diff);
+        if (valid_tex(cfg, m->emissivePart)) fetch_tex(&cfg->textures[m->emissivePart], tu, tv, 0, 0, emis);
+        if (valid_tex(cfg, m->specularPart)) fetch_tex(&cfg->textures[m->specularPart], tu, tv, 0, 0, spc);
+        if (valid_tex(cfg, m->bumpPart)) {
+            const psmo_texture* bt = &cfg->textures[m->bumpPart];
+            /* tangent, directTraverse.comp:190-209 */
+            float du1 = tc[2] - tc[0], du2 = tc[4] - tc[0];
+            float dv1 = tc[3] - tc[1], dv2 = tc[5] - tc[1];
+            float e0x = du1, e0y = du2, e1x = dv2, e1y = dv1 * -1.0f;
+            if (fabsf(e0x) < 0.000001f && fabsf(e0y) < 0.000001f) { e0x = 1.f; e0y = 0.f; }
+            if (fabsf(e1x) < 0.000001f && fabsf(e1y) < 0.000001f) { e1x = 1.f; e1y = 0.f; }
+            float f = 1.f / (e0x * e1x + e0y * e1y);
+            if (isnan(f)) f = 0.f;
+            if (isinf(f)) f = 10000.f;
+            float tang[3], tangent[3];
+            for (int k = 0; k < 3; k++) tang[k] = fmaf(e1x, d1[k], e1y * d2[k]) * f;
+            float ts = psign(dot3(tang, nor));
+            for (int k = 0; k < 3; k++) tangent[k] = tang[k] - nrm[k] * ts;
+            normalize3(tangent, tangent);
+            /* getNormalMapping, surface.comp:138-153 */
+            float nm4[4], nm[3];
+            fetch_tex(bt, tu, tv, 0, 0, nm4);
+            if (equalF(nm4[0], nm4[1]) && equalF(nm4[0], nm4[2])) { /* grey: a height map */
+                float h00[4], h01[4], h10[4];
+                fetch_tex(bt, tu, tv, 0, 0, h00);
+                fetch_tex(bt, tu, tv, 1, 0, h01);
+                fetch_tex(bt, tu, tv, 0, 1, h10);
+                float z0 = h00[0] * 2.0f, z1 = h01[0] * 2.0f, z2 = h10[0] * 2.0f;
+                float pa[3] = {1.0f - 0.0f, 0.0f - 0.0f, z1 - z0}, pb[3] = {0.0f - 0.0f, 1.0f - 0.0f, z2 - z0}, c2[3];
+                cross3(pa, pb, c2);
+                normalize3(c2, nm);
+            } else {
+                float raw[3] = {mixf(0.f, fmaf(nm4[0], 2.0f, -1.0f), 1.0f), mixf(0.f, fmaf(nm4[1], 2.0f, -1.0f), 1.0f),
+                                mixf(1.f, fmaf(nm4[2], 2.0f, -1.0f), 1.0f)};
+                normalize3(raw, nm);
+            }
+            /* surface.comp:176-186 */
+            float ns[3], tg[3], bc[3], bt3[3], w[3], o[3];
+            normalize3(nrm, ns);
+            normalize3(tangent, tg);
+            cross3(ns, tg, bc);
+            normalize3(bc, bt3);
+            normalize3(nm, w);
+            for (int k = 0; k < 3; k++) o[k] = (tg[k] * w[0] + bt3[k] * w[1]) + ns[k] * w[2];
+            normalize3(o, s->normal);
+        }
+        float emis2[4] = {emis[0] * 2.f, emis[1] * 2.f, emis[2] * 2.f, 1.0f};
+        float mr[4] = {spc[1], spc[2], 0.f, 0.f};
         uint32_t p[2];
         pack_half4(diff, p); unpack_half4(p, s->albedo);
-        pack_half4(emis, p); unpack_half4(p, s->emission);
-        pack_half4(spc, p); unpack_half4(p, s->mr);
+        pack_half4(emis2, p); unpack_half4(p, s->emission);
+        pack_half4(mr, p); unpack_half4(p, s->mr);
     }
 }
 

@@ -23,11 +23,11 @@ EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev",
-    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_load_mesh", "psm_bvh_build",
+    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
-    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
+    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
     "psm_rt_traverse", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
@@ -36,7 +36,7 @@ EXPORTS = [
 ]
 
 (BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
- BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS) = range(11)
+ BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS, BVH_TEXCOORDS) = range(12)
 
 RAY_DT = np.dtype([("origin", "<f4", 3), ("direct", "<f4", 3), ("color", "<f4", 3),
                    ("bitfield", "<i4"), ("texel", "<i4"), ("pkey", "<u4")])
@@ -229,8 +229,9 @@ class TriangleHierarchy:
     def setMaterialID(self, mid):
         self.materialID = mid
 
-    def loadTriangles(self, tris, normals=None, mats=None):
-        """loadMesh() reduced to its result: append world-space triangles (loader.comp:115-135)."""
+    def loadTriangles(self, tris, normals=None, mats=None, texcoords=None):
+        """loadMesh() reduced to its result: append world-space triangles (loader.comp:115-135);
+        texcoords: float32 [n,3,2] (u,v per vertex) or None."""
         tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
         n = tris.shape[0]
         nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 9)
@@ -238,6 +239,12 @@ class TriangleHierarchy:
         self.ctx.check(lib().psm_bvh_load_triangles(self._h, _p(tris), _p(nrm) if nrm is not None else None,
                                                     _p(mm) if mm is not None else None, C.c_size_t(n),
                                                     C.c_int32(self.materialID)), "psm_bvh_load_triangles")
+        if texcoords is not None:
+            tc = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 6)
+            if tc.shape[0] != n:
+                raise ValueError("texcoords: expected %d triangles, got %d" % (n, tc.shape[0]))
+            self.ctx.check(lib().psm_bvh_set_texcoords(self._h, C.c_size_t(self.triangleCount), _p(tc), C.c_size_t(n)),
+                           "psm_bvh_set_texcoords")
         self.triangleCount += n
         self.markDirty()
 
@@ -245,6 +252,7 @@ class TriangleHierarchy:
         """loadMesh(TriangleArrayInstance*) (TriangleHierarchy.inl:173-192): `mesh` is a dict with the
         fields of VertexInstance.hpp -- vertices (float pool), indices (uint32 words or None), accessors
         [(offset4, components, bufferView)], views [(offset4, stride4)], vertex_accessor, normal_accessor,
+        texcoord_accessor (v is stored as 1 - v, loader.comp:97-99),
         transform / transform_inv (row-major 4x4), material_id, index16, node_count, primitive_type,
         loading_offset. The pools are uploaded to device buffers and resolved by the HIP gather kernel."""
         verts = np.ascontiguousarray(mesh["vertices"], np.float32)
@@ -264,7 +272,7 @@ class TriangleHierarchy:
             d.accessors, d.accessor_count = C.cast(acc, C.c_void_p), len(mesh["accessors"])
             d.views, d.view_count = C.cast(views, C.c_void_p), len(mesh["views"])
             d.vertex_accessor, d.normal_accessor = mesh["vertex_accessor"], mesh.get("normal_accessor", -1)
-            d.texcoord_accessor, d.modifier_accessor = -1, -1
+            d.texcoord_accessor, d.modifier_accessor = mesh.get("texcoord_accessor", -1), -1
             t = np.ascontiguousarray(mesh["transform"], np.float32).reshape(16)
             ti = np.ascontiguousarray(mesh["transform_inv"], np.float32).reshape(16)
             for k in range(16):
@@ -322,12 +330,52 @@ class TriangleHierarchy:
             self._h = C.c_void_p()
 
 
+class TextureSet:
+    """psm::TextureSet (Include/Prismarine/TextureSet.{hpp,inl}): slot table of material textures. A texture
+    is an RGBA8 image, uint8 [h,w,4], row 0 = v 0 (GL order); slot 0 means "none" (TextureSet.inl:7-12)."""
+
+    def __init__(self):
+        self.textures = [None]
+        self.freedomTextures = []
+        self.revision = 1
+
+    def loadTexture(self, image):
+        """TextureSet.inl:73-86: reuse a freed slot, else append; returns the slot index materials refer to."""
+        img = np.ascontiguousarray(image, np.uint8)
+        if img.ndim != 3 or img.shape[2] != 4:
+            raise ValueError("texture must be uint8 [h,w,4]")
+        if self.freedomTextures:
+            idx = self.freedomTextures.pop()
+            self.textures[idx] = img
+        else:
+            idx = len(self.textures)
+            self.textures.append(img)
+        self.revision += 1
+        return idx
+
+    def freeTexture(self, idx):
+        self.freedomTextures.append(idx)
+        self.textures[idx] = None
+        self.revision += 1
+
+    def clearGlTextures(self):
+        for i in range(1, len(self.textures)):
+            self.freeTexture(i)
+
+    def loadToVGA(self):
+        pass  # uploaded by Pipeline.applyMaterials
+
+
 class MaterialSet:
     """psm::MaterialSet (Include/Prismarine/MaterialSet.hpp:28-41): a host-side material array."""
 
     def __init__(self):
         self.submats = []
         self.loadOffset = 0
+        self.texset = None
+
+    def setTextureSet(self, txs):
+        self.texset = txs
 
     def addSubmat(self, m):
         self.submats.append(m)
@@ -364,6 +412,7 @@ class Pipeline:
         self.raycountCache = 0
         self._rand_state = seed & 0xFFFFFFFF
         self._mat_sig = None
+        self._tex_sig = None
         self.resizeBuffers(256, 256)
         self.resize(256, 256)
 
@@ -466,6 +515,17 @@ class Pipeline:
             self.ctx.check(lib().psm_rt_set_materials(self._h, _p(arr), C.c_uint32(arr.shape[0]),
                                                       C.c_int32(mat.loadOffset)), "psm_rt_set_materials")
             self._mat_sig = sig
+        ts = mat.texset
+        if ts is not None and (id(ts), ts.revision) != self._tex_sig:
+            for i in range(1, 32):
+                img = ts.textures[i] if i < len(ts.textures) else None
+                if img is None:
+                    self.ctx.check(lib().psm_rt_set_texture(self._h, C.c_uint32(i), None, C.c_uint32(0), C.c_uint32(0)),
+                                   "psm_rt_set_texture")
+                else:
+                    self.ctx.check(lib().psm_rt_set_texture(self._h, C.c_uint32(i), _p(img), C.c_uint32(img.shape[1]),
+                                                            C.c_uint32(img.shape[0])), "psm_rt_set_texture")
+            self._tex_sig = (id(ts), ts.revision)
 
     def shade(self, time=None, force=False, reload=True):
         """reload=False leaves raycountCache stale: the caller learns the count elsewhere (ray_count_dev +

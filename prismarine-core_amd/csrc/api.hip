@@ -214,7 +214,7 @@ int psm_bvh_destroy(psm_bvh* b) {
     if (!b) return PSM_ERR_INVALID;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    dev_free(b->d_pos); dev_free(b->d_nrm); dev_free(b->d_mats); dev_free(b->d_tri48);
+    dev_free(b->d_pos); dev_free(b->d_nrm); dev_free(b->d_mats); dev_free(b->d_tri48); dev_free(b->d_tex);
     dev_free(b->d_keys); dev_free(b->d_idx); dev_free(b->d_leafbox); dev_free(b->d_leaftri);
     dev_free(b->d_block); dev_free(b->d_small); dev_free(b->d_opt); dev_free(b->d_seg);
     dev_free(b->d_sorted_tri); dev_free(b->d_pairbox); dev_free(b->d_link); dev_free(b->d_range); dev_free(b->d_node32);
@@ -242,14 +242,15 @@ int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
     int rc = PSM_OK;
     auto A = [&](int r) { if (rc == PSM_OK) rc = r; };
     A(dev_alloc(c, &b->d_pos, 9 * n)); A(dev_alloc(c, &b->d_nrm, 9 * n)); A(dev_alloc(c, &b->d_mats, n));
-    A(dev_alloc(c, &b->d_tri48, 3 * n)); A(dev_alloc(c, &b->d_keys, n)); A(dev_alloc(c, &b->d_idx, n));
+    A(dev_alloc(c, &b->d_tri48, 3 * n)); A(dev_alloc(c, &b->d_tex, 6 * n)); A(dev_alloc(c, &b->d_keys, n)); A(dev_alloc(c, &b->d_idx, n));
     A(dev_alloc(c, &b->d_leafbox, n)); A(dev_alloc(c, &b->d_leaftri, n));
     A(dev_alloc(c, &b->d_block, (n + 255) / 256 + 1)); A(dev_alloc(c, &b->d_small, (size_t)SM_WORDS));
     A(dev_alloc(c, &b->d_opt, (size_t)16)); A(dev_alloc(c, &b->d_seg, off));
     A(dev_alloc(c, &b->d_sorted_tri, n)); A(dev_alloc(c, &b->d_pairbox, 2 * n)); A(dev_alloc(c, &b->d_link, n));
     A(dev_alloc(c, &b->d_range, n)); A(dev_alloc(c, &b->d_node32, 2 * n));
     if (rc != PSM_OK) { psm_bvh_destroy(b); return rc; }
-    if (hipMemsetAsync(b->d_small, 0, SM_WORDS * 4, c->stream) != hipSuccess) { psm_bvh_destroy(b); return PSM_ERR_HIP; }
+    if (hipMemsetAsync(b->d_small, 0, SM_WORDS * 4, c->stream) != hipSuccess ||
+        hipMemsetAsync(b->d_tex, 0, 6 * n * sizeof(float), c->stream) != hipSuccess) { psm_bvh_destroy(b); return PSM_ERR_HIP; }
     *out = b;
     return PSM_OK;
 }
@@ -292,6 +293,17 @@ int psm_bvh_load_triangles(psm_bvh* b, const float* positions, const float* norm
     return launch_bvh_prepare_tris(b, first, (uint32_t)n);
 }
 
+int psm_bvh_set_texcoords(psm_bvh* b, size_t first, const float* uv, size_t n) {
+    if (!b || (n && !uv)) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    if (first + n > b->cap) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_set_texcoords: range exceeds capacity");
+    if (n == 0) return PSM_OK;
+    PSM_HIP(c, hipMemcpyAsync(b->d_tex + 6 * first, uv, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return PSM_OK;
+}
+
 int psm_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d) {
     if (!b || !d) return PSM_ERR_INVALID;
     psm_ctx* c = b->ctx;
@@ -299,6 +311,7 @@ int psm_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d) {
     if (d->node_count <= 0) return PSM_OK;  // TriangleHierarchy.inl:174
     if (!d->d_vertices || !d->accessors || !d->views || d->vertex_accessor < 0 ||
         (uint32_t)d->vertex_accessor >= d->accessor_count || d->normal_accessor >= (int32_t)d->accessor_count ||
+        d->texcoord_accessor >= (int32_t)d->accessor_count ||
         (d->is_indexed && !d->d_indices))
         return set_err(c, PSM_ERR_INVALID, "psm_bvh_load_mesh: bad mesh description");
     for (uint32_t i = 0; i < d->accessor_count; i++)
@@ -405,6 +418,7 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
         case PSM_BVH_POSITIONS: src = b->d_pos; elem = 36; break;
         case PSM_BVH_NORMALS: src = b->d_nrm; elem = 36; break;
         case PSM_BVH_MATERIALS: src = b->d_mats; elem = 4; break;
+        case PSM_BVH_TEXCOORDS: src = b->d_tex; elem = 24; break;
         default: return set_err(c, PSM_ERR_INVALID, "psm_bvh_download: unknown item");
     }
     if (bytes > b->cap * elem) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_download: too many bytes");
@@ -426,7 +440,8 @@ int psm_rt_destroy(psm_rt* r) {
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     rt_free_grid(r);
-    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky);
+    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table);
+    for (int i = 0; i < MAX_TEXTURES; i++) if (r->tex_host[i].texels) (void)hipFree(const_cast<uint32_t*>(r->tex_host[i].texels));
     delete r;
     return PSM_OK;
 }
@@ -439,6 +454,8 @@ int psm_rt_create(psm_ctx* c, psm_rt** out) {
     r->ctx = c;
     int rc = dev_alloc(c, &r->d_cnt, (size_t)8);
     if (rc == PSM_OK) rc = dev_alloc(c, &r->d_lights, (size_t)16);
+    if (rc == PSM_OK) rc = dev_alloc(c, &r->d_tex_table, (size_t)MAX_TEXTURES);
+    if (rc == PSM_OK) r->tex_dirty = true;
     if (rc != PSM_OK) { psm_rt_destroy(r); return rc; }
     (void)hipMemsetAsync(r->d_cnt, 0, 32, c->stream);
     // default sun, Pipeline.inl:93-98
@@ -567,6 +584,24 @@ int psm_rt_set_sky(psm_rt* r, const float rgba[4]) {
     return PSM_OK;
 }
 
+int psm_rt_set_texture(psm_rt* r, uint32_t slot, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!r || slot == 0 || slot >= (uint32_t)MAX_TEXTURES) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (r->tex_host[slot].texels) (void)hipFree(const_cast<uint32_t*>(r->tex_host[slot].texels));
+    r->tex_host[slot] = TexDesc{nullptr, 0, 0};
+    r->tex_dirty = true;
+    if (!rgba8 || width == 0 || height == 0) return PSM_OK;
+    uint32_t* d = nullptr;
+    int rc = dev_alloc(c, &d, (size_t)width * height);
+    if (rc != PSM_OK) return rc;
+    PSM_HIP(c, hipMemcpyAsync(d, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    r->tex_host[slot] = TexDesc{d, (int)width, (int)height};
+    return PSM_OK;
+}
+
 int psm_rt_set_skybox(psm_rt* r, const uint8_t* rgba8, uint32_t width, uint32_t height) {
     if (!r) return PSM_ERR_INVALID;
     psm_ctx* c = r->ctx;
@@ -635,6 +670,11 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
 int psm_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     if (!r || !b) return PSM_ERR_INVALID;
     (void)hipSetDevice(r->ctx->device);
+    if (r->tex_dirty) {
+        PSM_HIP(r->ctx, hipMemcpyAsync(r->d_tex_table, r->tex_host, sizeof(r->tex_host), hipMemcpyHostToDevice, r->ctx->stream));
+        PSM_HIP(r->ctx, hipStreamSynchronize(r->ctx->stream));
+        r->tex_dirty = false;
+    }
     if (!r->d_mats) return set_err(r->ctx, PSM_ERR_STATE, "shade before set_materials");
     int32_t n;
     int rc = psm_rt_ray_count(r, &n);

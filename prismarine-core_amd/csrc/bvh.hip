@@ -25,7 +25,6 @@ constexpr int SM_COUNT = 24;   // leaf count
 constexpr int SM_ROOT = 25;    // root link
 constexpr int SM_BFLOAT = 26;  // 8 floats: bounds after the -+1e-5 pad
 constexpr int SM_M0 = 34;      // 16 floats: first-pass transform inverse(opt)
-constexpr int SM_WORDS = 64;
 
 PSM_D int32_t float_to_ordered(float f) {
     int32_t i = (int32_t)f2u(f);
@@ -134,7 +133,7 @@ struct MeshArgs {
     uint32_t index_words;
     const psm_accessor* accessors;
     const psm_buffer_view* views;
-    int vertexAccessor, normalAccessor;
+    int vertexAccessor, normalAccessor, texcoordAccessor;
     float T[16], Ti[16];
     int materialID, isIndexed, index16, nodeCount, primitiveType, loadingOffset;
     uint32_t storingOffset;
@@ -152,11 +151,13 @@ PSM_D void read_by_accessor(const MeshArgs& a, int accessorID, uint32_t idx, flo
 }
 
 __global__ __launch_bounds__(128) void bvh_load_mesh(MeshArgs a, float* __restrict__ pos, float* __restrict__ nrm,
-                                                     int32_t* __restrict__ mats, float4* __restrict__ tri48) {
+                                                     int32_t* __restrict__ mats, float4* __restrict__ tri48,
+                                                     float* __restrict__ tex) {
     int ct = blockIdx.x * 128 + threadIdx.x;
     if (ct >= a.nodeCount) return;
     int trp = a.primitiveType == 1 ? 4 : 3;
     v3 vertice[4], normal[4];
+    float tu[4] = {0.f, 0.f, 0.f, 0.f}, tv[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < trp; i++) {
         uint32_t ptri = (uint32_t)a.loadingOffset + (uint32_t)(ct * trp + i);
         uint32_t vi = ptri;
@@ -167,6 +168,8 @@ __global__ __launch_bounds__(128) void bvh_load_mesh(MeshArgs a, float* __restri
         float p[4], n[4] = {0.f, 0.f, 0.f, 0.f};
         read_by_accessor(a, a.vertexAccessor, vi, p);
         if (a.normalAccessor != -1) read_by_accessor(a, a.normalAccessor, vi, n);
+        if (a.texcoordAccessor != -1) { float t4[4]; read_by_accessor(a, a.texcoordAccessor, vi, t4); tu[i] = t4[0]; tv[i] = t4[1]; }  // :94-96
+        tv[i] = 1.0f - tv[i];  // INVERT_TX_Y, loader.comp:97-99 (set by build-spv-new.bat:31-32)
         float po[4], no[4];
         mat_vec(a.T, p[0], p[1], p[2], 1.0f, po);     // mult4(meshUniform.transform, vec4(vpos, 1)), :101
         matT_vec(a.Ti, n[0], n[1], n[2], 0.0f, no);   // mult4(meshUniform.transformInv, vec4(vnorm, 0)), :100
@@ -189,6 +192,8 @@ __global__ __launch_bounds__(128) void bvh_load_mesh(MeshArgs a, float* __restri
             float* np = nrm + (size_t)9 * tidc + 3 * i;
             pp[0] = vv[i].x; pp[1] = vv[i].y; pp[2] = vv[i].z;
             np[0] = use.x; np[1] = use.y; np[2] = use.z;
+            tex[(size_t)6 * tidc + 2 * i] = tu[m[i]];
+            tex[(size_t)6 * tidc + 2 * i + 1] = tv[m[i]];
         }
         tri48[(size_t)3 * tidc + 0] = make_float4(vv[0].x, vv[0].y, vv[0].z, 1.0f);
         tri48[(size_t)3 * tidc + 1] = make_float4(vv[1].x - vv[0].x, vv[1].y - vv[0].y, vv[1].z - vv[0].z, 0.0f);
@@ -201,12 +206,12 @@ int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor*
     a.iverts = d->d_vertices; a.vertex_floats = (uint32_t)d->vertex_floats;
     a.vindics = d->d_indices; a.index_words = (uint32_t)d->index_words;
     a.accessors = d_acc; a.views = d_views;
-    a.vertexAccessor = d->vertex_accessor; a.normalAccessor = d->normal_accessor;
+    a.vertexAccessor = d->vertex_accessor; a.normalAccessor = d->normal_accessor; a.texcoordAccessor = d->texcoord_accessor;
     for (int i = 0; i < 16; i++) { a.T[i] = d->transform[i]; a.Ti[i] = d->transform_inv[i]; }
     a.materialID = d->material_id; a.isIndexed = d->is_indexed; a.index16 = d->index16; a.nodeCount = d->node_count;
     a.primitiveType = d->primitive_type; a.loadingOffset = d->loading_offset;
     a.storingOffset = b->tri_count;
-    bvh_load_mesh<<<(d->node_count + 127) / 128, 128, 0, b->ctx->stream>>>(a, b->d_pos, b->d_nrm, b->d_mats, b->d_tri48);
+    bvh_load_mesh<<<(d->node_count + 127) / 128, 128, 0, b->ctx->stream>>>(a, b->d_pos, b->d_nrm, b->d_mats, b->d_tri48, b->d_tex);
     PSM_HIP(b->ctx, hipGetLastError());
     return PSM_OK;
 }

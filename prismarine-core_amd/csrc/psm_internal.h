@@ -10,6 +10,12 @@
 
 namespace psm {
 
+struct TexDesc {
+    const uint32_t* texels;  // RGBA8, one texel per word, row 0 first
+    int w, h;
+};
+constexpr int MAX_TEXTURES = 32;  // surface.comp:46
+
 enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_COUNT };
 
 // device-resident counters (one block per context)
@@ -58,6 +64,7 @@ struct psm_bvh {
     float* d_pos = nullptr;       // 9 floats / triangle
     float* d_nrm = nullptr;       // 9 floats / triangle
     int32_t* d_mats = nullptr;    // material id / triangle
+    float* d_tex = nullptr;       // 6 floats / triangle: u,v per vertex
     float4* d_tri48 = nullptr;    // v0, e1, e2 (xyz, w unused) / triangle -- traversal layout
     uint64_t* d_keys = nullptr;   // Morton codes, slot order then sorted in place
     uint32_t* d_idx = nullptr;    // MortonIndices
@@ -110,6 +117,9 @@ struct psm_rt {
     uint32_t mat_count = 0;
     int32_t mat_offset = 0;
     float sky[4] = {0.5f, 0.7f, 1.0f, 1.0f};
+    psm::TexDesc tex_host[psm::MAX_TEXTURES] = {};
+    psm::TexDesc* d_tex_table = nullptr;
+    bool tex_dirty = false;
     uint32_t* d_sky = nullptr;    // equirect RGBA8 skybox (one texel per word) or null
     uint32_t sky_w = 0, sky_h = 0;
     int samples_lock = 4;         // SAMPLES_LOCK, constants.glsl:35

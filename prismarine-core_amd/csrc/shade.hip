@@ -130,16 +130,54 @@ PSM_D void unpack4(uint32_t lo, uint32_t hi, float* o) {
     o[0] = half_lo(lo); o[1] = half_hi(lo); o[2] = half_lo(hi); o[3] = half_hi(hi);
 }
 
-PSM_D Surf surface_eval(float4 hit, const float4* __restrict__ tri48, const float* __restrict__ nrm,
-                        const int32_t* __restrict__ tri_mats, const psm_material* __restrict__ mats,
-                        int mat_offset, int mat_count) {
+struct SurfSrc {
+    const float4* tri48;
+    const float* nrm;
+    const int32_t* tri_mats;
+    const psm_material* mats;
+    const float* uv;       // 6 floats / triangle
+    const TexDesc* tex;    // MAX_TEXTURES slots
+    int mat_offset, mat_count;
+};
+
+// validateTexture, surface.comp:81-83
+PSM_D bool valid_tex(const TexDesc* __restrict__ tex, uint32_t binding) {
+    return binding != 0u && binding != 0xFFFFFFFFu && binding < (uint32_t)MAX_TEXTURES && tex[binding].w > 0;
+}
+
+// fetchTexture, surface.comp:85-95: RGBA8 unorm, GL_LINEAR, GL_REPEAT (TextureSet.inl:113-118), fp32 weights;
+// NaN/Inf results read as 0 (a non-finite coordinate therefore reads 0)
+PSM_D void fetch_tex(const TexDesc t, float u, float v, int ox, int oy, float* o) {
+    float uu = u + (float)ox / (float)t.w, vv = v + (float)oy / (float)t.h;
+    if (!(pabs(uu) < INF) || !(pabs(vv) < INF)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    uu = uu - floorf(uu); vv = vv - floorf(vv);
+    float x = uu * (float)t.w - 0.5f, y = vv * (float)t.h - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float a = x - fx, b = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? x0 + t.w : x0; y0 = y0 < 0 ? y0 + t.h : y0;
+    x1 = x1 >= t.w ? x1 - t.w : x1; y1 = y1 >= t.h ? y1 - t.h : y1;
+    x0 = x0 >= t.w ? x0 - t.w : x0; y0 = y0 >= t.h ? y0 - t.h : y0;  // fract() rounding up to 1.0
+    uint32_t p00 = t.texels[y0 * t.w + x0], p10 = t.texels[y0 * t.w + x1];
+    uint32_t p01 = t.texels[y1 * t.w + x0], p11 = t.texels[y1 * t.w + x1];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float t00 = (float)((p00 >> (8 * c)) & 255u) / 255.0f, t10 = (float)((p10 >> (8 * c)) & 255u) / 255.0f;
+        float t01 = (float)((p01 >> (8 * c)) & 255u) / 255.0f, t11 = (float)((p11 >> (8 * c)) & 255u) / 255.0f;
+        float top = t00 * (1.0f - a) + t10 * a, bot = t01 * (1.0f - a) + t11 * a;
+        o[c] = top * (1.0f - b) + bot * b;
+    }
+}
+
+template <bool TEX>
+PSM_D Surf surface_eval(float4 hit, const SurfSrc& src) {
     Surf s;
     int tri = __float_as_int(hit.w);
     float u = hit.x, v = hit.y;
     s.t = hit.z;
-    float4 b = tri48[(size_t)3 * tri + 1], c = tri48[(size_t)3 * tri + 2];
+    float4 b = src.tri48[(size_t)3 * tri + 1], c = src.tri48[(size_t)3 * tri + 2];
     v3 d1 = mk3(b.x, b.y, b.z), d2 = mk3(c.x, c.y, c.z);
-    const float* n = nrm + (size_t)9 * tri;
+    const float* n = src.nrm + (size_t)9 * tri;
     float vs0 = (1.0f - u) - v, vs1 = u, vs2 = v;
     v3 nor = normalize3(cross3(d1, d2));
     v3 nn = mk3((vs0 * n[0] + vs1 * n[3]) + vs2 * n[6], (vs0 * n[1] + vs1 * n[4]) + vs2 * n[7],
@@ -149,16 +187,63 @@ PSM_D Surf surface_eval(float4 hit, const float4* __restrict__ tri48, const floa
     nn = nn * sg;
     s.normal_trav = nn;
     s.normal = normalize3(normalize3(nn));  // surface.comp:176-186 with no normal map
-    int matID = tri_mats[tri] - mat_offset;
-    s.active = !(matID >= mat_count || matID < 0);
+    int matID = src.tri_mats[tri] - src.mat_offset;
+    s.active = !(matID >= src.mat_count || matID < 0);
 #pragma unroll
     for (int k = 0; k < 4; k++) { s.albedo[k] = 0.f; s.emission[k] = 0.f; s.mr[k] = 0.f; }
     if (s.active) {
-        const psm_material* m = mats + matID;
-        float d0 = pmax(m->diffuse[0], 0.f), dd1 = pmax(m->diffuse[1], 0.f), dd2 = pmax(m->diffuse[2], 0.f);
-        unpack4(pack_half2(d0, dd1), pack_half2(dd2, 1.0f), s.albedo);
-        unpack4(pack_half2(0.f * 2.f, 0.f * 2.f), pack_half2(0.f * 2.f, 1.0f), s.emission);
-        unpack4(pack_half2(m->specular[1], m->specular[2]), pack_half2(0.f, 0.f), s.mr);
+        const psm_material* m = src.mats + matID;
+        float diff[4] = {pmax(m->diffuse[0], 0.f), pmax(m->diffuse[1], 0.f), pmax(m->diffuse[2], 0.f), 1.0f};
+        float emis[4] = {0.f, 0.f, 0.f, 0.f};
+        float spc[4] = {m->specular[0], m->specular[1], m->specular[2], m->specular[3]};
+        if (TEX) {
+        const float* tc = src.uv + (size_t)6 * tri;
+        float tu = (vs0 * tc[0] + vs1 * tc[2]) + vs2 * tc[4], tv = (vs0 * tc[1] + vs1 * tc[3]) + vs2 * tc[5];
+        if (valid_tex(src.tex, m->diffusePart)) fetch_tex(src.tex[m->diffusePart], tu, tv, 0, 0, diff);     // :155-161
+        if (valid_tex(src.tex, m->emissivePart)) fetch_tex(src.tex[m->emissivePart], tu, tv, 0, 0, emis);   // :110-116
+        if (valid_tex(src.tex, m->specularPart)) fetch_tex(src.tex[m->specularPart], tu, tv, 0, 0, spc);    // :102-108
+        if (valid_tex(src.tex, m->bumpPart)) {
+            const TexDesc bt = src.tex[m->bumpPart];
+            // tangent, directTraverse.comp:190-209
+            float du1 = tc[2] - tc[0], du2 = tc[4] - tc[0];
+            float dv1 = tc[3] - tc[1], dv2 = tc[5] - tc[1];
+            float e0x = du1, e0y = du2, e1x = dv2, e1y = dv1 * -1.0f;
+            if (pabs(e0x) < 0.000001f && pabs(e0y) < 0.000001f) { e0x = 1.f; e0y = 0.f; }
+            if (pabs(e1x) < 0.000001f && pabs(e1y) < 0.000001f) { e1x = 1.f; e1y = 0.f; }
+            float f = 1.f / (e0x * e1x + e0y * e1y);
+            if (isnan(f)) f = 0.f;
+            if (isinf(f)) f = 10000.f;
+            v3 tang = mk3(fmaf(e1x, d1.x, e1y * d2.x) * f, fmaf(e1x, d1.y, e1y * d2.y) * f, fmaf(e1x, d1.z, e1y * d2.z) * f);
+            float ts = psign(dot3(tang, nor));
+            v3 tangent = normalize3(tang - nn * ts);
+            // getNormalMapping, surface.comp:138-153
+            float nm4[4];
+            fetch_tex(bt, tu, tv, 0, 0, nm4);
+            v3 nm;
+            if (equalF(nm4[0], nm4[1]) && equalF(nm4[0], nm4[2])) {  // grey: a height map
+                float h00[4], h01[4], h10[4];
+                fetch_tex(bt, tu, tv, 0, 0, h00);
+                fetch_tex(bt, tu, tv, 1, 0, h01);
+                fetch_tex(bt, tu, tv, 0, 1, h10);
+                float z0 = h00[0] * 2.0f, z1 = h01[0] * 2.0f, z2 = h10[0] * 2.0f;
+                nm = normalize3(cross3(mk3(1.0f - 0.0f, 0.0f - 0.0f, z1 - z0), mk3(0.0f - 0.0f, 1.0f - 0.0f, z2 - z0)));
+            } else {
+                nm = normalize3(mk3(mixf(0.f, fmaf(nm4[0], 2.0f, -1.0f), 1.0f), mixf(0.f, fmaf(nm4[1], 2.0f, -1.0f), 1.0f),
+                                    mixf(1.f, fmaf(nm4[2], 2.0f, -1.0f), 1.0f)));
+            }
+            // surface.comp:176-186
+            v3 normal_s = normalize3(nn);
+            v3 tangent_s = normalize3(tangent);
+            v3 bitangent = normalize3(cross3(normal_s, tangent_s));
+            v3 w = normalize3(nm);
+            s.normal = normalize3(mk3((tangent_s.x * w.x + bitangent.x * w.y) + normal_s.x * w.z,
+                                      (tangent_s.y * w.x + bitangent.y * w.y) + normal_s.y * w.z,
+                                      (tangent_s.z * w.x + bitangent.z * w.y) + normal_s.z * w.z));
+        }
+        }  // TEX
+        unpack4(pack_half2(diff[0], diff[1]), pack_half2(diff[2], diff[3]), s.albedo);
+        unpack4(pack_half2(emis[0] * 2.f, emis[1] * 2.f), pack_half2(emis[2] * 2.f, 1.0f), s.emission);
+        unpack4(pack_half2(spc[1], spc[2]), pack_half2(0.f, 0.f), s.mr);
     }
     return s;
 }
@@ -279,10 +364,7 @@ struct ShadeArgs {
     const float4* hit0;
     const uint32_t* hitN;
     const float4* pool;
-    const float4* tri48;
-    const float* nrm;
-    const int32_t* tri_mats;
-    const psm_material* mats;
+    SurfSrc src;
     const psm_light* lights;
     float4 *sA, *sB, *sC;
     uint32_t* blockCounts;
@@ -290,13 +372,16 @@ struct ShadeArgs {
     int32_t* t_flag;
     uint32_t nrays;
     uint32_t time;
-    int mat_offset, mat_count, light_count;
+    int light_count;
     float sky[3];
     const uint32_t* sky_tex;
     int sky_w, sky_h;
 };
 
 // surface.comp + rayshading.comp:48-278
+// TEX = false is the same kernel with the sampler table known to be empty (validateTexture fails for every
+// part): the texture-less frame keeps its registers and occupancy
+template <bool TEX>
 __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     __shared__ uint32_t scan_tmp[8];
     uint32_t it = blockIdx.x * SHADE_BLOCK + threadIdx.x;
@@ -322,30 +407,22 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
         float uvt_t = INF;
         float c_albedo[4] = {0, 0, 0, 0}, c_emission[4] = {0, 0, 0, 0}, c_mr[4] = {0, 0, 0, 0};
         v3 c_normal = mk3(0, 0, 0);
-        int next = -1;
-        if (n > 0) {
-            int k = 0;
-            Surf s = surface_eval(a.hit0[it], a.tri48, a.nrm, a.tri_mats, a.mats, a.mat_offset, a.mat_count);
-            while (!s.active && k + 1 < n) {
-                k++;
-                s = surface_eval(a.pool[poff + k - 1], a.tri48, a.nrm, a.tri_mats, a.mats, a.mat_offset, a.mat_count);
-            }
-            uvt_t = s.t;
-            if (!s.active) {
-                c_normal = s.normal_trav;
-                next = -1;
-            } else {
+        // one walk over the chain: the first active hit seeds the composite (:60-86), the hits at the same
+        // distance behind it are blended in (:88-116)
+        bool found = false;
+        for (int k = 0; k < n; k++) {
+            Surf h = surface_eval<TEX>(k == 0 ? a.hit0[it] : a.pool[poff + k - 1], a.src);
+            if (!found) {
+                uvt_t = h.t;
+                if (!h.active) { c_normal = h.normal_trav; continue; }
+                found = true;
 #pragma unroll
-                for (int c = 0; c < 4; c++) { c_albedo[c] = s.albedo[c]; c_emission[c] = s.emission[c]; c_mr[c] = s.mr[c]; }
-                c_normal = s.normal;
-                next = (k + 1 < n) ? k + 1 : -1;
+                for (int c = 0; c < 4; c++) { c_albedo[c] = h.albedo[c]; c_emission[c] = h.emission[c]; c_mr[c] = h.mr[c]; }
+                c_normal = h.normal;
+                continue;
             }
-        }
-        for (int i = 0; i < 8; i++) {
-            if (next == -1) break;
-            Surf h = surface_eval(a.pool[poff + next - 1], a.tri48, a.nrm, a.tri_mats, a.mats, a.mat_offset, a.mat_count);
             if (!equalF(uvt_t, h.t)) break;
-            if (!h.active) { next = (next + 1 < n) ? next + 1 : -1; continue; }
+            if (!h.active) continue;
             // composite(), rayshading.comp:25-28
             float oa = c_albedo[3] + h.albedo[3] * (1.0f - c_albedo[3]);
             float den = pmax(oa, 0.00001f);
@@ -362,7 +439,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; c++) { c_mr[c] = mixf(c_mr[c], h.mr[c], aw); c_emission[c] = mixf(c_emission[c], h.emission[c], aw); }
             if (c_albedo[3] > 0.99999f) break;
-            next = (next + 1 < n) ? next + 1 : -1;
         }
 
         // physical lights, :119-138
@@ -699,19 +775,22 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     ShadeArgs a;
     a.qA = r->qA[r->cur]; a.qB = r->qB[r->cur]; a.qC = r->qC[r->cur];
     a.hit0 = r->hit0; a.hitN = r->hitN; a.pool = r->pool;
-    a.tri48 = b->d_tri48; a.nrm = b->d_nrm; a.tri_mats = b->d_mats;
-    a.mats = r->d_mats; a.lights = r->d_lights;
+    a.src.tri48 = b->d_tri48; a.src.nrm = b->d_nrm; a.src.tri_mats = b->d_mats; a.src.uv = b->d_tex;
+    a.src.mats = r->d_mats; a.src.tex = r->d_tex_table; a.lights = r->d_lights;
     a.sA = r->sA; a.sB = r->sB; a.sC = r->sC;
     a.blockCounts = r->d_block;
     a.t_sum = r->t_sum; a.t_flag = r->t_flag;
     a.nrays = n; a.time = time;
-    a.mat_offset = r->mat_offset; a.mat_count = (int)r->mat_count; a.light_count = (int)r->light_count;
+    a.src.mat_offset = r->mat_offset; a.src.mat_count = (int)r->mat_count; a.light_count = (int)r->light_count;
     a.sky[0] = r->sky[0]; a.sky[1] = r->sky[1]; a.sky[2] = r->sky[2];
     a.sky_tex = r->d_sky; a.sky_w = (int)r->sky_w; a.sky_h = (int)r->sky_h;
     int nxt = r->cur ^ 1;
     {
         TimedScope ts(c, CAT_SHADE);
-        rt_shade<<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        bool any_tex = false;
+        for (int i = 1; i < MAX_TEXTURES; i++) any_tex = any_tex || r->tex_host[i].texels != nullptr;
+        if (any_tex) rt_shade<true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else rt_shade<false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->d_cnt, c->d_counters);
         rt_compact<<<nb, SHADE_BLOCK, 0, c->stream>>>(r->sA, r->sB, r->sC, r->d_block, nb, r->limit, r->qA[nxt], r->qB[nxt],
                                                       r->qC[nxt]);

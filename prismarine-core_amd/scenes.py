@@ -408,7 +408,69 @@ def materials_array(materials):
         a[i]["emissive"] = m["emissive"]
         a[i]["ior"] = 1.0
         a[i]["roughness"] = 0.0001
+        for part in ("diffusePart", "specularPart", "bumpPart", "emissivePart"):
+            a[i][part] = m.get(part, 0)
     return a
+
+
+# ---------------------------------------------------------------------------
+# procedural textures + planar texcoords (no image files travel with the repo)
+# ---------------------------------------------------------------------------
+
+def planar_texcoords(tris, scale=1.5):
+    """Box-projected u,v per vertex [n,3,2]: drop the face normal's dominant axis (keeps both signs and
+    values outside [0,1) so GL_REPEAT is exercised)."""
+    t = np.asarray(tris, np.float32).reshape(-1, 3, 3)
+    n = np.cross((t[:, 1] - t[:, 0]).astype(np.float64), (t[:, 2] - t[:, 0]).astype(np.float64))
+    ax = np.argmax(np.abs(n), 1)
+    ua = np.where(ax == 0, 1, 0)
+    va = np.where(ax == 2, 1, 2)
+    idx = np.arange(t.shape[0])
+    uv = np.stack([t[idx, :, ua], t[idx, :, va]], -1)
+    return (uv * np.float32(scale)).astype(np.float32)
+
+
+def procedural_textures():
+    """{slot: uint8 [h,w,4]}: 1 colour checker with alpha, 2 tangent-space normal map, 3 emissive spots,
+    4 roughness/metallic map (.y/.z, surface.comp:189), 5 grey height map (surface.comp:141-148)."""
+    def grid(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        return (x + 0.5) / w, (y + 0.5) / h
+    out = {}
+    u, v = grid(64, 32)
+    chk = ((np.floor(u * 8) + np.floor(v * 4)) % 2)
+    out[1] = np.stack([0.25 + 0.6 * chk, 0.3 + 0.5 * u, 0.8 - 0.5 * v, 0.55 + 0.45 * chk], -1)
+    u, v = grid(32, 32)
+    nx, ny = 0.45 * np.sin(2 * np.pi * u * 3), 0.45 * np.cos(2 * np.pi * v * 2)
+    nz = np.sqrt(np.maximum(1 - nx * nx - ny * ny, 0))
+    out[2] = np.stack([0.5 + 0.5 * nx, 0.5 + 0.5 * ny, 0.5 + 0.5 * nz, np.ones_like(nx)], -1)
+    u, v = grid(16, 16)
+    spot = (((u - 0.5) ** 2 + (v - 0.5) ** 2) < 0.09).astype(np.float64)
+    out[3] = np.stack([spot, 0.8 * spot, 0.5 * spot, np.ones_like(spot)], -1)
+    u, v = grid(8, 24)
+    out[4] = np.stack([np.zeros_like(u), 0.2 + 0.7 * v, 0.9 * (u > 0.5), np.ones_like(u)], -1)
+    u, v = grid(48, 40)
+    hgt = 0.5 + 0.5 * np.sin(2 * np.pi * u * 2) * np.sin(2 * np.pi * v * 3)
+    out[5] = np.stack([hgt, hgt, hgt, np.ones_like(hgt)], -1)
+    return {k: np.ascontiguousarray(np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)) for k, a in out.items()}
+
+
+def textured(scene, scale=1.5):
+    """A copy of `scene` with box-projected texcoords, the procedural texture table and texture parts spread
+    over its materials (every combination of diffuse / specular / bump / emissive part occurs)."""
+    sc = dict(scene)
+    sc["texcoords"] = planar_texcoords(scene["tris"], scale)
+    sc["textures"] = procedural_textures()
+    combos = [{"diffusePart": 1, "bumpPart": 2}, {"bumpPart": 5, "specularPart": 4},
+              {"diffusePart": 1, "emissivePart": 3}, {"specularPart": 4, "bumpPart": 2, "emissivePart": 3}]
+    mats = []
+    for i, m in enumerate(scene["materials"]):
+        mm = dict(m)
+        mm.update(combos[i % len(combos)])
+        mats.append(mm)
+    sc["materials"] = mats
+    sc["name"] = scene["name"] + "+tex"
+    return sc
 
 
 # ---------------------------------------------------------------------------
@@ -452,24 +514,32 @@ def camera_matrices(eye, view, width, height):
 # glTF-style mesh descriptions (accessors / buffer views), the input of loadMesh
 # ---------------------------------------------------------------------------
 
-def make_indexed_mesh(tris, normals=None, interleaved=True, index16=False, quads=False, transform=None, material_id=0):
+def make_indexed_mesh(tris, normals=None, interleaved=True, index16=False, quads=False, transform=None, material_id=0,
+                      texcoords=None):
     """Turn a triangle soup into an indexed, accessor-described mesh (welds identical vertices).
     interleaved: one buffer view with stride 6 holding position|normal per vertex; else two planar views.
     quads: pair consecutive triangles (a,b,c),(d,a,c) into 4-index primitives where possible (tests only)."""
     tris = np.asarray(tris, np.float32).reshape(-1, 3, 3)
     n = tris.shape[0]
     nr = np.zeros_like(tris) if normals is None else np.asarray(normals, np.float32).reshape(-1, 3, 3)
-    rec = np.concatenate([tris.reshape(-1, 3), nr.reshape(-1, 3)], 1)
+    cols = [tris.reshape(-1, 3), nr.reshape(-1, 3)]
+    if texcoords is not None:
+        cols.append(np.asarray(texcoords, np.float32).reshape(-1, 2))
+    rec = np.concatenate(cols, 1)
     uniq, inv = np.unique(rec, axis=0, return_inverse=True)
     inv = inv.reshape(-1).astype(np.uint32)
+    w = rec.shape[1]
     if interleaved:
         verts = uniq.reshape(-1).astype(np.float32)
-        views = [(0, 6)]
-        accessors = [(0, 2, 0), (3, 2, 0)]
+        views = [(0, w)]
+        accessors = [(0, 2, 0), (3, 2, 0)] + ([(6, 1, 0)] if texcoords is not None else [])
     else:
-        verts = np.concatenate([uniq[:, :3].reshape(-1), uniq[:, 3:].reshape(-1)]).astype(np.float32)
+        verts = np.concatenate([uniq[:, :3].reshape(-1), uniq[:, 3:6].reshape(-1), uniq[:, 6:].reshape(-1)]).astype(np.float32)
         views = [(0, 3), (uniq.shape[0] * 3, 0)]  # stride 0 -> components + 1
         accessors = [(0, 2, 0), (0, 2, 1)]
+        if texcoords is not None:
+            views.append((uniq.shape[0] * 6, 0))
+            accessors.append((0, 1, 2))
     node_count, prim = n, 0
     idx = inv
     if quads:
@@ -485,6 +555,6 @@ def make_indexed_mesh(tris, normals=None, interleaved=True, index16=False, quads
     t = np.eye(4, dtype=np.float32) if transform is None else np.asarray(transform, np.float32).reshape(4, 4)
     ti = np.linalg.inv(t.astype(np.float64)).astype(np.float32)
     return {"vertices": verts, "indices": idx, "accessors": accessors, "views": views, "vertex_accessor": 0,
-            "normal_accessor": -1 if normals is None else 1, "transform": t.reshape(16), "transform_inv": ti.reshape(16),
+            "normal_accessor": -1 if normals is None else 1, "texcoord_accessor": -1 if texcoords is None else 2, "transform": t.reshape(16), "transform_inv": ti.reshape(16),
             "material_id": material_id, "index16": int(index16), "node_count": node_count, "primitive_type": prim,
             "loading_offset": 0}

@@ -15,11 +15,13 @@ pytestmark = pytest.mark.gpu
 def _load(psm, ctx, scene):
     th = psm.TriangleHierarchy(ctx)
     th.allocate(scene["tris"].shape[0])
-    th.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+    th.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
     return th
 
 
 def _scene(scenes, name):
+    if name.endswith("+tex"):
+        return scenes.textured(_scene(scenes, name[:-4]))
     if name == "cornell":
         return scenes.cornell()
     if name == "cornell_open":
@@ -138,6 +140,11 @@ def _setup_frame(psm, ctx, scenes, scene, w, h):
     ms = psm.MaterialSet()
     for m in scene["materials"]:
         ms.addSubmat(m)
+    if scene.get("textures"):
+        ts = psm.TextureSet()
+        for slot in sorted(scene["textures"]):
+            assert ts.loadTexture(scene["textures"][slot]) == slot
+        ms.setTextureSet(ts)
     cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
     return th, rt, ms, cam
 
@@ -223,13 +230,17 @@ def test_traverse_random_rays_with_chains(psm, ctx, oracle, scenes):
 
 
 # ---------------------------------------------------------------------------- shade + full frames
-@pytest.mark.parametrize("name,w,h", [("cornell_open", 96, 96), ("sponza_small", 160, 90)])
+@pytest.mark.parametrize("name,w,h", [("cornell_open", 96, 96), ("sponza_small", 160, 90),
+                                      ("cornell_open+tex", 96, 96), ("sponza_small+tex", 160, 90)])
 def test_shade_rounds_bit_exact_queues(psm, ctx, oracle, scenes, name, w, h):
+    """+tex: SURVEY f2 -- texcoords, the sampler table and every texture part of surface.comp:100-161."""
     scene = _scene(scenes, name)
     th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
     ob = oracle.build_scene(scene["tris"])
     mats = scenes.materials_array(scene["materials"])
     cfg = oracle.make_cfg(w, h, material_count=len(mats))
+    if scene.get("textures"):
+        oracle.set_textures(cfg, scene["texcoords"], scene["textures"])
     lights = oracle.default_lights(1)
     rt.camera_matrices(cam[0], cam[1], time=99)
     orays, ocoord, osum, oflag = oracle.camera(cfg, cam[0], cam[1], 99)
@@ -255,7 +266,8 @@ def test_shade_rounds_bit_exact_queues(psm, ctx, oracle, scenes, name, w, h):
     th.close()
 
 
-@pytest.mark.parametrize("name,w,h,frames", [("cornell_open", 64, 64, 3), ("sponza_small", 128, 72, 2)])
+@pytest.mark.parametrize("name,w,h,frames", [("cornell_open", 64, 64, 3), ("sponza_small", 128, 72, 2),
+                                             ("cornell_open+tex", 64, 64, 3), ("sponza_small+tex", 128, 72, 2)])
 def test_accumulated_radiance(psm, ctx, oracle, scenes, name, w, h, frames):
     """Viewer.cpp:296-312 call order, several frames; accumulated radiance within 1e-4 relative."""
     scene = _scene(scenes, name)
@@ -410,6 +422,57 @@ def test_load_mesh_matches_oracle(psm, ctx, oracle, scenes, kw):
         assert np.array_equal(th2.download(psm.BVH_KEYS, np.uint64, ob["count"]), ob["keys"])
         th2.close()
     th.close()
+
+
+def test_textures_change_the_image_and_slots_can_be_freed(psm, ctx, oracle, scenes):
+    """TextureSet slot reuse (TextureSet.inl:42-86): freeing the bump + emissive textures falls back to the
+    untextured branches of surface.comp; an unknown / empty slot is ignored (validateTexture, :81-83)."""
+    scene = _scene(scenes, "cornell_open+tex")
+    w, h = 48, 40
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+
+    def frame():
+        rt.setSeed(5)
+        rt.clearSampler()
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+        return rt.snapHdr()
+
+    img_all = frame()
+    ref_all, _ = oracle.render_frames(scene, w, h, frames=1, seed=5)
+    np.testing.assert_allclose(img_all[..., :3], ref_all[..., :3], rtol=1e-4, atol=1e-5)
+    ms.texset.freeTexture(2)
+    ms.texset.freeTexture(3)
+    img_less = frame()
+    less = dict(scene)
+    less["textures"] = {k: v for k, v in scene["textures"].items() if k not in (2, 3)}
+    ref_less, _ = oracle.render_frames(less, w, h, frames=1, seed=5)
+    np.testing.assert_allclose(img_less[..., :3], ref_less[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.abs(ref_less[..., :3] - ref_all[..., :3]).max() > 0.05
+    plain, _ = oracle.render_frames(scenes.cornell(open_top=True), w, h, frames=1, seed=5)
+    assert np.abs(plain[..., :3] - ref_all[..., :3]).max() > 0.05
+    # a freed slot is reused by the next texture (TextureSet.inl:76-80)
+    assert ms.texset.loadTexture(scene["textures"][3]) == 3
+    rt.close()
+    th.close()
+
+
+def test_load_mesh_texcoord_accessor(psm, ctx, oracle, scenes):
+    """loader.comp:94-99: texcoords read through their accessor, v stored as 1 - v (INVERT_TX_Y)."""
+    sc = scenes.sponza_like(n_tris=3000)
+    tc = scenes.planar_texcoords(sc["tris"], 0.7)
+    for kw in ({}, {"interleaved": False}, {"quads": True}):
+        mesh = scenes.make_indexed_mesh(sc["tris"], sc["normals"], texcoords=tc, **kw)
+        opos, onrm, omats, otex = oracle.load_mesh(mesh, with_tex=True)
+        if not kw:
+            assert np.array_equal(bits(otex), bits((np.float32([0, 1]) + np.float32([1, -1]) * tc).reshape(-1, 6)))
+        th = psm.TriangleHierarchy(ctx)
+        th.allocate(opos.shape[0])
+        th.loadMesh(mesh)
+        n = opos.shape[0]
+        gt = th.download(psm.BVH_TEXCOORDS, np.float32, 6 * n).reshape(n, 6)
+        assert np.array_equal(bits(gt), bits(otex)), kw
+        assert np.array_equal(bits(th.download(psm.BVH_POSITIONS, np.float32, 9 * n).reshape(n, 9)), bits(opos))
+        th.close()
 
 
 def _sky_image(w=64, h=32):
