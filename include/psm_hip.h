@@ -201,8 +201,15 @@ int psm_rt_camera(psm_rt* rt, const float cam_inv[16], const float proj_inv[16],
 /* raycountCache after reloadQueuedRays, Pipeline.inl:325-359 (the >=32 rule of getRayCount,
  * :459-461, is applied by the header layer). Synchronises. */
 int psm_rt_ray_count(psm_rt* rt, int32_t* count);
-/* intersection(obj), Pipeline.inl:385-405 -> directTraverse.comp */
+/* intersection(obj), Pipeline.inl:385-405 -> directTraverse.comp. The first call after the ray queue changed
+ * (camera, shade, upload_rays, reset_hits) starts the hit chains; further calls with other hierarchies extend
+ * them as the reference's ray.hit hand-over does (multi-BVH; directTraverse.comp:219-249,335-346):
+ * the search starts at the distance already found and new hits overwrite the front of the chain. At most 16
+ * hierarchies of < 2^27 triangles each per queue; psm_rt_shade() then interpolates each hit from the
+ * hierarchy that produced it (its `bvh` argument is used when only one was traversed). */
 int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
+/* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
+int psm_rt_reset_hits(psm_rt* rt);
 /* applyMaterials + shade, Pipeline.inl:407-436 -> surface.comp + rayshading.comp, then the
  * queue hand-off of reloadQueuedRays (:325-359). `time` replaces rand() (:426). */
 int psm_rt_shade(psm_rt* rt, psm_bvh* bvh, uint32_t time);

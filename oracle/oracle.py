@@ -196,6 +196,19 @@ def traverse(nodes, tris, M, origins, directs, nthreads=0, want_hits=True):
     return hits, counts, ctr
 
 
+def traverse_chain(nodes, tris, M, origins, directs, hits, counts, tri_base, nthreads=0):
+    """Multi-BVH: extend the chains in hits [n,8] / counts [n] (modified in place) with another hierarchy."""
+    tris = np.ascontiguousarray(tris, np.float32)
+    origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    directs = np.ascontiguousarray(directs, np.float32).reshape(-1, 3)
+    assert hits.flags.c_contiguous and counts.flags.c_contiguous and hits.shape == (origins.shape[0], BAKED_CAP)
+    ctr = Counters()
+    lib().psmo_traverse_chain_batch(_p(np.ascontiguousarray(nodes)), _p(tris), _p(np.ascontiguousarray(M, np.float32)),
+                                    _p(origins), _p(directs), C.c_int(origins.shape[0]), _p(hits), _p(counts),
+                                    C.c_int(tri_base), C.byref(ctr), C.c_int(nthreads))
+    return ctr
+
+
 def brute_force(tris, origin, direct):
     tris = np.ascontiguousarray(tris, np.float32)
     best = np.zeros(1, HIT_DT)
@@ -356,13 +369,19 @@ def rand_next(state):
 
 
 def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, built=None,
-                  cam=None, rows=None, record=None, skybox=None):
+                  cam=None, rows=None, record=None, skybox=None, parts=None):
     """Viewer.cpp:296-312 call order on the oracle: build, camera, <=depth x (traverse, shade), sample.
-    Returns (filtered image [h,w,4], stats)."""
+    Returns (filtered image [h,w,4], stats). parts: list of triangle-index arrays -- each becomes its own
+    hierarchy and every round intersects them one after the other (multi-BVH); the scene's arrays must be
+    ordered part by part."""
     from importlib import import_module
     scenes = import_module("prismarine-core_amd.scenes")
     tris = scene["tris"]
-    if built is None:
+    if parts is not None:
+        assert np.array_equal(np.concatenate(parts), np.arange(tris.shape[0]))
+        pbuilt = [build_scene(tris[ix]) for ix in parts]
+        built = pbuilt[0]
+    elif built is None:
         built = build_scene(tris)
     mats = scenes.materials_array(scene["materials"])
     cfg = make_cfg(width, height, material_count=len(mats))
@@ -382,7 +401,12 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
         for j in range(depth):
             if rays.shape[0] < 32:  # Pipeline::getRayCount, Pipeline.inl:459-461
                 break
-            hits, counts, ctr = traverse(built["nodes"], tris, built["M"], rays["origin"], rays["direct"], nthreads)
+            if parts is None:
+                hits, counts, ctr = traverse(built["nodes"], tris, built["M"], rays["origin"], rays["direct"], nthreads)
+            else:
+                hits, counts, ctr = traverse(pbuilt[0]["nodes"], tris[parts[0]], pbuilt[0]["M"], rays["origin"], rays["direct"], nthreads)
+                for pb, ix in zip(pbuilt[1:], parts[1:]):
+                    traverse_chain(pb["nodes"], tris[ix], pb["M"], rays["origin"], rays["direct"], hits, counts, int(ix[0]), nthreads)
             stats["rays"] += rays.shape[0]
             stats["rounds"].append(int(rays.shape[0]))
             stats["node_visits"] += ctr.node_visits

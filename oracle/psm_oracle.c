@@ -609,8 +609,15 @@ static void reorderTriangles(tstate* st) {
 int psmo_traverse(const psmo_node* nodes, const float* tris, const float M[16],
                   const float origin[3], const float direct_in[3], psmo_hit out[PSMO_BAKED_CAP],
                   psmo_counters* ctr) {
+    return psmo_traverse_from(nodes, tris, M, origin, direct_in, PSMO_INFINITY, out, ctr);
+}
+
+/* traverse() entered with the distance of the chain the ray already carries (:335-336, multi-BVH) */
+int psmo_traverse_from(const psmo_node* nodes, const float* tris, const float M[16],
+                       const float origin[3], const float direct_in[3], float start_dist,
+                       psmo_hit out[PSMO_BAKED_CAP], psmo_counters* ctr) {
     tstate st;
-    st.predist = PSMO_INFINITY;
+    st.predist = start_dist;
     st.triangleID = -1;
     st.bakedCount = 0;
     for (int i = 0; i < PSMO_BAKED_CAP; i++) { st.baked[i].u = 0; st.baked[i].v = 0; st.baked[i].t = PSMO_INFINITY; st.baked[i].tri = -1; }
@@ -756,6 +763,48 @@ void psmo_traverse_batch_ex(const psmo_node* nodes, const float* tris, const flo
                     else { psmo_hit z = {0.f, 0.f, PSMO_INFINITY, -1}; hits[(size_t)r * PSMO_BAKED_CAP + k] = z; }
                 }
             }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            total.node_visits += local.node_visits;
+            total.tri_tests += local.tri_tests;
+            total.stack_drops += local.stack_drops;
+            total.iter_caps += local.iter_caps;
+            total.baked_drops += local.baked_drops;
+        }
+    }
+    if (ctr) *ctr = total;
+}
+
+/* A further intersection() of the same rays with another hierarchy (directTraverse.comp:219-249,335-346,
+ * 497-508): the search starts at the head distance of the existing chain; the hits it bakes overwrite the
+ * front of that chain and what is left of the old chain stays linked behind them. Triangle ids are recorded
+ * as tri_base + local id so one concatenated triangle array serves the shading stage. The reference's
+ * "hit index 0 counts as no chain" slip (hid > 0, :225,229) is not reproduced. */
+void psmo_traverse_chain_batch(const psmo_node* nodes, const float* tris, const float M[16],
+                               const float* origins, const float* directs, int nrays, psmo_hit* hits,
+                               int32_t* counts, int tri_base, psmo_counters* ctr, int nthreads) {
+    psmo_counters total;
+    memset(&total, 0, sizeof(total));
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+    {
+        psmo_counters local;
+        memset(&local, 0, sizeof(local));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int r = 0; r < nrays; r++) {
+            psmo_hit tmp[PSMO_BAKED_CAP];
+            psmo_hit* chain = &hits[(size_t)r * PSMO_BAKED_CAP];
+            float start = counts[r] > 0 ? chain[0].t : PSMO_INFINITY;
+            int k = psmo_traverse_from(nodes, tris, M, &origins[3 * r], &directs[3 * r], start, tmp, &local);
+            for (int j = 0; j < k; j++) { chain[j] = tmp[j]; chain[j].tri += tri_base; }
+            if (k > counts[r]) counts[r] = k;
         }
 #ifdef _OPENMP
 #pragma omp critical

@@ -108,6 +108,13 @@ void psmo_traverse_batch_ex(const psmo_node* nodes, const float* tris, const flo
                             const float* origins, const float* directs, int nrays, psmo_hit* hits,
                             int32_t* counts, psmo_counters* ctr, int nthreads, uint32_t* per_ray_visits,
                             uint32_t* per_ray_tests);
+int psmo_traverse_from(const psmo_node* nodes, const float* tris, const float M[16],
+                       const float origin[3], const float direct[3], float start_dist,
+                       psmo_hit out[PSMO_BAKED_CAP], psmo_counters* ctr);
+/* multi-BVH: extend the chains in hits/counts (in/out) with another hierarchy's hits, ids offset by tri_base */
+void psmo_traverse_chain_batch(const psmo_node* nodes, const float* tris, const float M[16],
+                               const float* origins, const float* directs, int nrays, psmo_hit* hits,
+                               int32_t* counts, int tri_base, psmo_counters* ctr, int nthreads);
 int psmo_brute_force(const float* tris, int ntris, const float origin[3],
                      const float direct[3], psmo_hit* best);
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -498,8 +498,14 @@ class Pipeline:
     def getRayCount(self):
         return self.raycountCache if self.raycountCache >= 32 else 0  # Pipeline.inl:459-461
 
+    def resetHits(self):
+        """Forget the hit chains of the current queue (ray.hit = -1): the next intersection() starts afresh."""
+        self.ctx.check(lib().psm_rt_reset_hits(self._h), "psm_rt_reset_hits")
+
     def intersection(self, obj, clearDepth=0, force=False):
-        """force=True skips the local >=32 rule (tile-sharded frames decide on the global count)."""
+        """force=True skips the local >=32 rule (tile-sharded frames decide on the global count).
+        Called with several hierarchies before shade(), the hits chain across them (multi-BVH,
+        directTraverse.comp:219-249,335-346); download_hits() then reports tri | object_sequence << 27."""
         if obj is None or obj.triangleCount <= 0:
             return 0
         if (self.raycountCache if force else self.getRayCount()) <= 0:

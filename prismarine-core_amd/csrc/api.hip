@@ -440,7 +440,7 @@ int psm_rt_destroy(psm_rt* r) {
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     rt_free_grid(r);
-    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table);
+    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table); dev_free(r->d_geoms);
     for (int i = 0; i < MAX_TEXTURES; i++) if (r->tex_host[i].texels) (void)hipFree(const_cast<uint32_t*>(r->tex_host[i].texels));
     delete r;
     return PSM_OK;
@@ -455,6 +455,7 @@ int psm_rt_create(psm_ctx* c, psm_rt** out) {
     int rc = dev_alloc(c, &r->d_cnt, (size_t)8);
     if (rc == PSM_OK) rc = dev_alloc(c, &r->d_lights, (size_t)16);
     if (rc == PSM_OK) rc = dev_alloc(c, &r->d_tex_table, (size_t)MAX_TEXTURES);
+    if (rc == PSM_OK) rc = dev_alloc(c, &r->d_geoms, (size_t)MAX_TRAV_OBJECTS);
     if (rc == PSM_OK) r->tex_dirty = true;
     if (rc != PSM_OK) { psm_rt_destroy(r); return rc; }
     (void)hipMemsetAsync(r->d_cnt, 0, 32, c->stream);
@@ -667,6 +668,12 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
     return launch_rt_traverse(r, b);
 }
 
+int psm_rt_reset_hits(psm_rt* r) {
+    if (!r) return PSM_ERR_INVALID;
+    r->trav_n = 0;
+    return PSM_OK;
+}
+
 int psm_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     if (!r || !b) return PSM_ERR_INVALID;
     (void)hipSetDevice(r->ctx->device);
@@ -766,6 +773,7 @@ int psm_rt_upload_rays(psm_rt* r, const psm_ray* src, uint32_t count) {
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     r->ray_count = count;
     r->count_valid = true;
+    r->trav_n = 0;
     return PSM_OK;
 }
 

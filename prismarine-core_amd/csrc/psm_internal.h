@@ -15,6 +15,15 @@ struct TexDesc {
     int w, h;
 };
 constexpr int MAX_TEXTURES = 32;  // surface.comp:46
+constexpr int MAX_TRAV_OBJECTS = 16;  // hierarchies chained over one ray queue (multi-BVH)
+constexpr int OBJ_SHIFT = 27;          // hit.w = triangle | object << 27
+
+struct ObjGeom {  // what interpolateMeshData reads of one hierarchy (directTraverse.comp:116-147)
+    const float4* tri48;
+    const float* nrm;
+    const int32_t* tri_mats;
+    const float* uv;
+};
 
 enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_COUNT };
 
@@ -120,6 +129,9 @@ struct psm_rt {
     psm::TexDesc tex_host[psm::MAX_TEXTURES] = {};
     psm::TexDesc* d_tex_table = nullptr;
     bool tex_dirty = false;
+    psm_bvh* trav_objs[psm::MAX_TRAV_OBJECTS] = {};  // hierarchies traversed since the queue last changed
+    int trav_n = 0;
+    psm::ObjGeom* d_geoms = nullptr;
     uint32_t* d_sky = nullptr;    // equirect RGBA8 skybox (one texel per word) or null
     uint32_t sky_w = 0, sky_h = 0;
     int samples_lock = 4;         // SAMPLES_LOCK, constants.glsl:35

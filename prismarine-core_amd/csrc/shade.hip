@@ -137,6 +137,7 @@ struct SurfSrc {
     const psm_material* mats;
     const float* uv;       // 6 floats / triangle
     const TexDesc* tex;    // MAX_TEXTURES slots
+    const ObjGeom* geoms;  // MULTI: per-object geometry, indexed by the tag in hit.w
     int mat_offset, mat_count;
 };
 
@@ -169,15 +170,20 @@ PSM_D void fetch_tex(const TexDesc t, float u, float v, int ox, int oy, float* o
     }
 }
 
-template <bool TEX>
+template <bool TEX, bool MULTI>
 PSM_D Surf surface_eval(float4 hit, const SurfSrc& src) {
     Surf s;
     int tri = __float_as_int(hit.w);
+    ObjGeom g = {src.tri48, src.nrm, src.tri_mats, src.uv};
+    if (MULTI) {  // the hierarchy whose mosaics were bound when this hit was interpolated
+        g = src.geoms[(tri >> OBJ_SHIFT) & (MAX_TRAV_OBJECTS - 1)];
+        tri &= (1 << OBJ_SHIFT) - 1;
+    }
     float u = hit.x, v = hit.y;
     s.t = hit.z;
-    float4 b = src.tri48[(size_t)3 * tri + 1], c = src.tri48[(size_t)3 * tri + 2];
+    float4 b = g.tri48[(size_t)3 * tri + 1], c = g.tri48[(size_t)3 * tri + 2];
     v3 d1 = mk3(b.x, b.y, b.z), d2 = mk3(c.x, c.y, c.z);
-    const float* n = src.nrm + (size_t)9 * tri;
+    const float* n = g.nrm + (size_t)9 * tri;
     float vs0 = (1.0f - u) - v, vs1 = u, vs2 = v;
     v3 nor = normalize3(cross3(d1, d2));
     v3 nn = mk3((vs0 * n[0] + vs1 * n[3]) + vs2 * n[6], (vs0 * n[1] + vs1 * n[4]) + vs2 * n[7],
@@ -187,7 +193,7 @@ PSM_D Surf surface_eval(float4 hit, const SurfSrc& src) {
     nn = nn * sg;
     s.normal_trav = nn;
     s.normal = normalize3(normalize3(nn));  // surface.comp:176-186 with no normal map
-    int matID = src.tri_mats[tri] - src.mat_offset;
+    int matID = g.tri_mats[tri] - src.mat_offset;
     s.active = !(matID >= src.mat_count || matID < 0);
 #pragma unroll
     for (int k = 0; k < 4; k++) { s.albedo[k] = 0.f; s.emission[k] = 0.f; s.mr[k] = 0.f; }
@@ -197,7 +203,7 @@ PSM_D Surf surface_eval(float4 hit, const SurfSrc& src) {
         float emis[4] = {0.f, 0.f, 0.f, 0.f};
         float spc[4] = {m->specular[0], m->specular[1], m->specular[2], m->specular[3]};
         if (TEX) {
-        const float* tc = src.uv + (size_t)6 * tri;
+        const float* tc = g.uv + (size_t)6 * tri;
         float tu = (vs0 * tc[0] + vs1 * tc[2]) + vs2 * tc[4], tv = (vs0 * tc[1] + vs1 * tc[3]) + vs2 * tc[5];
         if (valid_tex(src.tex, m->diffusePart)) fetch_tex(src.tex[m->diffusePart], tu, tv, 0, 0, diff);     // :155-161
         if (valid_tex(src.tex, m->emissivePart)) fetch_tex(src.tex[m->emissivePart], tu, tv, 0, 0, emis);   // :110-116
@@ -381,7 +387,7 @@ struct ShadeArgs {
 // surface.comp + rayshading.comp:48-278
 // TEX = false is the same kernel with the sampler table known to be empty (validateTexture fails for every
 // part): the texture-less frame keeps its registers and occupancy
-template <bool TEX>
+template <bool TEX, bool MULTI>
 __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     __shared__ uint32_t scan_tmp[8];
     uint32_t it = blockIdx.x * SHADE_BLOCK + threadIdx.x;
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
         // distance behind it are blended in (:88-116)
         bool found = false;
         for (int k = 0; k < n; k++) {
-            Surf h = surface_eval<TEX>(k == 0 ? a.hit0[it] : a.pool[poff + k - 1], a.src);
+            Surf h = surface_eval<TEX, MULTI>(k == 0 ? a.hit0[it] : a.pool[poff + k - 1], a.src);
             if (!found) {
                 uvt_t = h.t;
                 if (!h.active) { c_normal = h.normal_trav; continue; }
@@ -764,6 +770,7 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
     PSM_HIP(c, hipGetLastError());
     r->ray_count = nrays;
     r->count_valid = true;
+    r->trav_n = 0;
     return PSM_OK;
 }
 
@@ -785,12 +792,24 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     a.sky[0] = r->sky[0]; a.sky[1] = r->sky[1]; a.sky[2] = r->sky[2];
     a.sky_tex = r->d_sky; a.sky_w = (int)r->sky_w; a.sky_h = (int)r->sky_h;
     int nxt = r->cur ^ 1;
+    const bool multi = r->trav_n > 1;
+    a.src.geoms = r->d_geoms;
+    if (multi) {  // hits carry an object tag: hand the kernel every traversed hierarchy's mosaics
+        ObjGeom g[MAX_TRAV_OBJECTS] = {};
+        for (int i = 0; i < r->trav_n; i++)
+            g[i] = ObjGeom{r->trav_objs[i]->d_tri48, r->trav_objs[i]->d_nrm, r->trav_objs[i]->d_mats, r->trav_objs[i]->d_tex};
+        PSM_HIP(c, hipMemcpyAsync(r->d_geoms, g, sizeof(g), hipMemcpyHostToDevice, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    r->trav_n = 0;  // the queue changes: the next intersection() starts new chains
     {
         TimedScope ts(c, CAT_SHADE);
         bool any_tex = false;
         for (int i = 1; i < MAX_TEXTURES; i++) any_tex = any_tex || r->tex_host[i].texels != nullptr;
-        if (any_tex) rt_shade<true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        else rt_shade<false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        if (any_tex && multi) rt_shade<true, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else if (any_tex) rt_shade<true, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else if (multi) rt_shade<false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else rt_shade<false, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->d_cnt, c->d_counters);
         rt_compact<<<nb, SHADE_BLOCK, 0, c->stream>>>(r->sA, r->sB, r->sC, r->d_block, nb, r->limit, r->qA[nxt], r->qB[nxt],
                                                       r->qC[nxt]);

@@ -71,14 +71,18 @@ struct Baked {
     int tri;
 };
 
-template <bool COUNT>
+// CHAIN: a further intersection() over the same rays with another hierarchy (multi-BVH). The
+// search starts from the distance of the chain the ray already carries (traverse(), :335-346) and the hits
+// it bakes overwrite the front of that chain, the rest of the old chain staying linked behind them
+// (includeChain, :219-249). Triangle ids are tagged with the object's sequence number (bits 27..30).
+template <bool COUNT, bool CHAIN>
 __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __restrict__ qA, const float4* __restrict__ qB,
                                                           uint32_t nrays, const uint4* __restrict__ node32,
                                                           const float4* __restrict__ tri48,
                                                           const uint32_t* __restrict__ sm, float4* __restrict__ hit0,
                                                           uint32_t* __restrict__ hitN, float4* __restrict__ pool,
                                                           uint32_t pool_cap, uint32_t* __restrict__ cnt,
-                                                          DevCounters* __restrict__ ctr) {
+                                                          DevCounters* __restrict__ ctr, uint32_t obj_tag) {
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
     uint32_t i = blockIdx.x * TRAV_BLOCK + threadIdx.x;
     const int tid = threadIdx.x;
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
 
     // hit state (TResult + bakedStack, :27-45)
     float predist = INF;
+    if (CHAIN) {
+        if (alive && (hitN[i] & 15u) != 0u) predist = hit0[i].z;
+    }
     int lastTri = -1;
     int bakedCount = 0;
     Baked head = {0.f, 0.f, INF, -1};
@@ -205,7 +212,48 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     }
     if (COUNT && it >= MAX_ITERS && validBox) nCap++;
 
-    if (alive) {
+    if (CHAIN) {
+        if (alive && bakedCount > 0) {
+            Baked bk[BAKED_CAP];
+            int n = bakedCount > BAKED_CAP ? BAKED_CAP : bakedCount;
+            bk[0] = head;
+            for (int k = 1; k < n; k++) bk[k] = extra[k - 1];
+            int clean = n;
+            if (n > 1) {  // reorderTriangles, :74-112
+                for (int iround = 1; iround < n; iround++) {
+                    for (int index = 0; index < n - iround; index++) {
+                        Baked a = bk[index], b = bk[index + 1];
+                        bool lessIdx = a.tri <= b.tri;
+                        bool deeper = lessF(a.t, b.t);
+                        if (lessIdx || deeper) { bk[index] = b; bk[index + 1] = a; }
+                    }
+                }
+                clean = 0;
+                for (int iround = 0; iround < BAKED_CAP; iround++) {
+                    if (iround >= n - 1) break;
+                    if (bk[iround + 1].tri != bk[iround].tri) bk[clean++] = bk[iround];
+                }
+                if (clean <= BAKED_CAP) bk[clean++] = bk[n - 1];
+            }
+            uint32_t oldN = hitN[i];
+            uint32_t oldCount = oldN & 15u, oldOff = oldN >> 4;
+            uint32_t k = (uint32_t)clean;
+            uint32_t count = k > oldCount ? k : oldCount, off = 0;
+            if (count > 1) {
+                off = atomicAdd(&cnt[2], count - 1);
+                if (off + (count - 1) > pool_cap) {
+                    if (COUNT) atomicAdd(&ctr->chain_pool_drops, 1ull);
+                    count = 1;
+                } else {
+                    for (uint32_t j = 1; j < count; j++)
+                        pool[off + j - 1] = j < k ? make_float4(bk[j].u, bk[j].v, bk[j].t, __int_as_float(bk[j].tri | (int)obj_tag))
+                                                  : pool[oldOff + j - 1];
+                }
+            }
+            hit0[i] = make_float4(bk[0].u, bk[0].v, bk[0].t, __int_as_float(bk[0].tri | (int)obj_tag));
+            hitN[i] = count | (off << 4);
+        }
+    } else if (alive) {
         uint32_t count = 0, off = 0;
         if (bakedCount <= 1) {
             count = (uint32_t)bakedCount;  // reorderTriangles is the identity on 0/1 entries
@@ -564,17 +612,25 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     psm_ctx* c = r->ctx;
     uint32_t n = r->ray_count;
     if (n == 0) return PSM_OK;
-    if (use_simple_traverse()) {
+    // the first intersection() after the queue changed starts the chains; later ones extend them
+    const bool chain = r->trav_n > 0;
+    if (r->trav_n >= MAX_TRAV_OBJECTS) return set_err(c, PSM_ERR_CAPACITY, "more than 16 hierarchies traversed for one ray queue");
+    if (b->tri_count > (1u << OBJ_SHIFT)) return set_err(c, PSM_ERR_CAPACITY, "hierarchy too large for the object tag (2^27 triangles)");
+    const uint32_t tag = (uint32_t)r->trav_n << OBJ_SHIFT;
+    r->trav_objs[r->trav_n++] = b;
+    if (chain || use_simple_traverse()) {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
         TimedScope ts(c, CAT_TRAVERSE);
-        if (c->counting)
-            rt_traverse<true><<<grid, TRAV_BLOCK, 0, c->stream>>>(r->qA[r->cur], r->qB[r->cur], n, b->d_node32,
-                                                                   b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool,
-                                                                   r->pool_cap, r->d_cnt, c->d_counters);
-        else
-            rt_traverse<false><<<grid, TRAV_BLOCK, 0, c->stream>>>(r->qA[r->cur], r->qB[r->cur], n, b->d_node32,
-                                                                    b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool,
-                                                                    r->pool_cap, r->d_cnt, c->d_counters);
+#define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
+                      r->pool_cap, r->d_cnt, c->d_counters, tag
+        if (chain) {
+            if (c->counting) rt_traverse<true, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
+            else rt_traverse<false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
+        } else {
+            if (c->counting) rt_traverse<true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
+            else rt_traverse<false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
+        }
+#undef PSM_TRAV_ARGS
     } else {
         // persistent grid: 256 CUs x 8 workgroups of 4 waves (one wave per SIMD each); fewer when the
         // queue is short. Ray cursors cnt[3], cnt[4] alternate between launches (each launch zeroes

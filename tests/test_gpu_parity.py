@@ -475,6 +475,150 @@ def test_load_mesh_texcoord_accessor(psm, ctx, oracle, scenes):
         th.close()
 
 
+def _multi_scene(scenes):
+    """Sponza-class scene cut into three hierarchies; the third repeats every 7th triangle of the others with
+    another material, so rays meet equal-distance hits coming from different hierarchies."""
+    sc = scenes.textured(scenes.sponza_like(n_tris=20011))
+    n = sc["tris"].shape[0]
+    dup = np.concatenate([np.arange(0, n, 7), np.arange(0, n, 35)])   # every 35th triangle twice: chains inside part 3
+    cat = lambda a: np.concatenate([a, a[dup]])
+    ms = dict(sc)
+    ms["tris"], ms["normals"], ms["texcoords"] = cat(sc["tris"]), cat(sc["normals"]), cat(sc["texcoords"])
+    ms["mats"] = np.concatenate([sc["mats"], (sc["mats"][dup] + 1) % len(sc["materials"])]).astype(np.int32)
+    cut = n // 2
+    parts = [np.arange(0, cut), np.arange(cut, n), np.arange(n, n + dup.size)]
+    return ms, parts
+
+
+def _load_parts(psm, ctx, scene, parts):
+    ths = []
+    for ix in parts:
+        th = psm.TriangleHierarchy(ctx)
+        th.allocate(ix.size)
+        th.loadTriangles(scene["tris"][ix], scene["normals"][ix], scene["mats"][ix], scene["texcoords"][ix])
+        th.build()
+        ths.append(th)
+    return ths
+
+
+def _global_tri(gh, gc, parts):
+    """tri | object << 27 (psm_rt_traverse) -> index into the concatenated scene arrays"""
+    base = np.array([int(ix[0]) for ix in parts] + [0] * (16 - len(parts)))
+    tri = gh["tri"].copy()
+    valid = np.arange(8)[None, :] < gc[:, None]
+    tri[valid] = base[(tri[valid] >> 27) & 15] + (tri[valid] & ((1 << 27) - 1))
+    out = gh.copy()
+    out["tri"] = tri
+    return out
+
+
+def test_multi_bvh_chained_intersection(psm, ctx, oracle, scenes):
+    """intersection() with several hierarchies over one ray queue (ray.hit handed from call to call,
+    directTraverse.comp:219-249,335-346,497-508): hit chains and the shaded queues bit-exact vs the oracle."""
+    scene, parts = _multi_scene(scenes)
+    w, h = 128, 72
+    ths = _load_parts(psm, ctx, scene, parts)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    ts = psm.TextureSet()
+    for slot in sorted(scene["textures"]):
+        ts.loadTexture(scene["textures"][slot])
+    ms.setTextureSet(ts)
+    cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
+    obs = [oracle.build_scene(scene["tris"][ix]) for ix in parts]
+    mats = scenes.materials_array(scene["materials"])
+    cfg = oracle.make_cfg(w, h, material_count=len(mats))
+    oracle.set_textures(cfg, scene["texcoords"], scene["textures"])
+    lights = oracle.default_lights(1)
+    rt.camera_matrices(cam[0], cam[1], time=7)
+    orays, ocoord, osum, oflag = oracle.camera(cfg, cam[0], cam[1], 7)
+    rt.applyMaterials(ms)
+    overrides = 0
+    for rnd in range(5):
+        if orays.shape[0] < 32:
+            break
+        oh, oc, _ = oracle.traverse(obs[0]["nodes"], scene["tris"][parts[0]], obs[0]["M"], orays["origin"], orays["direct"], 8)
+        rt.intersection(ths[0])
+        for k in (1, 2):
+            before = oh["tri"][:, 0].copy()
+            oracle.traverse_chain(obs[k]["nodes"], scene["tris"][parts[k]], obs[k]["M"], orays["origin"], orays["direct"],
+                                  oh, oc, int(parts[k][0]), 8)
+            overrides += int((before != oh["tri"][:, 0]).sum())
+            rt.intersection(ths[k])
+            gh, gc = rt.download_hits(orays.shape[0])
+            _hits_equal(_global_tri(gh, gc, parts), gc, oh, oc)
+        t = 500 + rnd
+        rt.shade(time=t)
+        orays = oracle.shade(cfg, lights, mats, scene["mats"], scene["tris"], scene["normals"], t, orays, oh, oc, osum, oflag)
+        assert rt.raycountCache == orays.shape[0], rnd
+        _rays_equal(rt.download_rays(), orays)
+    assert rnd >= 2 and overrides > 1000           # later hierarchies really replaced chain heads
+    assert (oc > 1).sum() > 0                      # and equal-distance chains across hierarchies occurred
+    rt.close()
+    for th in ths:
+        th.close()
+
+
+def test_multi_bvh_radiance_and_union_equivalence(psm, ctx, oracle, scenes):
+    """Whole frames over three hierarchies: radiance <= 1e-4 vs the oracle; and on a scene without coincident
+    triangles the chained result is the single-hierarchy result (same nearest hits)."""
+    scene, parts = _multi_scene(scenes)
+    w, h, frames = 96, 54, 2
+    ths = _load_parts(psm, ctx, scene, parts)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    ts = psm.TextureSet()
+    for slot in sorted(scene["textures"]):
+        ts.loadTexture(scene["textures"][slot])
+    ms.setTextureSet(ts)
+
+    def render(objs, sc):
+        rt.setSeed(21)
+        rt.clearSampler()
+        for _ in range(frames):
+            ms.loadToVGA()
+            rt.camera(sc["eye"], sc["view"])
+            for _ in range(16):
+                if rt.getRayCount() <= 0:
+                    break
+                for th in objs:
+                    rt.intersection(th)
+                rt.applyMaterials(ms)
+                rt.shade()
+            rt.sample()
+        return rt.snapHdr()
+
+    img = render(ths, scene)
+    ref, st = oracle.render_frames(scene, w, h, frames=frames, seed=21, parts=parts, nthreads=8)
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    for th in ths:
+        th.close()
+    # no coincident triangles: two hierarchies == one
+    plain = scenes.sponza_like(n_tris=20011)
+    n = plain["tris"].shape[0]
+    halves = [np.arange(0, n // 3), np.arange(n // 3, n)]
+    plain["texcoords"] = np.zeros((n, 3, 2), np.float32)
+    ms2 = psm.MaterialSet()
+    for m in plain["materials"]:
+        ms2.addSubmat(m)
+    ms, two = ms2, _load_parts(psm, ctx, plain, halves)
+    one = _load_parts(psm, ctx, plain, [np.arange(n)])
+    a = render(two, plain)
+    b = render(one, plain)
+    np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-4, atol=1e-5)
+    rt.close()
+    for th in two + one:
+        th.close()
+
+
 def _sky_image(w=64, h=32):
     yy, xx = np.mgrid[0:h, 0:w]
     img = np.zeros((h, w, 4), np.uint8)

@@ -19,9 +19,9 @@ rt.intersection(th); rt.shade(); sets.append(rt.download_rays())
 reps = int(os.environ.get("REPS", "5"))
 for name, rays in zip(("primary", "round2"), sets):
     rt.upload_rays(rays)
-    rt.intersection(th, force=True); ctx.sync()
+    rt.resetHits(); rt.intersection(th, force=True); ctx.sync()
     ctx.stats_enable(True, False); ctx.stats_reset()
-    for _ in range(reps): rt.intersection(th, force=True)
+    for _ in range(reps): rt.resetHits(); rt.intersection(th, force=True)
     st = ctx.stats()
     ms_ = st.traverse_ms / reps
     print("%s %s rays=%d  %.3f ms  %.1f Mrays/s" % (os.environ.get("TAG", ""), name, len(rays), ms_, len(rays) / ms_ / 1e3))
@@ -43,9 +43,9 @@ if os.environ.get("SORT_EXP"):
                       ("random", np.random.RandomState(0).permutation(len(rays)).astype(np.uint64))):
         order = np.argsort(key, kind="stable")
         rt.upload_rays(rays[order])
-        rt.intersection(th, force=True); ctx.sync()
+        rt.resetHits(); rt.intersection(th, force=True); ctx.sync()
         ctx.stats_enable(True, False); ctx.stats_reset()
-        for _ in range(reps): rt.intersection(th, force=True)
+        for _ in range(reps): rt.resetHits(); rt.intersection(th, force=True)
         st = ctx.stats(); ms_ = st.traverse_ms / reps
         print("%s round2 sorted by %s: %.3f ms  %.1f Mrays/s" % (os.environ.get("TAG", ""), name, ms_, len(rays) / ms_ / 1e3))
         ctx.stats_enable(False, False)
@@ -55,9 +55,9 @@ if os.environ.get("SIZE_EXP"):
     for frac in (1, 2, 4, 8, 16, 32, 64, 256):
         sub = rays[: len(rays) // frac]
         rt.upload_rays(sub)
-        rt.intersection(th, force=True); ctx.sync()
+        rt.resetHits(); rt.intersection(th, force=True); ctx.sync()
         ctx.stats_enable(True, False); ctx.stats_reset()
-        for _ in range(reps): rt.intersection(th, force=True)
+        for _ in range(reps): rt.resetHits(); rt.intersection(th, force=True)
         st = ctx.stats(); ms_ = st.traverse_ms / reps
         print("%s round2 first 1/%d (%d rays): %.3f ms  %.1f Mrays/s" % (os.environ.get("TAG", ""), frac, len(sub), ms_, len(sub) / ms_ / 1e3))
         ctx.stats_enable(False, False)
@@ -67,9 +67,9 @@ if os.environ.get("TINY_EXP"):
     for cnt_ in (64, 1024, 8192):
         sub = rays[:cnt_]
         rt.upload_rays(sub)
-        rt.intersection(th, force=True); ctx.sync()
+        rt.resetHits(); rt.intersection(th, force=True); ctx.sync()
         ctx.stats_enable(True, False); ctx.stats_reset()
-        for _ in range(20): rt.intersection(th, force=True)
+        for _ in range(20): rt.resetHits(); rt.intersection(th, force=True)
         st = ctx.stats(); ms_ = st.traverse_ms / 20
         print("%s tiny %d rays: %.4f ms" % (os.environ.get("TAG", ""), cnt_, ms_))
         ctx.stats_enable(False, False)
