@@ -196,6 +196,22 @@ def traverse(nodes, tris, M, origins, directs, nthreads=0, want_hits=True):
     return hits, counts, ctr
 
 
+def traverse_visits(nodes, tris, M, origins, directs, nthreads=0):
+    """Per-ray node-visit and triangle-test counts (divergence / tail studies; no hits returned)."""
+    tris = np.ascontiguousarray(tris, np.float32)
+    origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    directs = np.ascontiguousarray(directs, np.float32).reshape(-1, 3)
+    n = origins.shape[0]
+    counts = np.zeros(n, np.int32)
+    visits = np.zeros(n, np.uint32)
+    tests = np.zeros(n, np.uint32)
+    ctr = Counters()
+    lib().psmo_traverse_batch_ex(_p(np.ascontiguousarray(nodes)), _p(tris), _p(np.ascontiguousarray(M, np.float32)),
+                                 _p(origins), _p(directs), C.c_int(n), None, _p(counts), C.byref(ctr),
+                                 C.c_int(nthreads), _p(visits), _p(tests))
+    return visits, tests
+
+
 def traverse_chain(nodes, tris, M, origins, directs, hits, counts, tri_base, nthreads=0):
     """Multi-BVH: extend the chains in hits [n,8] / counts [n] (modified in place) with another hierarchy."""
     tris = np.ascontiguousarray(tris, np.float32)
