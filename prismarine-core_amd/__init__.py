@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsm_hip.so")
+LIB_PATH = os.environ.get("PSM_HIP_LIB") or os.path.join(_HERE, "libpsm_hip.so")  # override: A/B builds of the same ABI
 
 EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
