@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--emulate-tile", default=None, help="R/W: render only the tile of rank R of W on one GPU, no communication (Amdahl study)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path even on 1 GPU (rehearsal)")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="frames in flight per GPU (psm_lanes_render): each on its own HIP stream, folded into the "
+                         "accumulating image in frame order; 1 = one frame after another")
     return ap.parse_args()
 
 
@@ -63,10 +66,13 @@ class Renderer:
             # run the kernels on torch's stream: RCCL calls and kernels are ordered without host syncs
             stream = dist.torch.cuda.current_stream().cuda_stream
             dist.same_stream = True
-        self.ctx = psm.Context(dist.device_index, stream=stream)
-        self.th = psm.TriangleHierarchy(self.ctx)
-        self.th.allocate(scene["tris"].shape[0])
-        self.th.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
+        w, h = args.width, args.height
+        self.lanes = 1 if dist.active else max(1, args.lanes)
+        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000,
+                                    streams=[stream] if stream is not None else None)
+        self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
+        self.batch.allocate(scene["tris"].shape[0])
+        self.batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
         self.ms = psm.MaterialSet()
         for m in scene["materials"]:
             self.ms.addSubmat(m)
@@ -75,16 +81,13 @@ class Renderer:
             for slot in sorted(scene["textures"]):
                 assert ts.loadTexture(scene["textures"][slot]) == slot
             self.ms.setTextureSet(ts)
-        w, h = args.width, args.height
-        self.rt = psm.Pipeline(self.ctx, seed=1000)
-        self.rt.resizeBuffers(w, h)
-        self.rt.resize(w, h)
+        self.batch.applyMaterials(self.ms)
         if dist.active:
             self.rt.setTileInterleaved(dist.rank, dist.world)  # 8-row bands dealt round-robin
             dist.initial_total = w * h
         elif args.emulate_tile:
             r_, w_ = (int(v) for v in args.emulate_tile.split("/"))
-            self.rt.setTileInterleaved(r_, w_)
+            self.batch.each(lambda r: r.setTileInterleaved(r_, w_))
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if dist.active:
             torch = dist.torch
@@ -93,9 +96,18 @@ class Renderer:
             self.tile_dev = torch.zeros(self.per, dtype=torch.float32, device=gdev)
             self.all_dev = torch.zeros(dist.world * self.per, dtype=torch.float32, device=gdev) if dist.rank == 0 else None
 
+    def frames_in_flight(self, k):
+        """k x process() with `lanes` frames in flight (native scheduler), folded in frame order."""
+        return self.batch.render(k, self.scene["eye"], self.scene["view"], depth=self.args.depth)
+
     def frame(self, record=None):
-        """GltfViewer::process(), Viewer.cpp:296-312 (display excluded)."""
+        """GltfViewer::process(), Viewer.cpp:296-312 (display excluded): one frame on lane 0, with the rand()
+        stream the FrameBatch policy gives it (one draw of the accumulating stream seeds the frame's own)."""
         rt, th, ms, dist = self.rt, self.th, self.ms, self.dist
+        if not hasattr(self, "_master_state"):
+            self._master_state = 1000
+        self._master_state = (self._master_state * 214013 + 2531011) & 0xFFFFFFFF
+        rt.setSeed((self._master_state >> 16) & 0x7FFF)
         ms.loadToVGA()
         th.markDirty()
         th.build()
@@ -178,15 +190,28 @@ def main():
         scene = scenes.textured(scene)
     R = Renderer(psm, scenes, scene, args, dist)
     ctx = R.ctx
+    lanes_mode = not dist.active
 
-    # untimed: warm-up frames; frame 0 doubles as the counting pass (V, T are deterministic per seed)
-    for i in range(max(args.warmup, 0)):
-        R.frame()
-    ctx.sync()
+    def run_steps(k, record=None):
+        if lanes_mode:
+            return sum(r for _, r in R.frames_in_flight(k))
+        for i in range(k):
+            R.frame(record=record if i == 0 else None)
+        return None
 
-    # counting pass: same seeds as the timed frames, counters on, timing off
-    R.rt.setSeed(1000)
-    R.rt.clearSampler()
+    def reseed():
+        R.batch.setSeed(1000)
+        R._master_state = 1000
+        R.rt.clearSampler()
+        R.batch.clearSampler()
+
+    # untimed: warm-up steps on the timed path
+    run_steps(max(args.warmup, 0))
+    R.batch.sync()
+
+    # counting pass: the frames of the timed region (same rand() streams), one after another on lane 0,
+    # counters on: V, T, R are deterministic per seed
+    reseed()
     ctx.stats_enable(False, True)
     ctx.stats_reset()
     ray_sets = [] if (dist.rank == 0 and not args.no_cpu_baseline) else None
@@ -195,26 +220,42 @@ def main():
     cnt = ctx.stats()
     V, T, Rr = cnt.node_visits, cnt.tri_tests, cnt.rays_traced
 
-    # timed region: exactly K frames, HIP events on the traversal launches
-    R.rt.setSeed(1000)
-    R.rt.clearSampler()
-    ctx.stats_enable(True, False)
+    # kernel pass: the same frames again, one after another, HIP events on every launch (on the launching
+    # stream): per-stage times and the traversal kernel's own launch duration for the roofline
+    if lanes_mode:
+        reseed()
+        ctx.stats_enable(True, False)
+        ctx.stats_reset()
+        for i in range(args.steps):
+            R.frame()
+        ctx.sync()
+        kst = ctx.stats()
+        assert kst.rays_traced == Rr, (kst.rays_traced, Rr)
+        ctx.stats_enable(False, False)
+
+    # timed region: exactly K steps
+    reseed()
+    if not lanes_mode:
+        ctx.stats_enable(True, False)
     ctx.stats_reset()
     dist.barrier()
-    ctx.sync()
+    R.batch.sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        R.frame()
-    ctx.sync()
+    traced = run_steps(args.steps)
+    R.batch.sync()
     dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dist.max_float(elapsed)
-    st = ctx.stats()
-    assert st.rays_traced == Rr, (st.rays_traced, Rr)
-    total_rays = dist.sum_int(int(st.rays_traced))
+    if lanes_mode:
+        st = kst
+        assert traced == Rr, (traced, Rr)
+    else:
+        st = ctx.stats()
+        assert st.rays_traced == Rr, (st.rays_traced, Rr)
+    total_rays = dist.sum_int(int(Rr))
 
     if dist.rank == 0:
-        img = R.rt.snapHdr()
+        img = (R.batch if lanes_mode else R.rt).snapHdr()
         alg_bytes = Rr * 44 + V * 64 + T * 36
         launches = max(st.traverse_launches, 1)
         traffic, traffic_src = pmc_traffic("rt_traverse") if (world == 1 and args.scene == "sponza_like" and
@@ -233,18 +274,23 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
-                                   "per frame + camera + <=%d bounce rounds + sample" % (
-                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth),
+                                   "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU" % (
+                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth,
+                                       R.lanes),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world},
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes},
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
+            "stage_ms_per_frame_measured": "kernel pass (one frame after another)" if lanes_mode else "timed region",
             "stage_ms_per_frame": {"build": st.build_ms / args.steps, "sort": st.sort_ms / args.steps,
                                    "camera": st.camera_ms / args.steps, "traverse": st.traverse_ms / args.steps,
                                    "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rt_traverse", "launches": int(st.traverse_launches), "avg_launch_ms": avg_ms,
+                         "measured": ("kernel pass: the timed region's frames one after another, HIP events per launch "
+                                      "(launch durations overlap when several frames are in flight)") if lanes_mode
+                                     else "timed region, HIP events per launch",
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "R": int(Rr), "V": int(V), "T": int(T), "rank": 0},
             "image_mean": float(img[..., :3].mean()),

@@ -215,6 +215,10 @@ int psm_rt_reset_hits(psm_rt* rt);
 int psm_rt_shade(psm_rt* rt, psm_bvh* bvh, uint32_t time);
 /* sample(), Pipeline.inl:251-277 -> sampler.comp, deinterlace.comp, filter.comp */
 int psm_rt_sample(psm_rt* rt);
+/* sample() fed with the frame another Pipeline of the same ray-grid size rendered (its texel sums and jitter
+ * coordinates): folds that frame into rt's accumulating image exactly as rt's own sample() would have.
+ * Stream-ordered against both contexts, no host synchronisation. */
+int psm_rt_sample_from(psm_rt* rt, psm_rt* src);
 /* clearSampler(), Pipeline.inl:314-322 (also zeroes presampled: the GL texture starts undefined) */
 int psm_rt_clear_sampler(psm_rt* rt);
 /* snapHdr()/snapRawHdr(), Pipeline.inl:439-456: display_w*display_h*4 floats to host. Synchronises. */
@@ -251,6 +255,26 @@ int psm_rt_download_hits(psm_rt* rt, psm_hit* hits, int32_t* counts, uint32_t ma
 /* replace the current ray queue (host pointer) -- lets tests drive traverse with chosen rays */
 int psm_rt_upload_rays(psm_rt* rt, const psm_ray* src, uint32_t count);
 int psm_rt_download_texels(psm_rt* rt, float* sum_rgba, float* coord_xy, int32_t* flags);
+
+/* ---------------------------------------------------------------------------------------------
+ * several frames in flight (new; DESIGN.md "lanes")
+ * `frames` x GltfViewer::process() (Viewer.cpp:296-312) with up to `lanes` of them in flight: lane s =
+ * (rts[s], bvhs[s]) on its own context / stream. Frame f has its own CRT-rand() stand-in, started from
+ * frame_seeds[f] (one draw for camera(), one per shade(), as Pipeline.inl:282,426 draw them) and runs: build (if
+ * rebuild != 0, with `opt`), camera, at most `depth` rounds of { stop if fewer than 32 rays (Pipeline.inl:459-461);
+ * intersection; shade }, then sample() -- issued on `fold_into` (psm_rt_sample_from) in frame order, so the
+ * accumulated image equals the frames rendered one after another. Lanes never wait for each other's rounds: a
+ * frame's traversal tail overlaps the other frames' kernels, and a lane takes the next frame as soon as its own is
+ * folded. fold_into may be NULL when frames <= lanes (the lanes then keep their frames for the caller to fold).
+ * Materials / lights / sky / textures / tiles must have been set on every rt. Returns when everything is idle.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t rounds; /* shade() calls made for this frame */
+    uint64_t rays;   /* rays traced */
+} psm_lane_result;
+int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                     const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
+                     int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
 
 /* ---------------------------------------------------------------------------------------------
  * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing

@@ -385,11 +385,12 @@ def rand_next(state):
 
 
 def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, built=None,
-                  cam=None, rows=None, record=None, skybox=None, parts=None):
+                  cam=None, rows=None, record=None, skybox=None, parts=None, frame_streams=False):
     """Viewer.cpp:296-312 call order on the oracle: build, camera, <=depth x (traverse, shade), sample.
     Returns (filtered image [h,w,4], stats). parts: list of triangle-index arrays -- each becomes its own
     hierarchy and every round intersects them one after the other (multi-BVH); the scene's arrays must be
-    ordered part by part."""
+    ordered part by part. frame_streams: the FrameBatch policy -- the stream started by `seed` hands every
+    frame one draw, which seeds that frame's own rand() stream (camera + one draw per shade)."""
     from importlib import import_module
     scenes = import_module("prismarine-core_amd.scenes")
     tris = scene["tris"]
@@ -411,7 +412,10 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
     state = seed
     stats = {"rays": 0, "rounds": [], "node_visits": 0, "tri_tests": 0}
     y0, y1 = rows if rows else (0, height)
+    master = seed
     for f in range(frames):
+        if frame_streams:
+            state, master = rand_next(master)
         t, state = rand_next(state)
         rays, coord, tsum, flag = camera(cfg, cam_inv, proj_inv, t, y0, y1)
         for j in range(depth):

@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -634,6 +634,134 @@ def sharded_rounds(rays, intersector, materials, depth=16):
         rays.intersection(intersector, force=True)
         rays.shade(force=True)
         rays.reclaim()
+
+
+class LaneResult(C.Structure):
+    _fields_ = [("rounds", C.c_uint32), ("rays", C.c_uint64)]
+
+
+class FrameBatch:
+    """Several frames in flight on one GPU (psm_lanes_render): `lanes` independent copies of
+    GltfViewer::process() (Viewer.cpp:296-312), each on its own context / HIP stream with its own
+    TriangleHierarchy and Pipeline, so one frame's traversal tail overlaps the other frames' kernels.
+    lanes[0].rays is the accumulating Pipeline: after a batch the lanes are folded into it in frame order
+    (psm_rt_sample_from), which gives the image the same frames rendered one after another would give.
+
+    rand(): the accumulating stream (setSeed) hands every frame one draw; that draw seeds the frame's own
+    CRT-rand() stand-in, from which its camera() and shade() calls draw (Pipeline.inl:282,426)."""
+
+    class Lane:
+        def __init__(self, ctx, th, rays):
+            self.ctx, self.th, self.rays = ctx, th, rays
+
+    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None):
+        self.n = lanes
+        self.lanes = []
+        for s in range(lanes):
+            ctx = Context(device, stream=None if streams is None else streams[s])
+            th = TriangleHierarchy(ctx)
+            rt = Pipeline(ctx, seed=seed)
+            rt.resizeBuffers(width, height)
+            rt.resize(*(display or (width, height)))
+            self.lanes.append(FrameBatch.Lane(ctx, th, rt))
+        # the accumulating Pipeline only samples: it has its own context so that folding a finished frame
+        # never queues behind a lane's tracing kernels
+        self.master_ctx = Context(device, stream=master_stream)
+        self.master = Pipeline(self.master_ctx, seed=seed)
+        self.master.resizeBuffers(width, height)
+        self.master.resize(*(display or (width, height)))
+        self.width, self.height = width, height
+        self.frames_rendered = 0
+
+    # -- scene: every lane holds the same scene ------------------------------------------------------
+    def allocate(self, n):
+        for ln in self.lanes:
+            ln.th.allocate(n)
+
+    def loadTriangles(self, tris, normals=None, mats=None, texcoords=None):
+        for ln in self.lanes:
+            ln.th.loadTriangles(tris, normals, mats, texcoords)
+
+    def loadMesh(self, mesh):
+        for ln in self.lanes:
+            ln.th.loadMesh(mesh)
+
+    def clearTribuffer(self):
+        for ln in self.lanes:
+            ln.th.clearTribuffer()
+
+    def each(self, fn):
+        """Apply a setter to every lane's Pipeline: batch.each(lambda r: r.setSkybox(img))."""
+        for ln in self.lanes:
+            fn(ln.rays)
+
+    def applyMaterials(self, materials):
+        for ln in self.lanes:
+            ln.rays.applyMaterials(materials)
+
+    def setSeed(self, seed):
+        self.master.setSeed(seed)
+
+    # -- frames -----------------------------------------------------------------------------------------
+    def frame_seeds(self, frames):
+        return [self.master._rand() for _ in range(frames)]
+
+    def trace(self, cam_inv, proj_inv, seeds, depth=16, rebuild=True, optimization=None, fold=True):
+        """len(seeds) frames, up to `lanes` in flight. fold=True: sample() each into the accumulating Pipeline in
+        frame order. fold=False (len(seeds) <= lanes): frame f stays in lane f for the caller to fold.
+        Returns per-frame (rounds, rays)."""
+        k = len(seeds)
+        if k == 0:
+            return []
+        n = min(self.n, k)
+        rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes[:n]])
+        bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
+        sd = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
+        res = (LaneResult * k)()
+        ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
+        pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
+        opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
+        rc = lib().psm_lanes_render(rts, bvhs, C.c_uint32(n), _p(ci), _p(pi), sd, C.c_uint32(k), C.c_uint32(depth),
+                                    C.c_int(int(rebuild)), _p(opt) if opt is not None else None,
+                                    self.master._h if fold else None, res)
+        self.lanes[0].ctx.check(rc, "psm_lanes_render")
+        for ln in self.lanes[:n]:
+            ln.th._dirty = False
+            ln.rays._obj = ln.th
+        return [(res[f].rounds, res[f].rays) for f in range(k)]
+
+    def fold(self, k):
+        """sample() for frames left in lanes 0..k-1 by trace(fold=False), in frame order."""
+        for ln in self.lanes[:k]:
+            self.master.ctx.check(lib().psm_rt_sample_from(self.master._h, ln.rays._h), "psm_rt_sample_from")
+
+    def render(self, frames, eye, view, depth=16, rebuild=True):
+        """`frames` x process() with `lanes` frames in flight; returns per-frame (rounds, rays)."""
+        sc = self.master._sc
+        ci, pi = sc.camera_matrices(eye, view, self.master.displayWidth, self.master.displayHeight)
+        out = self.trace(ci, pi, self.frame_seeds(frames), depth, rebuild)
+        self.frames_rendered += frames
+        return out
+
+    def snapHdr(self, raw=False):
+        return self.master.snapHdr(raw)
+
+    def clearSampler(self):
+        self.master.clearSampler()
+
+    def sync(self):
+        for ln in self.lanes:
+            ln.ctx.sync()
+        self.master_ctx.sync()
+
+    def close(self):
+        for ln in self.lanes:
+            ln.rays.close()
+            ln.th.close()
+            ln.ctx.close()
+        self.lanes = []
+        self.master.close()
+        self.master_ctx.close()
 
 
 def render_frame(rays, intersector, materials, eye, view, depth=16):

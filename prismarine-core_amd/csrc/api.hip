@@ -441,6 +441,9 @@ int psm_rt_destroy(psm_rt* r) {
     (void)hipStreamSynchronize(r->ctx->stream);
     rt_free_grid(r);
     dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table); dev_free(r->d_geoms);
+    if (r->h_cnt) (void)hipHostFree(r->h_cnt);
+    if (r->ev_cnt) (void)hipEventDestroy(r->ev_cnt);
+    if (r->ev_fold) (void)hipEventDestroy(r->ev_fold);
     for (int i = 0; i < MAX_TEXTURES; i++) if (r->tex_host[i].texels) (void)hipFree(const_cast<uint32_t*>(r->tex_host[i].texels));
     delete r;
     return PSM_OK;
@@ -692,7 +695,7 @@ int psm_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
 int psm_rt_sample(psm_rt* r) {
     if (!r || !r->presampled || !r->t_sum) return PSM_ERR_INVALID;
     (void)hipSetDevice(r->ctx->device);
-    return launch_rt_sample(r);
+    return launch_rt_sample(r, r);
 }
 
 int psm_rt_snap(psm_rt* r, float* rgba, int raw) {

@@ -1,0 +1,173 @@
+// lanes.hip -- several frames in flight on one GPU.
+//
+// A bounce round ends with the slowest ray of its traversal launch (a wave running alone takes ~1 us per
+// BVH step), so a single frame leaves most of the chip idle for a good part of every
+// round. The frames of one accumulation (the 4 spp of BASELINE's metric) are independent until the sampler
+// folds them together, so this scheduler keeps `lanes` of them in flight, each on its own context / HIP
+// stream with its own hierarchy and ray buffers: while one frame's traversal drains, the other frames'
+// kernels fill the machine. Every frame is exactly GltfViewer::process() (Viewer.cpp:296-312): build,
+// camera, <= depth x (getRayCount >= 32 ? intersection, shade), sample -- with its own rand() stream, and
+// with sample() issued in frame order on the accumulating Pipeline (psm_rt_sample_from), which makes the
+// image identical to rendering the same frames one after another.
+//
+// Host side only: no kernel lives here. The scheduler is event driven: after each shade it queues an
+// asynchronous read-back of the lane's next ray count and polls the lanes' events, so no lane waits for
+// another one's round; a lane that finishes a frame takes the next one as soon as its frame is folded.
+#include "psm_internal.h"
+
+#include <cstring>
+#include <thread>
+
+namespace psm {
+
+static inline uint32_t lcg_next(uint32_t& state) {  // the CRT rand() stand-in of DESIGN.md 2.1
+    state = state * 214013u + 2531011u;
+    return (state >> 16) & 0x7fffu;
+}
+
+static int lane_resources(psm_rt* r) {
+    psm_ctx* c = r->ctx;
+    if (!r->h_cnt) PSM_HIP(c, hipHostMalloc((void**)&r->h_cnt, sizeof(uint32_t), hipHostMallocDefault));
+    if (!r->ev_cnt) PSM_HIP(c, hipEventCreateWithFlags(&r->ev_cnt, hipEventDisableTiming));
+    if (!r->ev_fold) PSM_HIP(c, hipEventCreateWithFlags(&r->ev_fold, hipEventDisableTiming));
+    return PSM_OK;
+}
+
+enum LaneState { IDLE, RUNNING, FINISHED };
+
+struct Lane {
+    psm_rt* rt = nullptr;
+    psm_bvh* bvh = nullptr;
+    LaneState state = IDLE;
+    int frame = -1;
+    uint32_t rand = 0;
+    uint32_t round = 0;
+    uint64_t rays = 0;
+};
+
+// sample() of `r` fed with src's frame; stream-ordered against both contexts
+static int fold(psm_rt* r, psm_rt* src) {
+    psm_ctx* c = r->ctx;
+    if (r == src || c->stream == src->ctx->stream) return launch_rt_sample(r, src);
+    int rc = lane_resources(src);
+    if (rc != PSM_OK) return rc;
+    PSM_HIP(c, hipEventRecord(src->ev_fold, src->ctx->stream));
+    PSM_HIP(c, hipStreamWaitEvent(c->stream, src->ev_fold, 0));
+    rc = launch_rt_sample(r, src);
+    if (rc != PSM_OK) return rc;
+    PSM_HIP(c, hipEventRecord(src->ev_fold, c->stream));
+    PSM_HIP(c, hipStreamWaitEvent(src->ctx->stream, src->ev_fold, 0));  // src's next camera() waits for the fold
+    return PSM_OK;
+}
+
+}  // namespace psm
+
+using namespace psm;
+
+extern "C" int psm_rt_sample_from(psm_rt* r, psm_rt* src) {
+    if (!r || !src || !r->presampled || !src->t_sum) return PSM_ERR_INVALID;
+    (void)hipSetDevice(r->ctx->device);
+    if (r->w != src->w || r->h != src->h) return set_err(r->ctx, PSM_ERR_INVALID, "psm_rt_sample_from: ray grids differ");
+    return fold(r, src);
+}
+
+extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                                const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
+                                int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results) {
+    if (!rts || !bvhs || !cam_inv || !proj_inv || lanes == 0 || lanes > 64 || (frames && !frame_seeds)) return PSM_ERR_INVALID;
+    for (uint32_t s = 0; s < lanes; s++) {
+        if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
+        for (uint32_t q = 0; q < s; q++)
+            if (rts[q] == rts[s] || rts[q]->ctx->stream == rts[s]->ctx->stream)
+                return set_err(rts[s]->ctx, PSM_ERR_INVALID, "psm_lanes_render: every lane needs its own context (stream) and ray buffers");
+        if (rts[s]->ctx != bvhs[s]->ctx)
+            return set_err(rts[s]->ctx, PSM_ERR_INVALID, "psm_lanes_render: a lane's hierarchy must live on the lane's context");
+        if (fold_into && (fold_into->w != rts[s]->w || fold_into->h != rts[s]->h))
+            return set_err(rts[s]->ctx, PSM_ERR_INVALID, "psm_lanes_render: fold_into and the lanes differ in ray-grid size");
+    }
+    if (!fold_into && frames > lanes)
+        return set_err(rts[0]->ctx, PSM_ERR_INVALID, "psm_lanes_render: more frames than lanes need fold_into (a lane's texel sums are overwritten by its next frame)");
+    (void)hipSetDevice(rts[0]->ctx->device);
+    std::vector<Lane> L(lanes);
+    for (uint32_t s = 0; s < lanes; s++) {
+        L[s].rt = rts[s];
+        L[s].bvh = bvhs[s];
+        int e = lane_resources(rts[s]);
+        if (e != PSM_OK) return e;
+    }
+    int rc = PSM_OK;
+    auto queue_round = [&](Lane& ln) -> int {  // intersection + shade + asynchronous read-back of the next count
+        psm_rt* r = ln.rt;
+        ln.rays += r->ray_count;
+        int e = psm_rt_traverse(r, ln.bvh);
+        if (e != PSM_OK) return e;
+        e = psm_rt_shade(r, ln.bvh, lcg_next(ln.rand));
+        if (e != PSM_OK) return e;
+        ln.round++;
+        PSM_HIP(r->ctx, hipMemcpyAsync(r->h_cnt, r->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, r->ctx->stream));
+        PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
+        return PSM_OK;
+    };
+    auto finish = [&](Lane& ln) {
+        ln.state = FINISHED;
+        if (results) { results[ln.frame].rounds = ln.round; results[ln.frame].rays = ln.rays; }
+    };
+    auto start = [&](Lane& ln, uint32_t f) -> int {
+        ln.frame = (int)f;
+        ln.rand = frame_seeds[f];
+        ln.round = 0;
+        ln.rays = 0;
+        if (rebuild) {
+            int e = psm_bvh_build(ln.bvh, opt);
+            if (e != PSM_OK) return e;
+        }
+        int e = psm_rt_camera(ln.rt, cam_inv, proj_inv, lcg_next(ln.rand));
+        if (e != PSM_OK) return e;
+        if (depth == 0 || ln.rt->ray_count < 32) { finish(ln); return PSM_OK; }  // Pipeline.inl:459-461
+        ln.state = RUNNING;
+        return queue_round(ln);
+    };
+    uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
+    while (rc == PSM_OK && next_fold < frames) {
+        bool progressed = false;
+        for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
+            Lane& ln = L[s];
+            if (ln.state == IDLE && next_frame < frames) {
+                rc = start(ln, next_frame++);
+                progressed = true;
+            } else if (ln.state == RUNNING) {
+                hipError_t q = hipEventQuery(ln.rt->ev_cnt);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) { rc = set_err(ln.rt->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
+                progressed = true;
+                ln.rt->ray_count = *ln.rt->h_cnt;  // what reloadQueuedRays learns (Pipeline.inl:325-359)
+                ln.rt->count_valid = true;
+                if (ln.round >= depth || ln.rt->ray_count < 32) finish(ln);
+                else rc = queue_round(ln);
+            }
+        }
+        // sample() in frame order
+        for (bool again = true; again && rc == PSM_OK;) {
+            again = false;
+            for (uint32_t s = 0; s < lanes; s++) {
+                Lane& ln = L[s];
+                if (ln.state == FINISHED && (uint32_t)ln.frame == next_fold) {
+                    if (fold_into) rc = fold(fold_into, ln.rt);
+                    ln.state = fold_into ? IDLE : FINISHED;
+                    ln.frame = fold_into ? -1 : -2;  // without fold_into the lane keeps its frame (frames <= lanes)
+                    next_fold++;
+                    again = progressed = true;
+                    break;
+                }
+            }
+        }
+        if (!progressed) {
+            if (++idle_spins > 256) std::this_thread::yield();
+        } else {
+            idle_spins = 0;
+        }
+    }
+    for (uint32_t s = 0; s < lanes; s++) (void)hipStreamSynchronize(L[s].rt->ctx->stream);
+    if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
+    return rc;
+}

@@ -132,6 +132,9 @@ struct psm_rt {
     psm_bvh* trav_objs[psm::MAX_TRAV_OBJECTS] = {};  // hierarchies traversed since the queue last changed
     int trav_n = 0;
     psm::ObjGeom* d_geoms = nullptr;
+    // frames in flight (lanes.hip): pinned slot + events, created on first use
+    uint32_t* h_cnt = nullptr;
+    hipEvent_t ev_cnt = nullptr, ev_fold = nullptr;
     uint32_t* d_sky = nullptr;    // equirect RGBA8 skybox (one texel per word) or null
     uint32_t sky_w = 0, sky_h = 0;
     int samples_lock = 4;         // SAMPLES_LOCK, constants.glsl:35
@@ -164,7 +167,7 @@ int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor*
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
-int launch_rt_sample(psm_rt* r);
+int launch_rt_sample(psm_rt* r, psm_rt* src);
 int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b);
 uint32_t tile_texel_count(const psm_rt* r);
 

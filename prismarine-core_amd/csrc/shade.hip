@@ -821,11 +821,11 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     return PSM_OK;
 }
 
-int launch_rt_sample(psm_rt* r) {
+int launch_rt_sample(psm_rt* r, psm_rt* src) {
     psm_ctx* c = r->ctx;
     uint32_t n = r->dw * r->dh;
     TimedScope ts(c, CAT_SAMPLE);
-    rt_sample<<<(n + 255) / 256, 256, 0, c->stream>>>(r->w, r->h, r->dw, r->dh, r->t_coord, r->t_sum, r->t_flag,
+    rt_sample<<<(n + 255) / 256, 256, 0, c->stream>>>(r->w, r->h, r->dw, r->dh, src->t_coord, src->t_sum, src->t_flag,
                                                       r->presampled, r->filtered, r->samples_lock);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;

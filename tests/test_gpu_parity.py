@@ -619,6 +619,44 @@ def test_multi_bvh_radiance_and_union_equivalence(psm, ctx, oracle, scenes):
         th.close()
 
 
+def test_frame_batch_lanes_equal_sequential_frames(psm, oracle, scenes):
+    """psm_lanes_render + psm_rt_sample_from: 5 frames on 3 lanes (two batches, the second one short) give the
+    image of the same 5 frames rendered one after another -- by the oracle (<= 1e-4) and by one Pipeline on
+    the GPU (same deposit counts, radiance to float-atomic order)."""
+    scene = scenes.textured(scenes.cornell(open_top=True))
+    w, h, frames, seed = 64, 48, 5, 4242
+    batch = psm.FrameBatch(3, w, h, seed=seed)
+    batch.allocate(scene["tris"].shape[0])
+    batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene["texcoords"])
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    ts = psm.TextureSet()
+    for slot in sorted(scene["textures"]):
+        ts.loadTexture(scene["textures"][slot])
+    ms.setTextureSet(ts)
+    batch.applyMaterials(ms)
+    per_frame = batch.render(frames, scene["eye"], scene["view"])
+    img = batch.snapHdr()
+    ref, st = oracle.render_frames(scene, w, h, frames=frames, seed=seed, frame_streams=True)
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    assert sum(r for _, r in per_frame) == st["rays"] and sum(n for n, _ in per_frame) == len(st["rounds"])
+    # the same frames, one after another, on a single Pipeline
+    ln = batch.lanes[1]
+    one = ln.rays
+    one.clearSampler()
+    master = psm.Pipeline(ln.ctx, seed=seed)   # only its rand() stream is used
+    for _ in range(frames):
+        one.setSeed(master._rand())
+        psm.render_frame(one, ln.th, ms, scene["eye"], scene["view"])
+    seq = one.snapHdr()
+    np.testing.assert_allclose(img[..., :3], seq[..., :3], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(img[..., 3], seq[..., 3])
+    master.close()
+    batch.close()
+
+
 def _sky_image(w=64, h=32):
     yy, xx = np.mgrid[0:h, 0:w]
     img = np.zeros((h, w, 4), np.uint8)
