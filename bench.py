@@ -67,9 +67,14 @@ class Renderer:
             stream = dist.torch.cuda.current_stream().cuda_stream
             dist.same_stream = True
         w, h = args.width, args.height
-        self.lanes = 1 if dist.active else max(1, args.lanes)
-        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000,
-                                    streams=[stream] if stream is not None else None)
+        self.lanes = max(1, args.lanes)
+        self.lane_streams = None
+        streams = None
+        if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
+            torch = dist.torch
+            self.lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(self.lanes - 1)]
+            streams = [st.cuda_stream for st in self.lane_streams]
+        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams)
         self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
         self.batch.allocate(scene["tris"].shape[0])
         self.batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
@@ -82,23 +87,70 @@ class Renderer:
                 assert ts.loadTexture(scene["textures"][slot]) == slot
             self.ms.setTextureSet(ts)
         self.batch.applyMaterials(self.ms)
-        if dist.active:
-            self.rt.setTileInterleaved(dist.rank, dist.world)  # 8-row bands dealt round-robin
+        if dist.active and not (args.emulate_tile and dist.world == 1):
+            self.batch.each(lambda r: r.setTileInterleaved(dist.rank, dist.world))  # 8-row bands dealt round-robin
             dist.initial_total = w * h
         elif args.emulate_tile:
             r_, w_ = (int(v) for v in args.emulate_tile.split("/"))
             self.batch.each(lambda r: r.setTileInterleaved(r_, w_))
+            dist.initial_total = self.rt.tile_texels()
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if dist.active:
             torch = dist.torch
             gdev = torch.device("cuda", dist.device_index)
             self.per = self.pdist.interleaved_texels(0, dist.world, w, h) * 4  # rank 0 owns the most bands
             self.tile_dev = torch.zeros(self.per, dtype=torch.float32, device=gdev)
+            self.lane_tiles = [self.tile_dev] + [torch.zeros(self.per, dtype=torch.float32, device=gdev) for _ in range(self.lanes - 1)]
             self.all_dev = torch.zeros(dist.world * self.per, dtype=torch.float32, device=gdev) if dist.rank == 0 else None
 
     def frames_in_flight(self, k):
         """k x process() with `lanes` frames in flight (native scheduler), folded in frame order."""
         return self.batch.render(k, self.scene["eye"], self.scene["view"], depth=self.args.depth)
+
+    def frames_in_flight_sharded(self, k):
+        """k x process() of a tile-sharded frame with `lanes` frames in flight on every rank: the lanes' kernels
+        overlap inside a round, one count exchange per round serves all lanes (dist.run_rounds_lanes), one
+        gather per frame, rank 0 folds the frames in order. Returns the rays this rank traced."""
+        dist, batch, ms = self.dist, self.batch, self.ms
+        torch = dist.torch
+        w, h = self.args.width, self.args.height
+        traced = 0
+        for f0 in range(0, k, self.lanes):
+            seeds = batch.frame_seeds(min(self.lanes, k - f0))
+            lanes = batch.lanes[: len(seeds)]
+            before = [ln.ctx.stats().rays_traced for ln in lanes]
+            if dist.backend == "nccl":
+                self.pdist.run_batch_sharded(dist, batch, self.cam[0], self.cam[1], seeds, self.args.depth)
+            else:  # host-exchange rehearsal path (gloo)
+                for ln, sd in zip(lanes, seeds):
+                    ln.rays.setSeed(sd)
+                    ms.loadToVGA()
+                    ln.th.markDirty()
+                    ln.th.build()
+                    ln.rays.camera_matrices(self.cam[0], self.cam[1])
+                self.pdist.run_rounds_lanes(dist, [(ln.rays, ln.th, ms) for ln in lanes], self.args.depth,
+                                            initial_totals=[dist.initial_total] * len(lanes))
+            traced += sum(ln.ctx.stats().rays_traced - b for ln, b in zip(lanes, before))
+            for s, ln in enumerate(lanes):  # frame order
+                ln.rays.pack_texels_dev(self.lane_tiles[s].data_ptr())
+                if dist.backend == "nccl":
+                    main = torch.cuda.current_stream()
+                    main.wait_stream(self.lane_streams[s])
+                    dist.gather_to_root(self.lane_tiles[s], self.all_dev)
+                    self.lane_streams[s].wait_stream(main)  # the lane's next pack / unpack comes after the gather
+                else:  # host-staged rehearsal path (gloo)
+                    ln.ctx.sync()
+                    got = dist.gather_to_root(self.lane_tiles[s].cpu())
+                    if dist.rank == 0:
+                        self.all_dev.copy_(got)
+                        torch.cuda.synchronize()
+                if dist.rank == 0:
+                    for r in range(1, dist.world):
+                        ln.rays.unpack_texels_dev(True, r, dist.world, self.all_dev.data_ptr() + r * self.per * 4)
+                    if dist.backend == "nccl":  # all_dev is reused by the next lane's gather
+                        torch.cuda.current_stream().wait_stream(self.lane_streams[s])
+                    batch.fold_one(ln)
+        return traced
 
     def frame(self, record=None):
         """GltfViewer::process(), Viewer.cpp:296-312 (display excluded): one frame on lane 0, with the rand()
@@ -180,6 +232,7 @@ def pmc_traffic(kernel):
 
 def main():
     args = parse()
+    os.environ["NCCL_DEBUG"] = os.environ.get("PSM_NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
     psm = importlib.import_module("prismarine-core_amd")
     pdist = importlib.import_module("prismarine-core_amd.dist")
@@ -190,14 +243,12 @@ def main():
         scene = scenes.textured(scene)
     R = Renderer(psm, scenes, scene, args, dist)
     ctx = R.ctx
-    lanes_mode = not dist.active
+    lanes_mode = True
 
-    def run_steps(k, record=None):
-        if lanes_mode:
-            return sum(r for _, r in R.frames_in_flight(k))
-        for i in range(k):
-            R.frame(record=record if i == 0 else None)
-        return None
+    def run_steps(k):
+        if dist.active:
+            return R.frames_in_flight_sharded(k)
+        return sum(r for _, r in R.frames_in_flight(k))
 
     def reseed():
         R.batch.setSeed(1000)
@@ -224,6 +275,7 @@ def main():
     # stream): per-stage times and the traversal kernel's own launch duration for the roofline
     if lanes_mode:
         reseed()
+        R.batch.sync()
         ctx.stats_enable(True, False)
         ctx.stats_reset()
         for i in range(args.steps):
@@ -235,8 +287,6 @@ def main():
 
     # timed region: exactly K steps
     reseed()
-    if not lanes_mode:
-        ctx.stats_enable(True, False)
     ctx.stats_reset()
     dist.barrier()
     R.batch.sync()
@@ -246,16 +296,12 @@ def main():
     dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = dist.max_float(elapsed)
-    if lanes_mode:
-        st = kst
-        assert traced == Rr, (traced, Rr)
-    else:
-        st = ctx.stats()
-        assert st.rays_traced == Rr, (st.rays_traced, Rr)
+    st = kst
+    assert traced == Rr, (traced, Rr)
     total_rays = dist.sum_int(int(Rr))
 
     if dist.rank == 0:
-        img = (R.batch if lanes_mode else R.rt).snapHdr()
+        img = R.batch.snapHdr()
         alg_bytes = Rr * 44 + V * 64 + T * 36
         launches = max(st.traverse_launches, 1)
         traffic, traffic_src = pmc_traffic("rt_traverse") if (world == 1 and args.scene == "sponza_like" and

@@ -275,6 +275,18 @@ typedef struct {
 int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
                      const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
                      int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
+/* The same frames when they are tile-sharded over several GPUs: the `fewer than 32 rays -> stop` rule then looks
+ * at each frame's GLOBAL count. A rank with >= 32 local rays knows the global count is >= 32 too, so every lane
+ * runs free (as above) until its LOCAL count drops below 32 or `depth` is reached, and then parks with its queue
+ * intact. Returns when all lanes are parked: rounds[s] = rounds done, counts_out[s] = local rays waiting. The host
+ * exchanges those (one small all-gather per batch as a rule: the tiles of a frame run dry in the same round) and,
+ * where a frame's global count says it goes on, calls again with start = 0 and force_until[s] = the round lane s
+ * must reach whatever its local count (it traces its few rays, or none, drawing its rand() every round so the
+ * ranks stay in step). start != 0 begins new frames: build (if rebuild) + camera, rounds[] reset.
+ * rand_state[s]: the frame's CRT-rand() stand-in state, in/out across calls. */
+int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                          const float proj_inv[16], uint32_t* rand_state, uint32_t* rounds, const uint32_t* force_until,
+                          uint32_t depth, int start, int rebuild, const double* opt, int32_t* counts_out);
 
 /* ---------------------------------------------------------------------------------------------
  * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing

@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -734,6 +734,35 @@ class FrameBatch:
         """sample() for frames left in lanes 0..k-1 by trace(fold=False), in frame order."""
         for ln in self.lanes[:k]:
             self.master.ctx.check(lib().psm_rt_sample_from(self.master._h, ln.rays._h), "psm_rt_sample_from")
+
+    # -- tile-sharded frames: lanes run free until their LOCAL count parks them (dist.run_batch_sharded) ----
+    def run_sharded(self, seeds=None, cam_inv=None, proj_inv=None, force_until=None, depth=16, rebuild=True):
+        """seeds given: begin len(seeds) frames (frame f on lane f) and run them until every lane is parked.
+        seeds None: resume the parked frames, lane s at least up to round force_until[s].
+        Returns (rounds, local_counts) per lane."""
+        if seeds is not None:
+            k = len(seeds)
+            self._k = k
+            self._rts = (C.c_void_p * k)(*[ln.rays._h for ln in self.lanes[:k]])
+            self._bvhs = (C.c_void_p * k)(*[ln.th._h for ln in self.lanes[:k]])
+            self._state = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
+            self._rounds = (C.c_uint32 * k)()
+            self._cam = (np.ascontiguousarray(cam_inv, np.float32).reshape(16), np.ascontiguousarray(proj_inv, np.float32).reshape(16))
+        k = self._k
+        fu = (C.c_uint32 * k)(*([0] * k if force_until is None else [int(v) for v in force_until]))
+        counts = (C.c_int32 * k)()
+        rc = lib().psm_lanes_run_sharded(self._rts, self._bvhs, C.c_uint32(k), _p(self._cam[0]), _p(self._cam[1]), self._state,
+                                         self._rounds, fu, C.c_uint32(depth), C.c_int(int(seeds is not None)),
+                                         C.c_int(int(rebuild)), None, counts)
+        self.lanes[0].ctx.check(rc, "psm_lanes_run_sharded")
+        if seeds is not None:
+            for ln in self.lanes[:k]:
+                ln.th._dirty = False
+                ln.rays._obj = ln.th
+        return list(self._rounds), list(counts)
+
+    def fold_one(self, lane):
+        self.master.ctx.check(lib().psm_rt_sample_from(self.master._h, lane.rays._h), "psm_rt_sample_from")
 
     def render(self, frames, eye, view, depth=16, rebuild=True):
         """`frames` x process() with `lanes` frames in flight; returns per-frame (rounds, rays)."""

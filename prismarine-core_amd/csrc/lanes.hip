@@ -171,3 +171,80 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
     return rc;
 }
+
+// ---- tile-sharded frames: free-running lanes that park instead of stopping ------------------------------
+//
+// With the frame sharded over several GPUs the `fewer than 32 rays -> stop` rule (Pipeline.inl:459-461) looks
+// at the frame's GLOBAL count. A rank whose local count is >= 32 knows the global one is too and needs nobody;
+// only a rank with fewer than 32 local rays has to ask. So every lane runs free, exactly as above, until its
+// local count drops below 32 (or `depth` is reached) and then PARKS, keeping its queue. The host exchanges
+// (round, count) of all lanes once everybody is parked -- normally once per batch, because the tiles of a frame
+// run dry in the same round -- and, where the global count says the frame goes on, calls again with
+// force_until[lane] = the round the lane has to reach regardless of its local count (it traces its few rays,
+// or none, and draws its rand() every round so the ranks stay in step).
+extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                                     const float proj_inv[16], uint32_t* rand_state, uint32_t* rounds,
+                                     const uint32_t* force_until, uint32_t depth, int start, int rebuild, const double* opt,
+                                     int32_t* counts_out) {
+    if (!rts || !bvhs || !rand_state || !rounds || !force_until || !counts_out || lanes == 0 || lanes > 64) return PSM_ERR_INVALID;
+    if (start && (!cam_inv || !proj_inv)) return PSM_ERR_INVALID;
+    for (uint32_t s = 0; s < lanes; s++) {
+        if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
+        int e = lane_resources(rts[s]);
+        if (e != PSM_OK) return e;
+    }
+    (void)hipSetDevice(rts[0]->ctx->device);
+    std::vector<LaneState> st(lanes, IDLE);  // RUNNING = a round is in flight, FINISHED = parked
+    int rc = PSM_OK;
+    auto step = [&](uint32_t s) -> int {  // park, or queue one more round
+        psm_rt* r = rts[s];
+        if (rounds[s] >= depth || (r->ray_count < 32 && rounds[s] >= force_until[s])) { st[s] = FINISHED; return PSM_OK; }
+        uint32_t t = lcg_next(rand_state[s]);  // drawn every round, ray or no ray
+        rounds[s]++;
+        if (r->ray_count == 0) return PSM_OK;  // nothing to trace: the lane is re-examined at once
+        int e = psm_rt_traverse(r, bvhs[s]);
+        if (e != PSM_OK) return e;
+        e = psm_rt_shade(r, bvhs[s], t);
+        if (e != PSM_OK) return e;
+        PSM_HIP(r->ctx, hipMemcpyAsync(r->h_cnt, r->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, r->ctx->stream));
+        PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
+        st[s] = RUNNING;
+        return PSM_OK;
+    };
+    for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
+        if (start) {
+            rounds[s] = 0;
+            if (rebuild) rc = psm_bvh_build(bvhs[s], opt);
+            if (rc == PSM_OK) rc = psm_rt_camera(rts[s], cam_inv, proj_inv, lcg_next(rand_state[s]));
+        }
+        while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+    }
+    uint32_t idle_spins = 0;
+    for (;;) {
+        if (rc != PSM_OK) break;
+        bool any = false, progressed = false;
+        for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
+            if (st[s] != RUNNING) continue;
+            any = true;
+            hipError_t q = hipEventQuery(rts[s]->ev_cnt);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
+            progressed = true;
+            rts[s]->ray_count = *rts[s]->h_cnt;
+            rts[s]->count_valid = true;
+            st[s] = IDLE;
+            while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+        }
+        if (!any) break;
+        if (!progressed) {
+            if (++idle_spins > 256) std::this_thread::yield();
+        } else {
+            idle_spins = 0;
+        }
+    }
+    for (uint32_t s = 0; s < lanes; s++) {
+        (void)hipStreamSynchronize(rts[s]->ctx->stream);
+        counts_out[s] = (int32_t)rts[s]->ray_count;
+    }
+    return rc;
+}

@@ -69,6 +69,14 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def sum_ints(self, values):
+        """Element-wise sum over ranks of a short list of ints (host path)."""
+        if not self.active:
+            return [int(v) for v in values]
+        t = self.torch.tensor([int(v) for v in values], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t)
+        return [int(v) for v in t.cpu().tolist()]
+
     def gather_to_root(self, tile, root_out=None):
         """Gather equally sized 1-D tensors to rank 0. Returns the concatenated tensor on rank 0
         (root_out if given), None elsewhere. `tile` must live on self.dev."""
@@ -141,3 +149,101 @@ def run_rounds(comm, rays, intersector, materials, depth=16, on_round=None):
         rays.set_ray_count(local)
         rounds += 1
     return rounds
+
+
+def run_rounds_lanes(comm, lanes, depth=16, lane_streams=None, initial_totals=None):
+    """The bounce loops of several frames in flight on this rank's tile (one frame per lane, each lane a
+    (rays, intersector, materials) triple whose camera() has already run), in lock step with the other ranks:
+    every round each live lane queues intersection + shade on its own stream, then ONE exchange carries all
+    lanes' ray counts, and the `getRayCount() < 32 -> stop` rule is applied per frame to its GLOBAL count.
+    Returns the number of rounds each frame ran.
+
+    lane_streams (torch streams the lanes' contexts were created on, backend nccl): the counts stay on the
+    device -- each lane copies its count into its slot of one tensor on its stream, the current stream waits
+    for the lanes and all-gathers the tensor, one host read per round. Without it counts go through the host."""
+    n = len(lanes)
+    for rays, _, materials in lanes:
+        rays.applyMaterials(materials)
+    local = [rays.raycountCache for rays, _, _ in lanes]
+    totals = list(initial_totals) if initial_totals is not None else comm.sum_ints(local)
+    rounds = [0] * n
+    device_exchange = lane_streams is not None and comm.active and comm.backend == "nccl"
+    if device_exchange:
+        torch, dist = comm.torch, comm.dist
+        cnt = torch.zeros(n, dtype=torch.int32, device=comm.dev)
+        allc = torch.zeros(comm.world * n, dtype=torch.int32, device=comm.dev)
+        main = torch.cuda.current_stream()
+    for _ in range(depth):
+        live = [s for s in range(n) if totals[s] >= 32]
+        if not live:
+            break
+        for s in live:
+            rays, intersector, _ = lanes[s]
+            rays.intersection(intersector, force=True)
+            rays.shade(force=True, reload=False) if device_exchange else rays.shade(force=True)
+            rays.reclaim()
+            rounds[s] += 1
+            if device_exchange:
+                rays.ray_count_dev(cnt.data_ptr() + 4 * s)
+        if device_exchange:
+            for s in live:
+                main.wait_stream(lane_streams[s])
+            dist.all_gather_into_tensor(allc, cnt)
+            counts = allc.cpu().view(comm.world, n)  # the one host synchronisation of the round
+            for s in range(n):
+                if s in live:
+                    lanes[s][0].set_ray_count(int(counts[comm.rank, s]))
+                    totals[s] = int(counts[:, s].sum())
+                else:
+                    totals[s] = 0
+            for s in live:  # the next round's kernels must not overtake the exchange's read of cnt
+                lane_streams[s].wait_stream(main)
+        else:
+            local = [lanes[s][0].raycountCache if s in live else 0 for s in range(n)]
+            totals = comm.sum_ints(local)
+    return rounds
+
+
+def decide_sharded(all_rounds, all_counts, depth):
+    """The stop rule of tile-sharded frames from what the ranks report once all their lanes are parked.
+    all_rounds / all_counts: [world][lanes] (rounds done, local rays waiting). Returns per lane
+    (over, force_until): a rank that is behind the furthest one catches up (any round below the furthest rank's
+    had >= 32 rays there alone); with every rank at the same round the global count decides -- fewer than 32
+    (or `depth` reached) ends the frame (Pipeline.inl:459-461), otherwise everybody runs one more round."""
+    world, n = len(all_rounds), len(all_rounds[0])
+    out = []
+    for s in range(n):
+        rs = [all_rounds[r][s] for r in range(world)]
+        pmax = max(rs)
+        if min(rs) < pmax:
+            out.append((False, pmax))
+        elif pmax >= depth or sum(all_counts[r][s] for r in range(world)) < 32:
+            out.append((True, pmax))
+        else:
+            out.append((False, pmax + 1))
+    return out
+
+
+def run_batch_sharded(comm, batch, cam_inv, proj_inv, seeds, depth):
+    """len(seeds) tile-sharded frames in flight on this rank (FrameBatch lanes, backend nccl). The lanes run free
+    on the native scheduler until their local counts park them (psm_lanes_run_sharded); then ONE small
+    all-gather tells every rank where the others stand and decide_sharded() applies the `< 32 rays -> stop`
+    rule to each frame's global count; frames that go on are resumed. Returns rounds per frame."""
+    torch, dist = comm.torch, comm.dist
+    k = len(seeds)
+    rounds, counts = batch.run_sharded(seeds, cam_inv, proj_inv, depth=depth)
+    over = [False] * k
+    while True:
+        mine = torch.tensor([rounds, counts], dtype=torch.int32).to(comm.dev)
+        allv = torch.empty(comm.world * 2 * k, dtype=torch.int32, device=comm.dev)
+        dist.all_gather_into_tensor(allv, mine.view(-1))
+        allv = allv.cpu().view(comm.world, 2, k).tolist()
+        verdict = decide_sharded([a[0] for a in allv], [a[1] for a in allv], depth)
+        force = []
+        for s in range(k):
+            over[s] = over[s] or verdict[s][0]
+            force.append(rounds[s] if over[s] else verdict[s][1])
+        if all(over):
+            return rounds
+        # a finished frame's lane stays parked: its count is < 32 and force_until equals its round
+        rounds, counts = batch.run_sharded(None, force_until=force, depth=depth)

@@ -85,6 +85,152 @@ def _worker(rank, world, port, w, h, out_path):
     comm.close()
 
 
+def _worker_lanes(rank, world, port, w, h, seeds, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PSM_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import torch
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    scenes = importlib.import_module("prismarine-core_amd.scenes")
+    from oracle import oracle as O
+    comm = pdist.Comm(world, backend="gloo")
+    scene = scenes.cornell(open_top=True)
+    y0, y1, per = pdist.tile_rows(comm.rank, world, h)
+    lanes = [OraclePipeline(O, scenes, scene, w, h, y0, y1, seed=sd) for sd in seeds]
+    rounds = pdist.run_rounds_lanes(comm, [(rt, None, None) for rt in lanes], depth=16)
+    merged = []
+    for rt in lanes:  # one gather per frame, in frame order
+        tile = torch.zeros(per * w * 4, dtype=torch.float32)
+        tile[: (y1 - y0) * w * 4] = torch.from_numpy(rt.tsum[y0 * w:y1 * w].reshape(-1).copy())
+        allt = comm.gather_to_root(tile)
+        if comm.rank == 0:
+            m = np.zeros((w * h, 4), np.float32)
+            for r in range(world):
+                a, b, _ = pdist.tile_rows(r, world, h)
+                m[a * w:b * w] = allt[r * per * w * 4: r * per * w * 4 + (b - a) * w * 4].numpy().reshape(-1, 4)
+            merged.append(m)
+    if comm.rank == 0:
+        np.save(out_path, np.stack(merged))
+        np.save(out_path + ".rounds.npy", np.asarray(rounds))
+    comm.close()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_frames_in_flight_equal_unsharded(tmp_path, oracle, scenes):
+    """dist.run_rounds_lanes: two frames in flight per rank, lock step on each frame's own global ray count."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    w, h, seeds = 36, 30, (5, 977)
+    out = str(tmp_path / "lanes.npy")
+    mp.spawn(_worker_lanes, args=(2, port, w, h, seeds, out), nprocs=2, join=True)
+    merged = np.load(out)
+    rounds = np.load(out + ".rounds.npy")
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    for f, sd in enumerate(seeds):
+        full = OraclePipeline(oracle, scenes, scenes.cornell(open_top=True), w, h, 0, h, seed=sd)
+        r = pdist.run_rounds(pdist.Comm(1), full, None, None)
+        assert r == rounds[f]
+        np.testing.assert_allclose(merged[f][:, :3], full.tsum[:, :3], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(merged[f][:, 3], full.tsum[:, 3])
+    assert not np.array_equal(merged[0], merged[1])
+
+
+def _park_run(lanes, rounds, force, depth):
+    """psm_lanes_run_sharded's stepping rule (lanes.hip) on oracle pipelines: run until the LOCAL count parks."""
+    for s, rt in enumerate(lanes):
+        while not (rounds[s] >= depth or (rt.raycountCache < 32 and rounds[s] >= force[s])):
+            rt.intersection(None, force=True)
+            rt.shade(force=True)
+            rounds[s] += 1
+    return [rt.raycountCache for rt in lanes]
+
+
+def _worker_parked(rank, world, port, w, h, seeds, rows, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PSM_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as tdist
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    scenes = importlib.import_module("prismarine-core_amd.scenes")
+    from oracle import oracle as O
+    comm = pdist.Comm(world, backend="gloo")
+    scene = scenes.cornell(open_top=True)
+    y0, y1 = rows[rank]
+    lanes = [OraclePipeline(O, scenes, scene, w, h, y0, y1, seed=sd) for sd in seeds]
+    k, depth = len(seeds), 16
+    rounds = [0] * k
+    counts = _park_run(lanes, rounds, [0] * k, depth)
+    over, exchanges = [False] * k, 0
+    while True:
+        mine = torch.tensor([rounds, counts], dtype=torch.int32)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        tdist.all_gather(allv, mine)
+        exchanges += 1
+        verdict = pdist.decide_sharded([a[0].tolist() for a in allv], [a[1].tolist() for a in allv], depth)
+        force = []
+        for s in range(k):
+            over[s] = over[s] or verdict[s][0]
+            force.append(rounds[s] if over[s] else verdict[s][1])
+        if all(over):
+            break
+        counts = _park_run(lanes, rounds, force, depth)
+    per = max(b - a for a, b in rows)
+    merged = []
+    for rt in lanes:
+        tile = torch.zeros(per * w * 4, dtype=torch.float32)
+        tile[: (y1 - y0) * w * 4] = torch.from_numpy(rt.tsum[y0 * w:y1 * w].reshape(-1).copy())
+        allt = comm.gather_to_root(tile)
+        if comm.rank == 0:
+            m = np.zeros((w * h, 4), np.float32)
+            for r in range(world):
+                a, b = rows[r]
+                m[a * w:b * w] = allt[r * per * w * 4: r * per * w * 4 + (b - a) * w * 4].numpy().reshape(-1, 4)
+            merged.append(m)
+    if comm.rank == 0:
+        np.save(out_path, np.stack(merged))
+        np.save(out_path + ".meta.npy", np.asarray(rounds + [exchanges]))
+    comm.close()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_parking_protocol_equals_unsharded(tmp_path, oracle, scenes):
+    """The free-running sharded protocol (lanes park on their LOCAL count, dist.decide_sharded applies the stop rule
+    to the GLOBAL one): a rank whose tile dies early has to catch up and keep drawing rand() in step."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    w, h, seeds = 36, 30, (5, 977)
+    rows = ((0, 2), (2, h))  # rank 0 owns two rows: its local count drops below 32 rounds before the frame ends
+    out = str(tmp_path / "parked.npy")
+    mp.spawn(_worker_parked, args=(2, port, w, h, seeds, rows, out), nprocs=2, join=True)
+    merged = np.load(out)
+    meta = np.load(out + ".meta.npy")
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    for f, sd in enumerate(seeds):
+        full = OraclePipeline(oracle, scenes, scenes.cornell(open_top=True), w, h, 0, h, seed=sd)
+        r = pdist.run_rounds(pdist.Comm(1), full, None, None)
+        assert r == meta[f]
+        np.testing.assert_allclose(merged[f][:, :3], full.tsum[:, :3], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(merged[f][:, 3], full.tsum[:, 3])
+    assert meta[-1] >= 2  # the early-parked rank needed at least one catch-up exchange
+
+
+def test_decide_sharded_rules():
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    d = pdist.decide_sharded
+    assert d([[4], [4]], [[3], [7]], 16) == [(True, 4)]            # same round, 10 rays in all: frame over
+    assert d([[4], [4]], [[20], [20]], 16) == [(False, 5)]         # same round, 40 rays in all: one more round
+    assert d([[2], [5]], [[0], [9]], 16) == [(False, 5)]           # rank 0 is behind: catch up to round 5
+    assert d([[16], [16]], [[500], [900]], 16) == [(True, 16)]     # depth reached
+    assert d([[3, 4], [3, 2]], [[1, 0], [2, 31]], 16) == [(True, 3), (False, 4)]
+
+
 def test_tile_rows_cover_the_frame():
     pdist = importlib.import_module("prismarine-core_amd.dist")
     for world in (1, 2, 3, 4, 8):
