@@ -9,8 +9,11 @@
 
 namespace NSM {
 
+    class FrameBatch;
+
     class Pipeline : public BaseClass {
     protected:
+        friend class FrameBatch;
         GLuint skybox = GLuint(-1);
         psm_rt * rt = nullptr;
         TriangleHierarchy * lastObj = nullptr;
@@ -80,5 +83,6 @@ namespace NSM {
         void setTile(uint32_t y0, uint32_t y1) { check(psm_rt_set_tile(rt, y0, y1), "Pipeline::setTile"); }
         void setSky(const glm::vec4 & rgba) { check(psm_rt_set_sky(rt, glm::value_ptr(rgba)), "Pipeline::setSky"); }
         psm_rt * handle() { return rt; }
+        void noteTraced(TriangleHierarchy * obj) { lastObj = obj; raycountCache = 0; }   // after psm_lanes_render: the frame is over
     };
 }

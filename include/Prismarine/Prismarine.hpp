@@ -8,3 +8,4 @@
 #include "MaterialSet.hpp"
 #include "TriangleHierarchy.hpp"
 #include "Pipeline.hpp"
+#include "FrameBatch.hpp"   // addition: several frames in flight (psm_lanes_render)

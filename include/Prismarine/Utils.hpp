@@ -36,8 +36,18 @@ namespace NSM {
     template<class T>
     size_t strided(size_t sizeo) { return sizeof(T) * sizeo; }
 
+    // Like a GL context, one psm context is "current": objects are created in it. ContextScope makes another
+    // one current for a while (FrameBatch creates each lane's objects in the lane's own context).
+    inline psm_ctx *& currentContextOverride() { static thread_local psm_ctx * c = nullptr; return c; }
+    struct ContextScope {
+        psm_ctx * prev;
+        explicit ContextScope(psm_ctx * c) : prev(currentContextOverride()) { currentContextOverride() = c; }
+        ~ContextScope() { currentContextOverride() = prev; }
+    };
+
     // the process-wide context: device from PSM_DEVICE (default 0); created on first use
     inline psm_ctx * context() {
+        if (currentContextOverride()) return currentContextOverride();
         static psm_ctx * ctx = nullptr;
         if (!ctx) {
             const char * e = std::getenv("PSM_DEVICE");

@@ -1,6 +1,7 @@
 // Drop-in check: the call sequence of the reference's GltfViewer::init/process
 // (Source/Examples/Viewer.cpp:56-63, 231-242, 296-312) written against include/Prismarine.
-// usage: viewer_order <triangles.bin> <w> <h> <frames> <out.bin>
+// usage: viewer_order <triangles.bin> <w> <h> <frames> <out.bin> [lanes]
+//   lanes given: the same frames through psm::FrameBatch (several frames in flight, FrameBatch.hpp)
 //   triangles.bin: int32 n, then n*9 float positions, n*9 float normals, n int32 material ids,
 //                  int32 m, then m * (4 float diffuse, 4 float specular)
 #include <cstdio>
@@ -27,12 +28,33 @@ int main(int argc, char ** argv) {
     uint32_t w = (uint32_t)std::atoi(argv[2]), h = (uint32_t)std::atoi(argv[3]);
     int frames = std::atoi(argv[4]);
 
+    int lanes = argc > 6 ? std::atoi(argv[6]) : 0;
+
     // GltfViewer::init
     psm::MaterialSet * materialManager = new psm::MaterialSet();
     for (int i = 0; i < m; i++) {
         psm::VirtualMaterial vm = psm::makeMaterial();
         for (int k = 0; k < 4; k++) { vm.diffuse[k] = md[8 * i + k]; vm.specular[k] = md[8 * i + 4 + k]; }
         materialManager->addSubmat(vm);
+    }
+    if (lanes > 0) {   // frames x process() with `lanes` of them in flight
+        psm::FrameBatch batch((uint32_t)lanes, w, h);
+        batch.setSeed(31337);
+        batch.allocate((size_t)n);
+        batch.clearTribuffer();
+        batch.loadTriangles(pos.data(), nrm.data(), mats.data(), (size_t)n);
+        batch.applyMaterials(materialManager);
+        batch.render((uint32_t)frames, glm::vec3(eye[0], eye[1], eye[2]), glm::vec3(view[0], view[1], view[2]), 16);
+        psm::Pipeline::HdrImage bi = batch.accumulator()->snapHdr();
+        FILE * bo = std::fopen(argv[5], "wb");
+        std::fwrite(bi.image, 4, (size_t)bi.width * bi.height * 4, bo);
+        std::fclose(bo);
+        delete[] bi.image;
+        uint64_t traced = 0;
+        for (auto & r : batch.lastResults) traced += r.rays;
+        std::printf("frames %d lanes %d rays %llu\n", frames, lanes, (unsigned long long)traced);
+        delete materialManager;
+        return 0;
     }
     psm::Pipeline * rays = new psm::Pipeline();
     rays->setSeed(31337);

@@ -736,3 +736,11 @@ def test_cpp_header_layer_viewer_call_order(psm, ctx, oracle, scenes, tmp_path):
     assert abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) < 0.02 * float(ref[..., :3].mean())
     close = np.abs(img[..., :3] - ref[..., :3]).max(-1) < 2e-3 + 1e-2 * ref[..., :3].max(-1)
     assert close.mean() > 0.9
+    # the same program through psm::FrameBatch: 5 frames, 3 in flight
+    out2 = str(tmp_path / "img_lanes.bin")
+    subprocess.check_call([exe, inp, str(w), str(h), "5", out2, "3"])
+    img2 = np.fromfile(out2, np.float32).reshape(h, w, 4)
+    ref2, _ = oracle.render_frames(sc, w, h, frames=5, seed=31337, frame_streams=True)
+    assert abs(float(img2[..., :3].mean()) - float(ref2[..., :3].mean())) < 0.02 * float(ref2[..., :3].mean())
+    close2 = np.abs(img2[..., :3] - ref2[..., :3]).max(-1) < 2e-3 + 1e-2 * ref2[..., :3].max(-1)
+    assert close2.mean() > 0.9
