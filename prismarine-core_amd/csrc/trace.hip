@@ -146,26 +146,67 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     int cur = root;
     int sp = 0;
     int it = 0;
-    for (; it < MAX_ITERS; it++) {
-        if (!validBox) break;
-        const uint4* np = node32 + 2 * (size_t)cur;
-        uint4 n0 = np[0], n1 = np[1];
-        int2 lk = make_int2((int)n1.z, (int)n1.w);
-        if (COUNT) nV++;
-        Slab L = slab_child(divident, norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
-        Slab R = slab_child(divident, norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
-        bool leftNear = lessEqualF(L.near, R.near);  // :414
-        bool ogL = (L.hit <= IP) && (L.hit * dirlenInv <= IP) && (L.hit > -PZERO) && (L.near <= IP) &&
-                   (L.near * dirlenInv <= IP) && (((L.near + toffset) * dirlenInv - PZERO) <= predist);
-        bool ogR = (R.hit <= IP) && (R.hit * dirlenInv <= IP) && (R.hit > -PZERO) && (R.near <= IP) &&
-                   (R.near * dirlenInv <= IP) && (((R.near + toffset) * dirlenInv - PZERO) <= predist);
-        bool leafL = ogL && lk.x < 0, leafR = ogR && lk.y < 0;
-        bool intL = ogL && lk.x >= 0, intR = ogR && lk.y >= 0;
-
-        if (leafL || leafR) {  // :441-448 -> testIntersectionPacked :261-309
-            bool leftOrder = (leafL && leafR) ? leftNear : leafL;
-            int triL = leafL ? ~lk.x : -1, triR = leafR ? ~lk.y : -1;
-            int tx = leftOrder ? triL : triR, ty = leftOrder ? triR : triL;
+    // Leaf tests are deferred, not reordered: a lane that reaches a leaf parks its triangle pair (pl, pr) and
+    // sits out the node steps of the others until enough lanes of the wave are parked (or nobody can step),
+    // then all of them run the triangle block together. Per ray the sequence of node steps and triangle
+    // tests is exactly the reference's (:441-476) -- a parked lane does nothing in between -- but the wave
+    // issues the ~150-instruction triangle block for ~half its live lanes instead of for 3-4 of them.
+    int pl = -1, pr = -1;
+    bool pLeftNear = false;
+    for (;;) {
+        const bool parked = (pl & pr) != -1 ? true : false;  // pl >= 0 || pr >= 0 (both are -1 or a triangle id)
+        const bool ready = validBox && !parked;
+        if (ready) {
+            if (it >= MAX_ITERS) {
+                validBox = false;
+                if (COUNT) nCap++;
+            } else {
+                it++;
+                const uint4* np = node32 + 2 * (size_t)cur;
+                uint4 n0 = np[0], n1 = np[1];
+                int2 lk = make_int2((int)n1.z, (int)n1.w);
+                if (COUNT) nV++;
+                Slab L = slab_child(divident, norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
+                Slab R = slab_child(divident, norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
+                bool leftNear = lessEqualF(L.near, R.near);  // :414
+                bool ogL = (L.hit <= IP) && (L.hit * dirlenInv <= IP) && (L.hit > -PZERO) && (L.near <= IP) &&
+                           (L.near * dirlenInv <= IP) && (((L.near + toffset) * dirlenInv - PZERO) <= predist);
+                bool ogR = (R.hit <= IP) && (R.hit * dirlenInv <= IP) && (R.hit > -PZERO) && (R.near <= IP) &&
+                           (R.near * dirlenInv <= IP) && (((R.near + toffset) * dirlenInv - PZERO) <= predist);
+                bool leafL = ogL && lk.x < 0, leafR = ogR && lk.y < 0;
+                bool intL = ogL && lk.x >= 0, intR = ogR && lk.y >= 0;
+                pl = leafL ? ~lk.x : -1;   // :441-448, tested below
+                pr = leafR ? ~lk.y : -1;
+                pLeftNear = leftNear;
+                bool descend = intL || intR;
+                if (descend) {  // :451-462
+                    bool leftOrder = (intL && intR) ? leftNear : intL;
+                    int lr0 = intL ? lk.x : -1, lr1 = intR ? lk.y : -1;
+                    if (!leftOrder) { int t = lr0; lr0 = lr1; lr1 = t; }
+                    if (lr1 != -1 && lr0 != lr1) {
+                        if (sp < STACK_CAP) stack[sp++][tid] = lr1;
+                        else if (COUNT) nDrop++;
+                    }
+                    cur = lr0;
+                } else {  // :467-476
+                    sp--;
+                    if (sp >= 0) cur = stack[sp][tid];
+                    else validBox = false;
+                }
+            }
+        }
+        const bool parkedNow = (pl & pr) != -1;
+        const unsigned long long pend = __ballot(parkedNow);
+        const unsigned long long canStep = __ballot(validBox && !parkedNow);
+        if (pend == 0ull) {
+            if (canStep == 0ull) break;
+            continue;
+        }
+        if (canStep != 0ull && 2 * __popcll(pend) < __popcll(pend | canStep)) continue;  // keep stepping the others
+        if (parkedNow) {  // testIntersectionPacked, :261-309
+            bool leafL = pl >= 0, leafR = pr >= 0;
+            bool leftOrder = (leafL && leafR) ? pLeftNear : leafL;
+            int tx = leftOrder ? pl : pr, ty = leftOrder ? pr : pl;
             bool vx = leftOrder ? leafL : leafR, vy = leftOrder ? leafR : leafL;
             bool validx = (tx >= 0) && (tx != lastTri) && vx;
             bool validy = (ty >= 0) && (ty != lastTri) && vy && (tx != ty);
@@ -193,24 +234,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                     }
                 }
             }
-        }
-        bool descend = intL || intR;
-        if (descend) {  // :451-462
-            bool leftOrder = (intL && intR) ? leftNear : intL;
-            int lr0 = intL ? lk.x : -1, lr1 = intR ? lk.y : -1;
-            if (!leftOrder) { int t = lr0; lr0 = lr1; lr1 = t; }
-            if (lr1 != -1 && lr0 != lr1) {
-                if (sp < STACK_CAP) stack[sp++][tid] = lr1;
-                else if (COUNT) nDrop++;
-            }
-            cur = lr0;
-        } else {  // :467-476
-            sp--;
-            if (sp >= 0) cur = stack[sp][tid];
-            else validBox = false;
+            pl = -1; pr = -1;
         }
     }
-    if (COUNT && it >= MAX_ITERS && validBox) nCap++;
 
     if (CHAIN) {
         if (alive && bakedCount > 0) {
