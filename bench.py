@@ -256,7 +256,9 @@ def main():
         R.rt.clearSampler()
         R.batch.clearSampler()
 
-    # untimed: warm-up steps on the timed path
+    # setup: one frame on every lane (first use of a lane allocates its continuation queues and loads code),
+    # then the untimed warm-up steps on the timed path
+    run_steps(R.lanes)
     run_steps(max(args.warmup, 0))
     R.batch.sync()
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_phases", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -497,6 +497,12 @@ class Pipeline:
 
     def getRayCount(self):
         return self.raycountCache if self.raycountCache >= 32 else 0  # Pipeline.inl:459-461
+
+    def setTraversePhases(self, caps, min_rays=1 << 20):
+        """Tuning knob (psm_rt_set_traverse_phases): wave-step caps of the launches an intersection() is cut into."""
+        arr = (C.c_uint32 * max(len(caps), 1))(*caps)
+        self.ctx.check(lib().psm_rt_set_traverse_phases(self._h, arr, C.c_uint32(len(caps)), C.c_uint32(min_rays)),
+                       "psm_rt_set_traverse_phases")
 
     def resetHits(self):
         """Forget the hit chains of the current queue (ray.hit = -1): the next intersection() starts afresh."""

@@ -441,6 +441,7 @@ int psm_rt_destroy(psm_rt* r) {
     (void)hipStreamSynchronize(r->ctx->stream);
     rt_free_grid(r);
     dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table); dev_free(r->d_geoms);
+    if (r->d_phase_mem) (void)hipFree(r->d_phase_mem);
     if (r->h_cnt) (void)hipHostFree(r->h_cnt);
     if (r->ev_cnt) (void)hipEventDestroy(r->ev_cnt);
     if (r->ev_fold) (void)hipEventDestroy(r->ev_fold);
@@ -669,6 +670,17 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
     int rc = psm_rt_ray_count(r, &n);
     if (rc != PSM_OK) return rc;
     return launch_rt_traverse(r, b);
+}
+
+int psm_rt_set_traverse_phases(psm_rt* r, const uint32_t* caps, uint32_t count, uint32_t min_rays) {
+    if (!r || count > 7 || (count && !caps)) return PSM_ERR_INVALID;
+    for (uint32_t k = 0; k < count; k++) {
+        if (caps[k] == 0) return PSM_ERR_INVALID;
+        r->phase_caps[k] = caps[k];
+    }
+    r->phase_caps_n = (int)count;
+    r->phase_min_rays = min_rays;
+    return PSM_OK;
 }
 
 int psm_rt_reset_hits(psm_rt* r) {

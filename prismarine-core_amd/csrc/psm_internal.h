@@ -25,6 +25,24 @@ struct ObjGeom {  // what interpolateMeshData reads of one hierarchy (directTrav
     const float* uv;
 };
 
+// state of a suspended traversal (trace.hip, phased launches)
+struct TravState {      // structure of arrays, `capacity` entries each
+    uint32_t* idx;      // ray index in the queue
+    int32_t* cur;
+    uint32_t* misc;     // sp | it << 8 | bakedCount << 24
+    float* predist;
+    int32_t* lastTri;
+    float4* head;       // u, v, t, tri of the chain head
+    int32_t* stack;     // [STACK_CAP][capacity]
+    uint32_t capacity;
+};
+struct Phase {
+    uint32_t cap;              // wave-steps this launch may take (0xFFFFFFFF: run to completion)
+    const uint32_t* in_count;  // resume: number of suspended rays (device), nullptr = fresh rays
+    TravState in, out;
+    uint32_t* out_count;
+};
+
 enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_COUNT };
 
 // device-resident counters (one block per context)
@@ -132,6 +150,14 @@ struct psm_rt {
     psm_bvh* trav_objs[psm::MAX_TRAV_OBJECTS] = {};  // hierarchies traversed since the queue last changed
     int trav_n = 0;
     psm::ObjGeom* d_geoms = nullptr;
+    // phased traversal (trace.hip): continuation queues, allocated on first use
+    void* d_phase_mem = nullptr;
+    psm::TravState phase_state[2] = {};
+    uint32_t* d_phase_cnt = nullptr;
+    uint32_t phase_cap = 0;
+    uint32_t phase_caps[7] = {0};   // wave-step caps of the launches before the last one; n = 0: one launch
+    int phase_caps_n = -1;          // -1: defaults (PSM_TRAV_PHASES or 96)
+    uint32_t phase_min_rays = 1u << 20;
     // frames in flight (lanes.hip): pinned slot + events, created on first use
     uint32_t* h_cnt = nullptr;
     hipEvent_t ev_cnt = nullptr, ev_fold = nullptr;

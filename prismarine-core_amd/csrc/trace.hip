@@ -75,18 +75,29 @@ struct Baked {
 // search starts from the distance of the chain the ray already carries (traverse(), :335-346) and the hits
 // it bakes overwrite the front of that chain, the rest of the old chain staying linked behind them
 // (includeChain, :219-249). Triangle ids are tagged with the object's sequence number (bits 27..30).
-template <bool COUNT, bool CHAIN>
+// PHASED: a traversal is cut into launches of at most `cap` wave-steps. A wave runs in lock step, so its
+// cost is its slowest ray (mean 56 steps per bounce ray, mean per-wave maximum 118): when the cap is hit, the
+// rays that are not done write their traversal state (node, stack, best hit) to a dense continuation queue and
+// the next launch resumes them packed 64 to a wave. Per ray nothing changes -- the same node steps and
+// triangle tests in the same order -- so hits, chains and counters are bit-exact; only the idle lanes go.
+template <bool COUNT, bool CHAIN, bool PHASED>
 __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __restrict__ qA, const float4* __restrict__ qB,
                                                           uint32_t nrays, const uint4* __restrict__ node32,
                                                           const float4* __restrict__ tri48,
                                                           const uint32_t* __restrict__ sm, float4* __restrict__ hit0,
                                                           uint32_t* __restrict__ hitN, float4* __restrict__ pool,
                                                           uint32_t pool_cap, uint32_t* __restrict__ cnt,
-                                                          DevCounters* __restrict__ ctr, uint32_t obj_tag) {
+                                                          DevCounters* __restrict__ ctr, uint32_t obj_tag, Phase ph) {
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
     uint32_t i = blockIdx.x * TRAV_BLOCK + threadIdx.x;
     const int tid = threadIdx.x;
     bool alive = i < nrays;
+    const bool resume = PHASED && ph.in_count != nullptr;
+    uint32_t slot = i;
+    if (resume) {
+        alive = slot < *ph.in_count;
+        i = alive ? ph.in.idx[slot] : 0u;
+    }
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
 
     float4 A = alive ? qA[i] : make_float4(0, 0, 0, 0);
@@ -146,6 +157,21 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     int cur = root;
     int sp = 0;
     int it = 0;
+    if (resume && alive) {  // pick the ray up where the previous launch left it
+        uint32_t m = ph.in.misc[slot];
+        cur = ph.in.cur[slot];
+        sp = (int)(m & 255u);
+        it = (int)((m >> 8) & 0xFFFFu);
+        bakedCount = (int)(m >> 24);
+        predist = ph.in.predist[slot];
+        lastTri = ph.in.lastTri[slot];
+        float4 hd = ph.in.head[slot];
+        head.u = hd.x; head.v = hd.y; head.t = hd.z; head.tri = __float_as_int(hd.w);
+        for (int k = 0; k < sp; k++) stack[k][tid] = ph.in.stack[(size_t)k * ph.in.capacity + slot];
+        validBox = true;
+    }
+    uint32_t wsteps = 0;
+    bool suspended = false;
     // Leaf tests are deferred, not reordered: a lane that reaches a leaf parks its triangle pair (pl, pr) and
     // sits out the node steps of the others until enough lanes of the wave are parked (or nobody can step),
     // then all of them run the triangle block together. Per ray the sequence of node steps and triangle
@@ -198,11 +224,13 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
         const bool parkedNow = (pl & pr) != -1;
         const unsigned long long pend = __ballot(parkedNow);
         const unsigned long long canStep = __ballot(validBox && !parkedNow);
+        const bool capHit = PHASED && (++wsteps >= ph.cap);  // wave-uniform
         if (pend == 0ull) {
             if (canStep == 0ull) break;
-            continue;
+            if (!capHit) continue;
+        } else if (!capHit && canStep != 0ull && 2 * __popcll(pend) < __popcll(pend | canStep)) {
+            continue;  // keep stepping the others
         }
-        if (canStep != 0ull && 2 * __popcll(pend) < __popcll(pend | canStep)) continue;  // keep stepping the others
         if (parkedNow) {  // testIntersectionPacked, :261-309
             bool leafL = pl >= 0, leafR = pr >= 0;
             bool leftOrder = (leafL && leafR) ? pLeftNear : leafL;
@@ -236,7 +264,33 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
             }
             pl = -1; pr = -1;
         }
+        if (capHit) {
+            // every parked test has just run. Rays with work left and a chain of at most one hit hand their state
+            // to the next launch (a longer chain lives in registers / scratch: such a ray, < 0.1 %, finishes here)
+            const bool susp = validBox && bakedCount <= 1;
+            const unsigned long long sb = __ballot(susp);
+            if (sb != 0ull) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)sb) - 1;
+                if (lane_id() == leader) base = atomicAdd(ph.out_count, (uint32_t)__popcll(sb));
+                base = __shfl(base, leader);
+                if (susp) {
+                    const uint32_t o = base + (uint32_t)__popcll(sb & ((1ull << lane_id()) - 1ull));
+                    ph.out.idx[o] = i;
+                    ph.out.cur[o] = cur;
+                    ph.out.misc[o] = (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24);
+                    ph.out.predist[o] = predist;
+                    ph.out.lastTri[o] = lastTri;
+                    ph.out.head[o] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
+                    for (int k = 0; k < sp; k++) ph.out.stack[(size_t)k * ph.out.capacity + o] = stack[k][tid];
+                    validBox = false;
+                    suspended = true;
+                }
+            }
+            if (__ballot(validBox) == 0ull) break;
+        }
     }
+    if (PHASED && suspended) alive = false;  // its result is written by the launch that finishes it
 
     if (CHAIN) {
         if (alive && bakedCount > 0) {
@@ -634,6 +688,53 @@ static bool use_simple_traverse() {
     return v == 1;
 }
 
+constexpr size_t MAX_PHASES = 8;
+
+// wave-step caps of the phased traversal: PSM_TRAV_PHASES="96" (default; "64,64" = three launches), "" or "0" = one launch
+static const std::vector<uint32_t>& phase_caps() {
+    static std::vector<uint32_t> caps;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char* e = getenv("PSM_TRAV_PHASES");
+        std::string v = e ? e : "96";
+        size_t pos = 0;
+        while (pos < v.size() && caps.size() + 1 < MAX_PHASES) {
+            size_t q = v.find(',', pos);
+            if (q == std::string::npos) q = v.size();
+            int x = atoi(v.substr(pos, q - pos).c_str());
+            if (x > 0) caps.push_back((uint32_t)x);
+            pos = q + 1;
+        }
+    }
+    return caps;
+}
+
+static int ensure_phase_buffers(psm_rt* r) {
+    psm_ctx* c = r->ctx;
+    if (r->d_phase_mem && r->phase_cap == r->limit) return PSM_OK;
+    if (r->d_phase_mem) { (void)hipStreamSynchronize(c->stream); (void)hipFree(r->d_phase_mem); r->d_phase_mem = nullptr; }
+    const size_t L = r->limit;
+    const size_t per = L * (4 * 5 + 16 + 4 * STACK_CAP);  // idx, cur, misc, predist, lastTri, head, stack
+    PSM_HIP(c, hipMalloc(&r->d_phase_mem, 2 * per + sizeof(uint32_t) * MAX_PHASES));
+    char* base = (char*)r->d_phase_mem;
+    for (int k = 0; k < 2; k++) {
+        char* p = base + k * per;
+        TravState& t = r->phase_state[k];
+        t.head = (float4*)p; p += L * 16;
+        t.idx = (uint32_t*)p; p += L * 4;
+        t.cur = (int32_t*)p; p += L * 4;
+        t.misc = (uint32_t*)p; p += L * 4;
+        t.predist = (float*)p; p += L * 4;
+        t.lastTri = (int32_t*)p; p += L * 4;
+        t.stack = (int32_t*)p;
+        t.capacity = (uint32_t)L;
+    }
+    r->d_phase_cnt = (uint32_t*)(base + 2 * per);
+    r->phase_cap = r->limit;
+    return PSM_OK;
+}
+
 int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     psm_ctx* c = r->ctx;
     uint32_t n = r->ray_count;
@@ -646,15 +747,39 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     r->trav_objs[r->trav_n++] = b;
     if (chain || use_simple_traverse()) {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
-        TimedScope ts(c, CAT_TRAVERSE);
 #define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
                       r->pool_cap, r->d_cnt, c->d_counters, tag
-        if (chain) {
-            if (c->counting) rt_traverse<true, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
-            else rt_traverse<false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
+        std::vector<uint32_t> caps = r->phase_caps_n < 0 ? phase_caps() : std::vector<uint32_t>(r->phase_caps, r->phase_caps + r->phase_caps_n);
+        if (chain || caps.empty() || n < r->phase_min_rays) {
+            TimedScope ts(c, CAT_TRAVERSE);
+            Phase none = {};
+            none.cap = 0xFFFFFFFFu;
+            if (chain) {
+                if (c->counting) rt_traverse<true, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
+                else rt_traverse<false, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
+            } else {
+                if (c->counting) rt_traverse<true, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
+                else rt_traverse<false, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
+            }
         } else {
-            if (c->counting) rt_traverse<true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
-            else rt_traverse<false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS);
+            // phased: launch p runs at most caps[p] wave-steps and hands unfinished rays to launch p+1 through a
+            // dense continuation queue; the last launch runs to completion. Resume launches are sized for the
+            // worst case (every ray suspended); blocks past the device-side count exit at once.
+            int rc = ensure_phase_buffers(r);
+            if (rc != PSM_OK) return rc;
+            const size_t np = caps.size() + 1;
+            PSM_HIP(c, hipMemsetAsync(r->d_phase_cnt, 0, sizeof(uint32_t) * MAX_PHASES, c->stream));
+            for (size_t p = 0; p < np; p++) {
+                Phase ph;
+                ph.cap = p < caps.size() ? caps[p] : 0xFFFFFFFFu;
+                ph.in_count = p == 0 ? nullptr : r->d_phase_cnt + (p - 1);
+                ph.in = r->phase_state[(p + 1) & 1];
+                ph.out = r->phase_state[p & 1];
+                ph.out_count = r->d_phase_cnt + p;
+                TimedScope ts(c, CAT_TRAVERSE);
+                if (c->counting) rt_traverse<true, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
+                else rt_traverse<false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
+            }
         }
 #undef PSM_TRAV_ARGS
     } else {

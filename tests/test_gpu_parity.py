@@ -229,6 +229,33 @@ def test_traverse_random_rays_with_chains(psm, ctx, oracle, scenes):
     th.close()
 
 
+@pytest.mark.parametrize("caps", [[1], [3, 5, 7], [16, 16, 16, 16, 16, 16, 16], [40]])
+def test_phased_traversal_is_bit_exact(psm, ctx, oracle, scenes, caps):
+    """psm_rt_set_traverse_phases: rays suspended after a few wave-steps and resumed from the continuation queue
+    (up to seven times) give the hits, chains and counters of one uninterrupted launch."""
+    scene = scenes.sponza_like(n_tris=20011)
+    w, h = 160, 90
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    ob = oracle.build_scene(scene["tris"])
+    rt.setTraversePhases(caps, min_rays=0)
+    rt.camera_matrices(cam[0], cam[1], time=11)
+    rt.applyMaterials(ms)
+    for rnd in range(3):
+        rays = rt.download_rays()
+        ctx.stats_enable(False, True)
+        ctx.stats_reset()
+        rt.intersection(th, force=True)
+        st = ctx.stats()
+        ctx.stats_enable(False, False)
+        gh, gc = rt.download_hits(rays.shape[0])
+        oh, oc, octr = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], rays["origin"], rays["direct"], 8)
+        _hits_equal(gh, gc, oh, oc)
+        assert (st.node_visits, st.tri_tests) == (octr.node_visits, octr.tri_tests)
+        rt.shade(time=40 + rnd)
+    rt.close()
+    th.close()
+
+
 # ---------------------------------------------------------------------------- shade + full frames
 @pytest.mark.parametrize("name,w,h", [("cornell_open", 96, 96), ("sponza_small", 160, 90),
                                       ("cornell_open+tex", 96, 96), ("sponza_small+tex", 160, 90)])
