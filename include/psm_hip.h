@@ -211,8 +211,9 @@ int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
 /* Phased traversal (a tuning knob, results never change): an intersection() over at least `min_rays` rays is cut
  * into count + 1 launches; launch k runs at most caps[k] wave-steps (a wave steps as long as its slowest ray), the
  * rays still under way hand their state (node, stack, best hit) to a dense continuation queue and the next launch
- * resumes them packed 64 to a wave; the last launch runs to completion. Default: one cap of 96 from 2^20 rays
- * (what pays on C3 with frames in flight); count = 0: always one launch. */
+ * resumes them packed 64 to a wave; the last launch runs to completion. Default (never called): automatic -- one
+ * cap of 96 from 2^20 rays while the Pipeline is one of several frames in flight (psm_lanes_*: the other frames'
+ * kernels fill the extra launch's tail), a single launch otherwise; count = 0: always one launch. */
 int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count, uint32_t min_rays);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
 int psm_rt_reset_hits(psm_rt* rt);

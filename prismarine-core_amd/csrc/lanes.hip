@@ -95,6 +95,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         int e = lane_resources(rts[s]);
         if (e != PSM_OK) return e;
     }
+    for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
     int rc = PSM_OK;
     auto queue_round = [&](Lane& ln) -> int {  // intersection + shade + asynchronous read-back of the next count
         psm_rt* r = ln.rt;
@@ -167,7 +168,10 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
             idle_spins = 0;
         }
     }
-    for (uint32_t s = 0; s < lanes; s++) (void)hipStreamSynchronize(L[s].rt->ctx->stream);
+    for (uint32_t s = 0; s < lanes; s++) {
+        (void)hipStreamSynchronize(L[s].rt->ctx->stream);
+        rts[s]->in_flight = 1;
+    }
     if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
     return rc;
 }
@@ -194,6 +198,7 @@ extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, u
         if (e != PSM_OK) return e;
     }
     (void)hipSetDevice(rts[0]->ctx->device);
+    for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
     std::vector<LaneState> st(lanes, IDLE);  // RUNNING = a round is in flight, FINISHED = parked
     int rc = PSM_OK;
     auto step = [&](uint32_t s) -> int {  // park, or queue one more round
@@ -245,6 +250,7 @@ extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, u
     for (uint32_t s = 0; s < lanes; s++) {
         (void)hipStreamSynchronize(rts[s]->ctx->stream);
         counts_out[s] = (int32_t)rts[s]->ray_count;
+        rts[s]->in_flight = 1;
     }
     return rc;
 }

@@ -156,7 +156,8 @@ struct psm_rt {
     uint32_t* d_phase_cnt = nullptr;
     uint32_t phase_cap = 0;
     uint32_t phase_caps[7] = {0};   // wave-step caps of the launches before the last one; n = 0: one launch
-    int phase_caps_n = -1;          // -1: defaults (PSM_TRAV_PHASES or 96)
+    int phase_caps_n = -1;          // -1: automatic -- PSM_TRAV_PHASES or 96 while frames are in flight, one launch otherwise
+    uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
     uint32_t phase_min_rays = 1u << 20;
     // frames in flight (lanes.hip): pinned slot + events, created on first use
     uint32_t* h_cnt = nullptr;

@@ -749,7 +749,9 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
 #define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
                       r->pool_cap, r->d_cnt, c->d_counters, tag
-        std::vector<uint32_t> caps = r->phase_caps_n < 0 ? phase_caps() : std::vector<uint32_t>(r->phase_caps, r->phase_caps + r->phase_caps_n);
+        // automatic: phases only pay when other frames' kernels fill the launch tails they add (lanes.hip)
+        std::vector<uint32_t> caps = r->phase_caps_n < 0 ? (r->in_flight > 1 ? phase_caps() : std::vector<uint32_t>())
+                                                         : std::vector<uint32_t>(r->phase_caps, r->phase_caps + r->phase_caps_n);
         if (chain || caps.empty() || n < r->phase_min_rays) {
             TimedScope ts(c, CAT_TRAVERSE);
             Phase none = {};
