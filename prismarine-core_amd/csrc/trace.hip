@@ -195,12 +195,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                 Slab L = slab_child(divident, norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
                 Slab R = slab_child(divident, norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
                 bool leftNear = lessEqualF(L.near, R.near);  // :414
-                // :425-429. IP = INF - PZERO = INF in fp32, so `x <= IP` only rejects NaN, and x * k is NaN whenever
-                // x is: the reference's separate `x <= IP` tests are implied by the `x * k <= IP` ones.
-                bool ogL = (L.hit * dirlenInv <= IP) && (L.hit > -PZERO) && (L.near * dirlenInv <= IP) &&
-                           (((L.near + toffset) * dirlenInv - PZERO) <= predist);
-                bool ogR = (R.hit * dirlenInv <= IP) && (R.hit > -PZERO) && (R.near * dirlenInv <= IP) &&
-                           (((R.near + toffset) * dirlenInv - PZERO) <= predist);
+                bool ogL = (L.hit <= IP) && (L.hit * dirlenInv <= IP) && (L.hit > -PZERO) && (L.near <= IP) &&
+                           (L.near * dirlenInv <= IP) && (((L.near + toffset) * dirlenInv - PZERO) <= predist);
+                bool ogR = (R.hit <= IP) && (R.hit * dirlenInv <= IP) && (R.hit > -PZERO) && (R.near <= IP) &&
+                           (R.near * dirlenInv <= IP) && (((R.near + toffset) * dirlenInv - PZERO) <= predist);
                 bool leafL = ogL && lk.x < 0, leafR = ogR && lk.y < 0;
                 bool intL = ogL && lk.x >= 0, intR = ogR && lk.y >= 0;
                 pl = leafL ? ~lk.x : -1;   // :441-448, tested below
