@@ -229,6 +229,47 @@ def test_traverse_random_rays_with_chains(psm, ctx, oracle, scenes):
     th.close()
 
 
+@pytest.mark.parametrize("scale", [0.004, 35.0])
+def test_traverse_scaled_scene_bit_exact(psm, ctx, oracle, scenes, scale):
+    """INFINITY is 10000 in the reference (constants.glsl:82) and the unit-cube transform makes the ray-parameter
+    scale dirlenInv smaller or larger than 1: the `<= INFINITY - PZERO` tests of directTraverse.comp:425-429 bite
+    differently in a scene a few millimetres across and in one whose far hits lie beyond 10000."""
+    base = scenes.sponza_like(n_tris=20011)
+    scene = dict(base)
+    scene["tris"] = (base["tris"] * np.float32(scale)).astype(np.float32)
+    scene["eye"] = (np.asarray(base["eye"], np.float32) * np.float32(scale)).astype(np.float32)
+    scene["view"] = base["view"]
+    w, h = 128, 72
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    ob = oracle.build_scene(scene["tris"])
+    mats = scenes.materials_array(scene["materials"])
+    cfg = oracle.make_cfg(w, h, material_count=len(mats))
+    lights = oracle.default_lights(1)
+    rt.camera_matrices(cam[0], cam[1], time=3)
+    orays, ocoord, osum, oflag = oracle.camera(cfg, cam[0], cam[1], 3)
+    rt.applyMaterials(ms)
+    hits_seen = 0
+    for rnd in range(3):
+        if orays.shape[0] < 32:
+            break
+        _rays_equal(rt.download_rays(), orays)
+        ctx.stats_enable(False, True)
+        ctx.stats_reset()
+        rt.intersection(th)
+        st = ctx.stats()
+        ctx.stats_enable(False, False)
+        oh, oc, octr = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], orays["origin"], orays["direct"], 8)
+        gh, gc = rt.download_hits(orays.shape[0])
+        _hits_equal(gh, gc, oh, oc)
+        assert (st.node_visits, st.tri_tests) == (octr.node_visits, octr.tri_tests)
+        hits_seen += int((oc > 0).sum())
+        rt.shade(time=70 + rnd)
+        orays = oracle.shade(cfg, lights, mats, scene["mats"], scene["tris"], scene["normals"], 70 + rnd, orays, oh, oc, osum, oflag)
+    assert hits_seen > 1000
+    rt.close()
+    th.close()
+
+
 @pytest.mark.parametrize("caps", [[1], [3, 5, 7], [16, 16, 16, 16, 16, 16, 16], [40]])
 def test_phased_traversal_is_bit_exact(psm, ctx, oracle, scenes, caps):
     """psm_rt_set_traverse_phases: rays suspended after a few wave-steps and resumed from the continuation queue
