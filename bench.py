@@ -233,6 +233,9 @@ def pmc_traffic(kernel):
 def main():
     args = parse()
     os.environ["NCCL_DEBUG"] = os.environ.get("PSM_NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
+    # one hardware queue per frame in flight + the accumulating stream (the runtime's default of 4 makes two
+    # streams share a queue); read by the HIP runtime when it initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
     psm = importlib.import_module("prismarine-core_amd")
     pdist = importlib.import_module("prismarine-core_amd.dist")

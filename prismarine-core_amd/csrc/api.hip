@@ -495,7 +495,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     auto A = [&](int x) { if (rc == PSM_OK) rc = x; };
     for (int q = 0; q < 2; q++) { A(dev_alloc(c, &r->qA[q], L)); A(dev_alloc(c, &r->qB[q], L)); A(dev_alloc(c, &r->qC[q], L)); }
     A(dev_alloc(c, &r->sA, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sB, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sC, nb * SHADE_BLOCK * 4));
-    A(dev_alloc(c, &r->d_block, 2 * nb + 2)); A(dev_alloc(c, &r->qT, 4 * L));
+    A(dev_alloc(c, &r->d_block, 2 * nb + 2));  // qT: allocated by the persistent-threads tracer when it is selected
     A(dev_alloc(c, &r->hit0, L)); A(dev_alloc(c, &r->hitN, L));
     r->pool_cap = (uint32_t)std::max<size_t>(L / 2, 1024);  // hits buffer = L/2 in the reference, Pipeline.inl:193
     A(dev_alloc(c, &r->pool, (size_t)r->pool_cap));

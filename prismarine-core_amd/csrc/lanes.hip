@@ -15,6 +15,7 @@
 // another one's round; a lane that finishes a frame takes the next one as soon as its frame is folded.
 #include "psm_internal.h"
 
+#include <chrono>
 #include <cstring>
 #include <thread>
 
@@ -128,13 +129,20 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         ln.state = RUNNING;
         return queue_round(ln);
     };
+    // PSM_LANES_PROFILE=1: how much of the wall time the scheduler thread spends issuing work
+    static const bool profile = getenv("PSM_LANES_PROFILE") != nullptr;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_begin = clk::now();
+    double issue_s = 0.0;
     uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
     while (rc == PSM_OK && next_fold < frames) {
         bool progressed = false;
         for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
             Lane& ln = L[s];
             if (ln.state == IDLE && next_frame < frames) {
+                const clk::time_point t0 = clk::now();
                 rc = start(ln, next_frame++);
+                issue_s += std::chrono::duration<double>(clk::now() - t0).count();
                 progressed = true;
             } else if (ln.state == RUNNING) {
                 hipError_t q = hipEventQuery(ln.rt->ev_cnt);
@@ -144,7 +152,11 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
                 ln.rt->ray_count = *ln.rt->h_cnt;  // what reloadQueuedRays learns (Pipeline.inl:325-359)
                 ln.rt->count_valid = true;
                 if (ln.round >= depth || ln.rt->ray_count < 32) finish(ln);
-                else rc = queue_round(ln);
+                else {
+                    const clk::time_point t0 = clk::now();
+                    rc = queue_round(ln);
+                    issue_s += std::chrono::duration<double>(clk::now() - t0).count();
+                }
             }
         }
         // sample() in frame order
@@ -173,6 +185,11 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         rts[s]->in_flight = 1;
     }
     if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
+    if (profile) {
+        const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
+        fprintf(stderr, "psm_lanes_render: %u frames on %u lanes, wall %.3f ms, issuing %.3f ms (%.0f %%)\n", frames, lanes,
+                wall * 1e3, issue_s * 1e3, 100.0 * issue_s / wall);
+    }
     return rc;
 }
 

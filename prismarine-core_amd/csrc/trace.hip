@@ -813,6 +813,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         uint32_t need = (n + PT_BLOCK - 1) / PT_BLOCK;
         uint32_t grid = need < cap ? need : cap;
         TimedScope ts(c, CAT_TRAVERSE);
+        if (!r->qT) PSM_HIP(c, hipMalloc((void**)&r->qT, sizeof(float4) * 4 * (size_t)r->limit));  // freed with the ray grid
         rt_project<<<(n + 255) / 256, 256, 0, c->stream>>>(r->qA[r->cur], r->qB[r->cur], n, r->limit, b->d_small, r->qT);
         if (c->counting)
             rt_traverse_pt<true><<<grid, PT_BLOCK, 0, c->stream>>>(r->qT, n, r->limit, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN,
