@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--emulate-tile", default=None, help="R/W: render only the tile of rank R of W on one GPU, no communication (Amdahl study)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path even on 1 GPU (rehearsal)")
+    ap.add_argument("--no-rebuild", action="store_true", help="study only, not the headline workload: build the BVH once")
     ap.add_argument("--lanes", type=int, default=4,
                     help="frames in flight per GPU (psm_lanes_render): each on its own HIP stream, folded into the "
                          "accumulating image in frame order; 1 = one frame after another")
@@ -105,7 +106,13 @@ class Renderer:
 
     def frames_in_flight(self, k):
         """k x process() with `lanes` frames in flight (native scheduler), folded in frame order."""
-        return self.batch.render(k, self.scene["eye"], self.scene["view"], depth=self.args.depth)
+        if self.args.no_rebuild and not getattr(self, "_built_once", False):
+            for ln in self.batch.lanes:
+                ln.th.markDirty()
+                ln.th.build()
+            self._built_once = True
+        return self.batch.render(k, self.scene["eye"], self.scene["view"], depth=self.args.depth,
+                                 rebuild=not self.args.no_rebuild)
 
     def frames_in_flight_sharded(self, k):
         """k x process() of a tile-sharded frame with `lanes` frames in flight on every rank: the lanes' kernels
