@@ -131,3 +131,26 @@ def test_full_1080p_frame_sampled_parity_determinism_conservation(psm, ctx, orac
     ctx.stats_enable(False, False)
     rt.close()
     th.close()
+
+
+def test_full_1080p_frames_in_flight_radiance_vs_oracle(psm, oracle, scenes):
+    """BASELINE config 3 through the path bench.py times: two 1080p frames in flight (psm_lanes_render, phased
+    traversal above 2^20 rays, deferred leaf tests), folded in frame order -- every texel of the accumulated image
+    within 1e-4 relative of the oracle's two frames, ray and round counts equal."""
+    sc = scenes.sponza_like()
+    w, h, frames, seed = 1920, 1080, 2, 1000
+    batch = psm.FrameBatch(2, w, h, seed=seed)
+    batch.allocate(sc["tris"].shape[0])
+    batch.loadTriangles(sc["tris"], sc["normals"], sc["mats"])
+    ms = psm.MaterialSet()
+    for m in sc["materials"]:
+        ms.addSubmat(m)
+    batch.applyMaterials(ms)
+    per_frame = batch.render(frames, sc["eye"], sc["view"])
+    img = batch.snapHdr()
+    batch.close()
+    ref, st = oracle.render_frames(sc, w, h, frames=frames, seed=seed, nthreads=16, frame_streams=True)
+    assert sum(r for _, r in per_frame) == st["rays"] and sum(n for n, _ in per_frame) == len(st["rounds"])
+    assert st["rays"] > 12_000_000
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
