@@ -209,6 +209,9 @@ def cpu_baseline(scene, ray_sets, args):
     t0 = time.time()
     ob = O.build_scene(scene["tris"])
     build_s = time.time() - t0
+    t0 = time.time()
+    O.radix_sort(ob["keys_unsorted"], ob["idx"])
+    sort_s = time.time() - t0
     threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
     origins = np.ascontiguousarray(rays["origin"])
     directs = np.ascontiguousarray(rays["direct"])
@@ -220,6 +223,7 @@ def cpu_baseline(scene, ray_sets, args):
         dt = time.time() - t0
         best = dt if best is None else min(best, dt)
     return {"value": rays.shape[0] / best / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "build_ms": build_s * 1e3, "sort_mkeys_s": ob["count"] / sort_s / 1e6, "build_sort_cores": 1,
             "sample": "%d of the %d rays of frame 0 (all bounce rounds, every %d-th ray), oracle psmo_traverse_batch, "
                       "best of 2; oracle BVH build %.2f s on 1 core" % (rays.shape[0], n, max(1, n // max(rays.shape[0], 1)), build_s)}
 
