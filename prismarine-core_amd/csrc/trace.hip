@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "psm_common.h"
 #include "psm_internal.h"
@@ -679,34 +680,32 @@ __global__ __launch_bounds__(PT_BLOCK) void rt_traverse_pt(const float4* __restr
     }
 }
 
-static bool use_simple_traverse() {
-    static int v = -1;
-    if (v < 0) {
+static bool use_simple_traverse() {  // thread-safe (lanes issue from their own host threads)
+    static const bool simple = [] {
         const char* e = getenv("PSM_TRAVERSE");
-        v = (e && std::strcmp(e, "persistent") == 0) ? 0 : 1;  // see DESIGN.md "traversal": measured faster
-    }
-    return v == 1;
+        return !(e && std::strcmp(e, "persistent") == 0);  // see DESIGN.md "traversal": measured faster
+    }();
+    return simple;
 }
 
 constexpr size_t MAX_PHASES = 8;
 
 // wave-step caps of the phased traversal: PSM_TRAV_PHASES="96" (default; "64,64" = three launches), "" or "0" = one launch
 static const std::vector<uint32_t>& phase_caps() {
-    static std::vector<uint32_t> caps;
-    static bool init = false;
-    if (!init) {
-        init = true;
+    static const std::vector<uint32_t> caps = [] {
+        std::vector<uint32_t> c;
         const char* e = getenv("PSM_TRAV_PHASES");
         std::string v = e ? e : "96";
         size_t pos = 0;
-        while (pos < v.size() && caps.size() + 1 < MAX_PHASES) {
+        while (pos < v.size() && c.size() + 1 < MAX_PHASES) {
             size_t q = v.find(',', pos);
             if (q == std::string::npos) q = v.size();
             int x = atoi(v.substr(pos, q - pos).c_str());
-            if (x > 0) caps.push_back((uint32_t)x);
+            if (x > 0) c.push_back((uint32_t)x);
             pos = q + 1;
         }
-    }
+        return c;
+    }();
     return caps;
 }
 
@@ -788,6 +787,8 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         // persistent grid: 256 CUs x 8 workgroups of 4 waves (one wave per SIMD each); fewer when the
         // queue is short. Ray cursors cnt[3], cnt[4] alternate between launches (each launch zeroes
         // the other one), so no memset sits between traversals.
+        static std::mutex pt_mutex;  // the lazily tuned statics below; lanes may issue from several host threads
+        std::lock_guard<std::mutex> pt_lock(pt_mutex);
         static int resident[2] = {0, 0};
         int& res = resident[c->counting ? 1 : 0];
         if (res == 0) {
