@@ -385,12 +385,15 @@ def rand_next(state):
 
 
 def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, built=None,
-                  cam=None, rows=None, record=None, skybox=None, parts=None, frame_streams=False):
+                  cam=None, rows=None, record=None, skybox=None, parts=None, frame_streams=False,
+                  lights=None, display=None):
     """Viewer.cpp:296-312 call order on the oracle: build, camera, <=depth x (traverse, shade), sample.
     Returns (filtered image [h,w,4], stats). parts: list of triangle-index arrays -- each becomes its own
     hierarchy and every round intersects them one after the other (multi-BVH); the scene's arrays must be
     ordered part by part. frame_streams: the FrameBatch policy -- the stream started by `seed` hands every
-    frame one draw, which seeds that frame's own rand() stream (camera + one draw per shade)."""
+    frame one draw, which seeds that frame's own rand() stream (camera + one draw per shade). lights: LIGHT_DT
+    array (default: the one reference sun); display: (w, h) of the sampled image when it differs from the ray grid
+    (the viewer traces a 2x supersampled grid, Application.hpp:222,277)."""
     from importlib import import_module
     scenes = import_module("prismarine-core_amd.scenes")
     tris = scene["tris"]
@@ -401,14 +404,15 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
     elif built is None:
         built = build_scene(tris)
     mats = scenes.materials_array(scene["materials"])
-    cfg = make_cfg(width, height, material_count=len(mats))
+    lights = default_lights(1) if lights is None else np.ascontiguousarray(lights, LIGHT_DT)
+    dw, dh = display if display else (width, height)
+    cfg = make_cfg(width, height, display=(dw, dh), lights=lights.shape[0], material_count=len(mats))
     if skybox is not None:
         set_skybox(cfg, skybox)
     if scene.get("texcoords") is not None or scene.get("textures"):
         set_textures(cfg, scene.get("texcoords"), scene.get("textures"))
-    lights = default_lights(1)
-    cam_inv, proj_inv = cam if cam else scenes.camera_matrices(scene["eye"], scene["view"], width, height)
-    presampled = np.zeros((width * height, 4), np.float32)
+    cam_inv, proj_inv = cam if cam else scenes.camera_matrices(scene["eye"], scene["view"], dw, dh)
+    presampled = np.zeros((dw * dh, 4), np.float32)
     state = seed
     stats = {"rays": 0, "rounds": [], "node_visits": 0, "tri_tests": 0}
     y0, y1 = rows if rows else (0, height)
@@ -436,4 +440,4 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
             t, state = rand_next(state)
             rays = shade(cfg, lights, mats, scene["mats"], tris, scene["normals"], t, rays, hits, counts, tsum, flag)
         filtered = sample(cfg, coord, tsum, flag, presampled)
-    return filtered.reshape(height, width, 4), stats
+    return filtered.reshape(dh, dw, 4), stats

@@ -725,6 +725,70 @@ def test_frame_batch_lanes_equal_sequential_frames(psm, oracle, scenes):
     batch.close()
 
 
+def _three_lights(oracle):
+    L = oracle.default_lights(3)
+    L[1]["lightVector"] = (-0.5, 0.8, 0.6, 30.0)
+    L[1]["lightColor"] = (40.0, 10.0, 5.0, 3.0)
+    L[1]["lightOffset"] = (0.2, 0.0, -0.3, 0.0)
+    L[2]["lightVector"] = (0.1, -1.0, 0.2, 5.0)
+    L[2]["lightColor"] = (2.0, 8.0, 30.0, 1.5)
+    L[2]["lightAmbient"] = (0.05, 0.02, 0.01, 0.0)
+    return L
+
+
+def test_three_lights_radiance(psm, ctx, oracle, scenes):
+    """setLightCount / lightVector / lightColor / lightOffset (Pipeline.hpp:103-121): three spherical lights of
+    different size, one below the horizon (lightCenter's sign flip, shadinglib.glsl:22-26)."""
+    scene = scenes.cornell(open_top=True)
+    w, h, frames = 64, 48, 2
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    L = _three_lights(oracle)
+    rt.setLights(L)
+    rt.setSeed(3)
+    for _ in range(frames):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    img = rt.snapHdr()
+    ref, _ = oracle.render_frames(scene, w, h, frames=frames, seed=3, lights=L)
+    one, _ = oracle.render_frames(scene, w, h, frames=frames, seed=3)
+    assert np.abs(ref[..., :3] - one[..., :3]).max() > 0.1
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    rt.close()
+    th.close()
+
+
+def test_supersampled_ray_grid_and_depth_limit(psm, ctx, oracle, scenes):
+    """The viewer traces a ray grid twice the window (Application.hpp:222,277): resizeBuffers(2w, 2h) with
+    resize(w, h) -- sampler.comp:37-97 gathers the 2x2 texels whose jittered coordinate lands in a pixel. And the
+    `for j < depth` bound of Viewer.cpp:304 cuts frames short."""
+    scene = scenes.cornell(open_top=True)
+    gw, gh, dw, dh, frames = 96, 64, 48, 32, 2
+    th = _load(psm, ctx, scene)
+    th.build()
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(gw, gh)
+    rt.resize(dw, dh)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    rt.setSeed(3)
+    for _ in range(frames):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    img = rt.snapHdr()
+    assert img.shape == (dh, dw, 4)
+    ref, st = oracle.render_frames(scene, gw, gh, frames=frames, seed=3, display=(dw, dh))
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3]) and ref[..., 3].max() > 2   # several texels per pixel
+    # depth limit
+    rt.clearSampler()
+    rt.setSeed(3)
+    rounds = psm.render_frame(rt, th, ms, scene["eye"], scene["view"], depth=2)
+    ref2, st2 = oracle.render_frames(scene, gw, gh, frames=1, seed=3, display=(dw, dh), depth=2)
+    assert rounds == 2 == len(st2["rounds"]) and len(st["rounds"]) > 4
+    np.testing.assert_allclose(rt.snapHdr()[..., :3], ref2[..., :3], rtol=1e-4, atol=1e-5)
+    rt.close()
+    th.close()
+
+
 def _sky_image(w=64, h=32):
     yy, xx = np.mgrid[0:h, 0:w]
     img = np.zeros((h, w, 4), np.uint8)
