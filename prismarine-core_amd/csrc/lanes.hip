@@ -133,7 +133,9 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     static const bool profile = getenv("PSM_LANES_PROFILE") != nullptr;
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
-    double issue_s = 0.0;
+    double issue_s = 0.0, gpu_wait_s = 0.0, react_s = 0.0;  // profile: issue -> count seen, count seen -> next issue
+    uint32_t waits = 0;
+    std::vector<clk::time_point> t_issued(lanes), t_seen(lanes);
     uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
     while (rc == PSM_OK && next_fold < frames) {
         bool progressed = false;
@@ -142,20 +144,26 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
             if (ln.state == IDLE && next_frame < frames) {
                 const clk::time_point t0 = clk::now();
                 rc = start(ln, next_frame++);
-                issue_s += std::chrono::duration<double>(clk::now() - t0).count();
+                t_issued[s] = clk::now();
+                issue_s += std::chrono::duration<double>(t_issued[s] - t0).count();
                 progressed = true;
             } else if (ln.state == RUNNING) {
                 hipError_t q = hipEventQuery(ln.rt->ev_cnt);
                 if (q == hipErrorNotReady) continue;
                 if (q != hipSuccess) { rc = set_err(ln.rt->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
                 progressed = true;
+                t_seen[s] = clk::now();
+                gpu_wait_s += std::chrono::duration<double>(t_seen[s] - t_issued[s]).count();
+                waits++;
                 ln.rt->ray_count = *ln.rt->h_cnt;  // what reloadQueuedRays learns (Pipeline.inl:325-359)
                 ln.rt->count_valid = true;
                 if (ln.round >= depth || ln.rt->ray_count < 32) finish(ln);
                 else {
                     const clk::time_point t0 = clk::now();
                     rc = queue_round(ln);
-                    issue_s += std::chrono::duration<double>(clk::now() - t0).count();
+                    t_issued[s] = clk::now();
+                    react_s += std::chrono::duration<double>(t0 - t_seen[s]).count();
+                    issue_s += std::chrono::duration<double>(t_issued[s] - t0).count();
                 }
             }
         }
@@ -187,8 +195,10 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
     if (profile) {
         const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
-        fprintf(stderr, "psm_lanes_render: %u frames on %u lanes, wall %.3f ms, issuing %.3f ms (%.0f %%)\n", frames, lanes,
-                wall * 1e3, issue_s * 1e3, 100.0 * issue_s / wall);
+        fprintf(stderr, "psm_lanes_render: %u frames on %u lanes, wall %.3f ms, issuing %.3f ms (%.0f %%); per round: issued -> count seen "
+                        "%.1f us\n", frames, lanes, wall * 1e3, issue_s * 1e3, 100.0 * issue_s / wall,
+                waits ? gpu_wait_s * 1e6 / waits : 0.0);
+        (void)react_s;
     }
     return rc;
 }
