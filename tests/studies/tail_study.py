@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Per-round traversal time vs work and vs the longest ray: is a launch bounded by throughput or by the
-dependent chain of its slowest wave? Uses the oracle only to count per-ray steps (study tool, not product)."""
+dependent chain of its slowest wave? Lives under tests/ because it uses the oracle (to count per-ray steps):
+only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/.
+usage (on a GPU box): python tests/studies/tail_study.py"""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import oracle as O

@@ -59,10 +59,10 @@ def test_no_device_fails_loudly(psm):
 def test_product_does_not_use_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
     banned = ("psmo_", "libpsm_oracle", "from oracle", "import oracle", "oracle/")
-    for top in ("prismarine-core_amd", "include"):
+    for top in ("prismarine-core_amd", "include", "tools", "profiles"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
             for f in files:
-                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
+                if f.endswith((".py", ".sh", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     for b in banned:
                         assert b not in txt, "%s references %r" % (os.path.join(dirpath, f), b)
