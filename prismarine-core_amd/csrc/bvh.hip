@@ -529,7 +529,7 @@ int launch_bvh_bounds(psm_bvh* b) {
     psm_ctx* c = b->ctx;
     uint32_t n = b->tri_count;
     bvh_init_bounds<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
-    uint32_t grid = min((n + 255u) / 256u, 2048u);
+    uint32_t grid = min((n + 255u) / 256u, 256u);  // one workgroup per CU: the 8 atomics per workgroup on the same 8 words are the cost
     if (grid) bvh_bounds<<<grid, 256, 0, c->stream>>>(b->d_pos, n, b->d_small);
     bvh_fit_transform<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
     PSM_HIP(c, hipGetLastError());
