@@ -273,7 +273,8 @@ int psm_rt_download_texels(psm_rt* rt, float* sum_rgba, float* coord_xy, int32_t
  * accumulated image equals the frames rendered one after another. Lanes never wait for each other's rounds: a
  * frame's traversal tail overlaps the other frames' kernels, and a lane takes the next frame as soon as its own is
  * folded. fold_into may be NULL when frames <= lanes (the lanes then keep their frames for the caller to fold).
- * Materials / lights / sky / textures / tiles must have been set on every rt. Returns when everything is idle.
+ * Materials / lights / sky / textures / tiles must have been set on every rt. One hierarchy per lane: frames that
+ * intersect several hierarchies (multi-BVH) go through the per-call API. Returns when everything is idle.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     uint32_t rounds; /* shade() calls made for this frame */
