@@ -23,6 +23,7 @@ namespace NSM {
         const TextureSet * texOwner = nullptr;
         uint32_t randState = 1;       // host rand() of Pipeline.inl:282,426 (MSVC CRT LCG), see setSeed
         uint32_t lightcount = 1;
+        int enable360 = 0;            // cameraUniformData.enable360, Pipeline.inl:119
         void init();
         uint32_t nextRand() { randState = randState * 214013u + 2531011u; return (randState >> 16) & 0x7fffu; }
 

@@ -25,7 +25,11 @@ namespace NSM {
 
     inline void Pipeline::setLightCount(size_t lc) { lightcount = (uint32_t)(lc < 1 ? 1 : (lc > 6 ? 6 : lc)); }
 
-    inline void Pipeline::switchMode() { clearRays(); clearSampler(); }   // 360-degree camera: not implemented
+    inline void Pipeline::switchMode() {   // :128-132
+        clearRays(); clearSampler();
+        enable360 = enable360 == 1 ? 0 : 1;
+        check(psm_rt_set_camera_mode(rt, enable360), "Pipeline::switchMode");
+    }
 
     inline void Pipeline::resize(const uint32_t & w, const uint32_t & h) {
         displayWidth = w; displayHeight = h;

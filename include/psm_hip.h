@@ -198,6 +198,9 @@ int psm_rt_set_materials(psm_rt* rt, const psm_material* mats, uint32_t count, i
  * matrices the reference uploads (:283-284); `time` replaces the host rand() (:282). Clears the
  * ray counters (clearRays) and this frame's texel sums. */
 int psm_rt_camera(psm_rt* rt, const float cam_inv[16], const float proj_inv[16], uint32_t time);
+/* cameraUniform.enable360 (switchMode(), Pipeline.inl:128-132; camera.comp:48-59): primary rays over the whole
+ * sphere (equirect image) from the camera position instead of through the projection */
+int psm_rt_set_camera_mode(psm_rt* rt, int enable360);
 /* raycountCache after reloadQueuedRays, Pipeline.inl:325-359 (the >=32 rule of getRayCount,
  * :459-461, is applied by the header layer). Synchronises. */
 int psm_rt_ray_count(psm_rt* rt, int32_t* count);

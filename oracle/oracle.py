@@ -38,7 +38,7 @@ class FrameCfg(C.Structure):
                 ("display_height", C.c_int), ("light_count", C.c_int), ("material_offset", C.c_int),
                 ("material_count", C.c_int), ("sky", C.c_float * 4), ("ray_limit", C.c_int),
                 ("samples_lock", C.c_int), ("sky_tex", C.c_void_p), ("sky_w", C.c_int), ("sky_h", C.c_int),
-                ("texcoords", C.c_void_p), ("textures", Texture * 32)]
+                ("texcoords", C.c_void_p), ("textures", Texture * 32), ("enable360", C.c_int)]
 
 
 def build(force=False):
@@ -386,7 +386,7 @@ def rand_next(state):
 
 def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, built=None,
                   cam=None, rows=None, record=None, skybox=None, parts=None, frame_streams=False,
-                  lights=None, display=None):
+                  lights=None, display=None, enable360=False):
     """Viewer.cpp:296-312 call order on the oracle: build, camera, <=depth x (traverse, shade), sample.
     Returns (filtered image [h,w,4], stats). parts: list of triangle-index arrays -- each becomes its own
     hierarchy and every round intersects them one after the other (multi-BVH); the scene's arrays must be
@@ -407,6 +407,7 @@ def render_frames(scene, width, height, frames=1, seed=1, depth=16, nthreads=0, 
     lights = default_lights(1) if lights is None else np.ascontiguousarray(lights, LIGHT_DT)
     dw, dh = display if display else (width, height)
     cfg = make_cfg(width, height, display=(dw, dh), lights=lights.shape[0], material_count=len(mats))
+    cfg.enable360 = int(enable360)
     if skybox is not None:
         set_skybox(cfg, skybox)
     if scene.get("texcoords") is not None or scene.get("textures"):

@@ -163,6 +163,7 @@ typedef struct {
     int sky_w, sky_h;
     const float* texcoords;        /* optional, 6 floats / triangle (u,v per vertex); NULL = all (0,0) */
     psmo_texture textures[32];     /* sampler table, surface.comp:46-52; slot 0 unused */
+    int enable360;                 /* cameraUniform.enable360 (switchMode, Pipeline.inl:128-132) */
 } psmo_frame_cfg;
 
 int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],

@@ -237,6 +237,26 @@ static int camera_bands(const psmo_frame_cfg* cfg, const float camInv[16], const
         float dd[3] = {co[0] - orig[0], co[1] - orig[1], co[2] - orig[2]};
         float dir[3];
         normalize3(dd, dir);
+        if (cfg->enable360 == 1) { /* camera.comp:48-59: equirect directions, two fixed quaternion turns */
+            const float PI_F = 3.1415926535897932384626422832795028841971f;
+            float picx = (ndc[0] * -1.f) * PI_F, picy = (ndc[1] * 0.5f) * PI_F;
+            float v[3] = {psmo_cosf(picy) * psmo_cosf(picx), psmo_cosf(picy) * psmo_sinf(picx), psmo_sinf(picy)};
+            const float axes[2][3] = {{0.f, 0.f, -1.f}, {1.f, 0.f, 0.f}};
+            for (int q = 0; q < 2; q++) {
+                float half = PI_F / 4.f;
+                float sh = psmo_sinf(half), ch = psmo_cosf(half);
+                float qv[3] = {axes[q][0] * sh, axes[q][1] * sh, axes[q][2] * sh};
+                float c1[3], t[3], c2[3];
+                cross3(v, qv, c1);
+                for (int k = 0; k < 3; k++) t[k] = c1[k] + ch * v[k];
+                cross3(t, qv, c2);
+                for (int k = 0; k < 3; k++) v[k] = v[k] + 2.0f * c2[k];
+            }
+            float o4[4] = {0.f, 0.f, 0.f, 1.f}, d4[4] = {v[0], v[1], v[2], 0.f}, od[4];
+            mat_vec(camInv, o4, orig);
+            mat_vec(camInv, d4, od);
+            for (int k = 0; k < 3; k++) dir[k] = od[k];
+        }
         psmo_ray r;
         for (int k = 0; k < 3; k++) { r.origin[k] = orig[k]; r.direct[k] = dir[k]; r.color[k] = 1.0f; }
         int bf = 0;

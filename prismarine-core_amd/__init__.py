@@ -27,7 +27,7 @@ EXPORTS = [
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
-    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_ray_count",
+    "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
     "psm_rt_traverse", "psm_rt_set_traverse_phases", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
@@ -478,6 +478,13 @@ class Pipeline:
 
     def clearSampler(self):
         self.ctx.check(lib().psm_rt_clear_sampler(self._h), "psm_rt_clear_sampler")
+
+    def switchMode(self):
+        """Pipeline.inl:128-132: clear, then toggle the 360-degree camera (camera.comp:48-59)."""
+        self.raycountCache = 0
+        self.clearSampler()
+        self.enable360 = 0 if getattr(self, "enable360", 0) else 1
+        self.ctx.check(lib().psm_rt_set_camera_mode(self._h, C.c_int(self.enable360)), "psm_rt_set_camera_mode")
 
     def camera_matrices(self, cam_inv, proj_inv, time=None):
         t = self._rand() if time is None else time

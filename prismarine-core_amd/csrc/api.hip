@@ -672,6 +672,12 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
     return launch_rt_traverse(r, b);
 }
 
+int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
+    if (!r) return PSM_ERR_INVALID;
+    r->enable360 = enable360 ? 1 : 0;
+    return PSM_OK;
+}
+
 int psm_rt_set_traverse_phases(psm_rt* r, const uint32_t* caps, uint32_t count, uint32_t min_rays) {
     if (!r || count > 7 || (count && !caps)) return PSM_ERR_INVALID;
     for (uint32_t k = 0; k < count; k++) {

@@ -150,6 +150,7 @@ struct psm_rt {
     psm_bvh* trav_objs[psm::MAX_TRAV_OBJECTS] = {};  // hierarchies traversed since the queue last changed
     int trav_n = 0;
     psm::ObjGeom* d_geoms = nullptr;
+    int enable360 = 0;            // cameraUniform.enable360 (switchMode)
     // phased traversal (trace.hip): continuation queues, allocated on first use
     void* d_phase_mem = nullptr;
     psm::TravState phase_state[2] = {};

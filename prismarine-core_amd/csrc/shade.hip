@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
                                                  Tile tile, uint32_t nrays, float4* __restrict__ qA,
                                                  float4* __restrict__ qB, float4* __restrict__ qC,
                                                  float2* __restrict__ t_coord, float4* __restrict__ t_sum,
-                                                 int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt) {
+                                                 int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt, int enable360) {
     uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx == 0) { cnt[0] = nrays; cnt[1] = 0; cnt[2] = 0; }
     if (idx >= w * h) return;
@@ -105,6 +105,25 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
 #pragma unroll
     for (int k = 0; k < 4; k++) { co[k] = co[k] / cw; orig[k] = orig[k] / ow; }
     v3 dir = normalize3(mk3(co[0] - orig[0], co[1] - orig[1], co[2] - orig[2]));
+    if (enable360 == 1) {  // camera.comp:48-59: equirect directions, two fixed quaternion turns
+        const float PI_F = 3.1415926535897932384626422832795028841971f;
+        float picx = (nx * -1.f) * PI_F, picy = (ny * 0.5f) * PI_F;
+        v3 v = mk3(pcos(picy) * pcos(picx), pcos(picy) * psin(picx), psin(picy));
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float half = PI_F / 4.f;
+            const float sh = psin(half), ch = pcos(half);
+            v3 qv = q == 0 ? mk3(0.f * sh, 0.f * sh, -1.f * sh) : mk3(1.f * sh, 0.f * sh, 0.f * sh);
+            v3 c1 = cross3(v, qv);
+            v3 t = mk3(c1.x + ch * v.x, c1.y + ch * v.y, c1.z + ch * v.z);
+            v3 c2 = cross3(t, qv);
+            v = mk3(v.x + 2.0f * c2.x, v.y + 2.0f * c2.y, v.z + 2.0f * c2.z);
+        }
+        float od[4];
+        mat_vec(camInv.m, 0.f, 0.f, 0.f, 1.f, orig);
+        mat_vec(camInv.m, v.x, v.y, v.z, 0.f, od);
+        dir = mk3(od[0], od[1], od[2]);
+    }
     int bf = 0;
     S_ACTIVE(bf, 1); S_TYPE(bf, 0); S_DL(bf, 0); S_BOUNCE(bf, 4); S_BASIS(bf, 1);
     S_BOUNCE(bf, R_BOUNCE(bf) - 1);  // createRayIdx -> createRayStrict, rayslib.glsl:130-156
@@ -766,7 +785,7 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
     TimedScope ts(c, CAT_CAMERA);
     uint32_t nrays = tile_texel_count(r);
     rt_camera<<<(n + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, make_tile(r), nrays, r->qA[r->cur], r->qB[r->cur],
-                                                      r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt);
+                                                      r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt, r->enable360);
     PSM_HIP(c, hipGetLastError());
     r->ray_count = nrays;
     r->count_valid = true;

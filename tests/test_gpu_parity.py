@@ -789,6 +789,39 @@ def test_supersampled_ray_grid_and_depth_limit(psm, ctx, oracle, scenes):
     th.close()
 
 
+def test_camera_360_mode(psm, ctx, oracle, scenes):
+    """switchMode() (Pipeline.inl:128-132) -> cameraUniform.enable360 (camera.comp:48-59): primary rays over the
+    whole sphere from the camera position, bit-exact; a frame's radiance within 1e-4; switching back restores the
+    projected camera."""
+    scene = scenes.cornell(open_top=True)
+    w, h = 96, 48
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    mats = scenes.materials_array(scene["materials"])
+    cfg = oracle.make_cfg(w, h, material_count=len(mats))
+    rt.switchMode()
+    cfg.enable360 = 1
+    rt.camera_matrices(cam[0], cam[1], time=21)
+    orays, _, _, _ = oracle.camera(cfg, cam[0], cam[1], 21)
+    grays = rt.download_rays()
+    _rays_equal(grays, orays)
+    d = grays["direct"]
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-4)
+    assert (d[:, 1] > 0.5).any() and (d[:, 1] < -0.5).any() and (d[:, 0] > 0.5).any() and (d[:, 0] < -0.5).any()
+    assert np.ptp(grays["origin"], axis=0).max() < 1e-6            # every ray starts at the eye
+    rt.setSeed(8)
+    rt.clearSampler()
+    psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    ref, _ = oracle.render_frames(scene, w, h, frames=1, seed=8, enable360=True)
+    np.testing.assert_allclose(rt.snapHdr()[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    rt.switchMode()
+    cfg.enable360 = 0
+    rt.camera_matrices(cam[0], cam[1], time=21)
+    orays, _, _, _ = oracle.camera(cfg, cam[0], cam[1], 21)
+    _rays_equal(rt.download_rays(), orays)
+    rt.close()
+    th.close()
+
+
 def _sky_image(w=64, h=32):
     yy, xx = np.mgrid[0:h, 0:w]
     img = np.zeros((h, w, 4), np.uint8)
