@@ -115,9 +115,11 @@ class Renderer:
                                  rebuild=not self.args.no_rebuild)
 
     def frames_in_flight_sharded(self, k):
-        """k x process() of a tile-sharded frame with `lanes` frames in flight on every rank: the lanes' kernels
-        overlap inside a round, one count exchange per round serves all lanes (dist.run_rounds_lanes), one
-        gather per frame, rank 0 folds the frames in order. Returns the rays this rank traced."""
+        """k x process() of a tile-sharded frame with `lanes` frames in flight on every rank. RCCL: the lanes run
+        free until their local ray counts park them and one small all-gather per batch applies the global stop
+        rule (dist.run_batch_sharded); gloo rehearsal: lock-step rounds with a host exchange
+        (dist.run_rounds_lanes). One gather per frame, rank 0 folds the frames in order. Returns the rays this rank
+        traced."""
         dist, batch, ms = self.dist, self.batch, self.ms
         torch = dist.torch
         w, h = self.args.width, self.args.height
