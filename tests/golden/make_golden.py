@@ -32,4 +32,14 @@ np.savez_compressed(os.path.join(HERE, "cornell_32.npz"), tris=sc["tris"], M=b["
 sc = scenes.cornell(open_top=True)
 img, stats = O.render_frames(sc, 48, 48, frames=2, seed=31337)
 np.savez_compressed(os.path.join(HERE, "cornell_open_radiance.npz"), image=img, rays=np.int64(stats["rays"]))
+# round-1 additions: textures + normal maps + every texture part, three lights, the 2x supersampled ray grid, the
+# per-frame rand() streams of frames in flight, and the 360-degree camera
+sct = scenes.textured(scenes.cornell(open_top=True))
+L = O.default_lights(3)
+L[1]["lightVector"] = (-0.5, 0.8, 0.6, 30.0); L[1]["lightColor"] = (40.0, 10.0, 5.0, 3.0); L[1]["lightOffset"] = (0.2, 0.0, -0.3, 0.0)
+L[2]["lightVector"] = (0.1, -1.0, 0.2, 5.0); L[2]["lightColor"] = (2.0, 8.0, 30.0, 1.5); L[2]["lightAmbient"] = (0.05, 0.02, 0.01, 0.0)
+img2, st2 = O.render_frames(sct, 64, 48, frames=3, seed=2718, frame_streams=True, lights=L, display=(32, 24))
+img3, st3 = O.render_frames(sc, 48, 24, frames=1, seed=99, enable360=True)
+np.savez_compressed(os.path.join(HERE, "cornell_open_round1_features.npz"), textured=img2, textured_rays=np.int64(st2["rays"]),
+                    pano=img3, pano_rays=np.int64(st3["rays"]))
 print("wrote fixtures; rays", stats["rays"], "hit fraction", float((counts > 0).mean()))

@@ -822,6 +822,44 @@ def test_camera_360_mode(psm, ctx, oracle, scenes):
     th.close()
 
 
+def test_gpu_matches_committed_golden_fixture(psm, oracle, scenes):
+    """The HIP path against tests/golden/cornell_open_round1_features.npz (committed oracle output, not recomputed
+    here): textures + normal maps, three lights, 2x supersampled ray grid, three frames in flight on two lanes;
+    and the 360-degree camera."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_open_round1_features.npz"))
+    sct = scenes.textured(scenes.cornell(open_top=True))
+    batch = psm.FrameBatch(2, 64, 48, seed=2718, display=(32, 24))
+    batch.allocate(sct["tris"].shape[0])
+    batch.loadTriangles(sct["tris"], sct["normals"], sct["mats"], sct["texcoords"])
+    ms = psm.MaterialSet()
+    for m in sct["materials"]:
+        ms.addSubmat(m)
+    ts = psm.TextureSet()
+    for slot in sorted(sct["textures"]):
+        ts.loadTexture(sct["textures"][slot])
+    ms.setTextureSet(ts)
+    batch.applyMaterials(ms)
+    L = _three_lights(oracle)
+    batch.each(lambda r: r.setLights(L))
+    per_frame = batch.render(3, sct["eye"], sct["view"])
+    img = batch.snapHdr()
+    assert sum(r for _, r in per_frame) == int(g["textured_rays"])
+    np.testing.assert_allclose(img[..., :3], g["textured"][..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], g["textured"][..., 3])
+    batch.close()
+    ctx = psm.Context(0)
+    sc = scenes.cornell(open_top=True)
+    th, rt, ms2, cam = _setup_frame(psm, ctx, scenes, sc, 48, 24)
+    rt.switchMode()
+    rt.setSeed(99)
+    psm.render_frame(rt, th, ms2, sc["eye"], sc["view"])
+    np.testing.assert_allclose(rt.snapHdr()[..., :3], g["pano"][..., :3], rtol=1e-4, atol=1e-5)
+    rt.close()
+    th.close()
+    ctx.close()
+
+
 def _sky_image(w=64, h=32):
     yy, xx = np.mgrid[0:h, 0:w]
     img = np.zeros((h, w, 4), np.uint8)
