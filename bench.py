@@ -102,6 +102,7 @@ class Renderer:
             self.per = self.pdist.interleaved_texels(0, dist.world, w, h) * 4  # rank 0 owns the most bands
             self.tile_dev = torch.zeros(self.per, dtype=torch.float32, device=gdev)
             self.lane_tiles = [self.tile_dev] + [torch.zeros(self.per, dtype=torch.float32, device=gdev) for _ in range(self.lanes - 1)]
+            self.gather_done = [None] * self.lanes
             self.all_dev = torch.zeros(dist.world * self.per, dtype=torch.float32, device=gdev) if dist.rank == 0 else None
 
     def frames_in_flight(self, k):
@@ -141,12 +142,16 @@ class Renderer:
                                             initial_totals=[dist.initial_total] * len(lanes))
             traced += sum(ln.ctx.stats().rays_traced - b for ln, b in zip(lanes, before))
             for s, ln in enumerate(lanes):  # frame order
+                if dist.backend == "nccl" and self.gather_done[s] is not None:
+                    self.lane_streams[s].wait_event(self.gather_done[s])  # the previous gather has read this tile buffer
                 ln.rays.pack_texels_dev(self.lane_tiles[s].data_ptr())
                 if dist.backend == "nccl":
                     main = torch.cuda.current_stream()
                     main.wait_stream(self.lane_streams[s])
                     dist.gather_to_root(self.lane_tiles[s], self.all_dev)
-                    self.lane_streams[s].wait_stream(main)  # the lane's next pack / unpack comes after the gather
+                    self.gather_done[s] = main.record_event()
+                    if dist.rank == 0:
+                        self.lane_streams[s].wait_event(self.gather_done[s])  # the unpack below reads all_dev
                 else:  # host-staged rehearsal path (gloo)
                     ln.ctx.sync()
                     got = dist.gather_to_root(self.lane_tiles[s].cpu())
