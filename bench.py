@@ -331,6 +331,7 @@ def main():
                                                                 (args.width, args.height) == (1920, 1080)) else (None, None)
         avg_ms = st.traverse_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        copy_gbs = ctx.copy_bandwidth(1 << 30, 5)  # the box's achievable ceiling next to the vendor peak
         out = {
             "metric": "Mrays/sec + ms/frame, Sponza 1920x1080 4spp",
             "value": total_rays / elapsed / 1e6,
@@ -356,6 +357,7 @@ def main():
                                    "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "measured_copy_gbs": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs > 0 else None,
                          "kernel": "rt_traverse", "launches": int(st.traverse_launches), "avg_launch_ms": avg_ms,
                          "measured": ("kernel pass: the timed region's frames one after another, HIP events per launch "
                                       "(launch durations overlap when several frames are in flight)") if lanes_mode

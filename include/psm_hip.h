@@ -48,7 +48,9 @@ int psm_ctx_create(int device, psm_ctx** out);
  * so kernels and RCCL calls are ordered without host synchronisation); the stream is not owned */
 int psm_ctx_create_on_stream(int device, void* hip_stream, psm_ctx** out);
 int psm_ctx_destroy(psm_ctx* ctx);
-int psm_ctx_sync(psm_ctx* ctx);                 /* synchronises (glFinish, Viewer.cpp:314) */
+int psm_ctx_sync(psm_ctx* ctx);
+/* measured HBM ceiling of the box: device-to-device copy of `bytes`, best of `reps`, in GB/s of traffic (read + write) */
+int psm_ctx_copy_bandwidth(psm_ctx* ctx, size_t bytes, int reps, double* gb_per_s);                 /* synchronises (glFinish, Viewer.cpp:314) */
 void* psm_ctx_stream(psm_ctx* ctx);             /* the hipStream_t every launch goes to */
 const char* psm_last_error(psm_ctx* ctx);
 int psm_device_count(void);

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSM_HIP_LIB") or os.path.join(_HERE, "libpsm_hip.so")  # override: A/B builds of the same ABI
 
 EXPORTS = [
-    "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_stream", "psm_last_error",
+    "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_copy_bandwidth", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev",
     "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build",
@@ -130,6 +130,12 @@ class Context:
     @property
     def stream(self):
         return lib().psm_ctx_stream(self._h)
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=5):
+        """Measured device-to-device copy rate in GB/s of traffic (read + write): the box's achievable HBM ceiling."""
+        v = C.c_double()
+        self.check(lib().psm_ctx_copy_bandwidth(self._h, C.c_size_t(nbytes), C.c_int(reps), C.byref(v)), "psm_ctx_copy_bandwidth")
+        return v.value
 
     def stats_enable(self, timing=True, counting=False):
         self.check(lib().psm_stats_enable(self._h, C.c_int(int(timing)), C.c_int(int(counting))), "psm_stats_enable")

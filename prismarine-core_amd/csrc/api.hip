@@ -134,6 +134,40 @@ int psm_ctx_destroy(psm_ctx* c) {
     return PSM_OK;
 }
 
+// Achievable HBM ceiling of this box: device-to-device copy of `bytes` (read + write = 2 x bytes of traffic),
+// best of `reps`, timed with HIP events on the context's stream (report the roofline fraction
+// against a measured ceiling as well as the vendor peak).
+int psm_ctx_copy_bandwidth(psm_ctx* c, size_t bytes, int reps, double* gb_per_s) {
+    if (!c || !gb_per_s || bytes == 0 || reps <= 0) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PSM_OK;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = PSM_ERR_HIP;
+    float best = 0.f;
+    if (rc == PSM_OK) {
+        (void)hipMemsetAsync(a, 1, bytes, c->stream);
+        (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream);  // warm-up
+        for (int i = 0; i < reps && rc == PSM_OK; i++) {
+            (void)hipEventRecord(e0, c->stream);
+            (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream);
+            (void)hipEventRecord(e1, c->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = PSM_ERR_HIP; break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms > 0.f && (best == 0.f || ms < best)) best = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (rc != PSM_OK) return set_err(c, rc, "psm_ctx_copy_bandwidth");
+    *gb_per_s = best > 0.f ? 2.0 * (double)bytes / ((double)best * 1e-3) / 1e9 : 0.0;
+    return PSM_OK;
+}
+
 int psm_ctx_sync(psm_ctx* c) {
     if (!c) return PSM_ERR_INVALID;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
