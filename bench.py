@@ -352,7 +352,9 @@ def main():
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
             "stage_ms_per_frame_measured": "kernel pass (one frame after another)" if lanes_mode else "timed region",
-            "stage_ms_per_frame": {"build": st.build_ms / args.steps, "sort": st.sort_ms / args.steps,
+            "stage_ms_per_frame": {"build": st.build_ms / args.steps, "bounds": st.bounds_ms / args.steps,
+                                   "morton": st.morton_ms / args.steps, "sort": st.sort_ms / args.steps,
+                                   "emit_refit": st.emit_ms / args.steps,
                                    "camera": st.camera_ms / args.steps, "traverse": st.traverse_ms / args.steps,
                                    "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

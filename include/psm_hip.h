@@ -313,6 +313,7 @@ typedef struct {
     float traverse_ms;        /* sum of HIP-event durations of the traverse kernel */
     float build_ms, sort_ms, shade_ms, camera_ms, sample_ms;
     uint32_t rounds;
+    float bounds_ms, morton_ms, emit_ms; /* parts of build_ms: minmax + fit, Morton codes + leaves, node emission + link + refit */
 } psm_stats;
 int psm_stats_enable(psm_ctx* ctx, int timing, int counting);
 int psm_stats_reset(psm_ctx* ctx);

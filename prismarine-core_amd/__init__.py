@@ -78,7 +78,8 @@ class Stats(C.Structure):
                 ("chain_pool_drops", C.c_uint64), ("ray_limit_drops", C.c_uint64),
                 ("traverse_launches", C.c_uint32), ("traverse_ms", C.c_float), ("build_ms", C.c_float),
                 ("sort_ms", C.c_float), ("shade_ms", C.c_float), ("camera_ms", C.c_float),
-                ("sample_ms", C.c_float), ("rounds", C.c_uint32)]
+                ("sample_ms", C.c_float), ("rounds", C.c_uint32), ("bounds_ms", C.c_float), ("morton_ms", C.c_float),
+                ("emit_ms", C.c_float)]
 
 
 _lib = None

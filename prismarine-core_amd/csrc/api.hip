@@ -916,6 +916,9 @@ int psm_stats_get(psm_ctx* c, psm_stats* out) {
     out->camera_ms = c->cat_ms[CAT_CAMERA];
     out->sample_ms = c->cat_ms[CAT_SAMPLE];
     out->rounds = c->rounds;
+    out->bounds_ms = c->cat_ms[CAT_BOUNDS];
+    out->morton_ms = c->cat_ms[CAT_MORTON];
+    out->emit_ms = c->cat_ms[CAT_EMIT];
     return PSM_OK;
 }
 

@@ -527,6 +527,7 @@ int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n) {
 
 int launch_bvh_bounds(psm_bvh* b) {
     psm_ctx* c = b->ctx;
+    TimedScope ts(c, CAT_BOUNDS);
     uint32_t n = b->tri_count;
     bvh_init_bounds<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
     uint32_t grid = min((n + 255u) / 256u, 256u);  // one workgroup per CU: the 8 atomics per workgroup on the same 8 words are the cost
@@ -538,6 +539,7 @@ int launch_bvh_bounds(psm_bvh* b) {
 
 int launch_bvh_morton(psm_bvh* b) {
     psm_ctx* c = b->ctx;
+    TimedScope ts(c, CAT_MORTON);
     uint32_t n = b->tri_count;
     uint32_t nb = (n + 255u) / 256u;
     if (nb == 0) return PSM_OK;
@@ -551,6 +553,7 @@ int launch_bvh_morton(psm_bvh* b) {
 
 int launch_bvh_emit(psm_bvh* b) {
     psm_ctx* c = b->ctx;
+    TimedScope ts(c, CAT_EMIT);
     uint32_t n = b->tri_count;  // upper bound of the leaf count
     if (n == 0) return PSM_OK;
     int nlev = (int)b->seg_off.size() - 1;  // levels 0..nlev-1

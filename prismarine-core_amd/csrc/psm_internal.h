@@ -43,7 +43,7 @@ struct Phase {
     uint32_t* out_count;
 };
 
-enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_COUNT };
+enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_BOUNDS, CAT_MORTON, CAT_EMIT, CAT_COUNT };
 
 // device-resident counters (one block per context)
 struct DevCounters {
