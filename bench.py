@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--lanes", type=int, default=4,
                     help="frames in flight per GPU (psm_lanes_render): each on its own HIP stream, folded into the "
                          "accumulating image in frame order; 1 = one frame after another")
+    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive", "persistent"],
+                    help="tuning study: traversal kernel schedule (psm_rt_set_traverse_mode); results never depend on it")
+    ap.add_argument("--trav-caps", default="96", help="phased: wave-step caps, comma separated")
+    ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
     return ap.parse_args()
 
 
@@ -88,6 +92,14 @@ class Renderer:
                 assert ts.loadTexture(scene["textures"][slot]) == slot
             self.ms.setTextureSet(ts)
         self.batch.applyMaterials(self.ms)
+        if args.traverse != "auto" or args.trav_adaptive:
+            def tune(r):
+                if args.trav_adaptive:
+                    r.setTraverseAdaptive(*[int(v) for v in args.trav_adaptive.split(",")])
+                if args.traverse == "phased":
+                    r.setTraversePhases([int(v) for v in args.trav_caps.split(",")])
+                r.setTraverseMode(args.traverse)
+            self.batch.each(tune)
         if dist.active and not (args.emulate_tile and dist.world == 1):
             self.batch.each(lambda r: r.setTileInterleaved(dist.rank, dist.world))  # 8-row bands dealt round-robin
             dist.initial_total = w * h

@@ -213,13 +213,30 @@ int psm_rt_ray_count(psm_rt* rt, int32_t* count);
  * hierarchies of < 2^27 triangles each per queue; psm_rt_shade() then interpolates each hit from the
  * hierarchy that produced it (its `bvh` argument is used when only one was traversed). */
 int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
-/* Phased traversal (a tuning knob, results never change): an intersection() over at least `min_rays` rays is cut
- * into count + 1 launches; launch k runs at most caps[k] wave-steps (a wave steps as long as its slowest ray), the
- * rays still under way hand their state (node, stack, best hit) to a dense continuation queue and the next launch
- * resumes them packed 64 to a wave; the last launch runs to completion. Default (never called): automatic -- one
- * cap of 96 from 2^20 rays while the Pipeline is one of several frames in flight (psm_lanes_*: the other frames'
- * kernels fill the extra launch's tail), a single launch otherwise; count = 0: always one launch. */
+/* Which kernel schedule an intersection() runs as. A tuning knob: hits, chains and counters never depend on it
+ * (every schedule performs, per ray, the node steps and triangle tests of directTraverse.comp:333-484 in the
+ * same order). A wave64 steps as long as its slowest ray; the schedules differ in how they keep lanes busy:
+ *   WHOLE       one launch, 64 consecutive rays per wave, run to completion
+ *   PHASED      launch k runs at most caps[k] wave-steps, then the rays still under way hand their state (node,
+ *               stack, best hit) to a dense continuation queue and the next launch resumes them packed 64 to a
+ *               wave; the last launch runs to completion (psm_rt_set_traverse_phases)
+ *   ADAPTIVE    the same hand-over, triggered per wave by __ballot / popcount: a wave hands over as soon as fewer
+ *               than min_live of its lanes have work left; resume launches are persistent waves striding over the
+ *               continuation queue (psm_rt_set_traverse_adaptive)
+ *   PERSISTENT  persistent threads with per-lane refill from a launch-wide ray cursor (rt_traverse_pt)
+ *   AUTO        the library's choice (default). Further hierarchies of a multi-BVH queue always run WHOLE. */
+enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3, PSM_TRAVERSE_PERSISTENT = 4 };
+int psm_rt_set_traverse_mode(psm_rt* rt, int mode);
+/* PHASED: count caps (1..7) -> count + 1 launches, for intersections over at least min_rays rays; count = 0 selects
+ * WHOLE. Selects PSM_TRAVERSE_PHASED. */
 int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count, uint32_t min_rays);
+/* ADAPTIVE parameters (does not change the mode): hand over below min_live live lanes (2..64) but not before
+ * min_steps wave-steps; a resume launch that finds at most final_rays rays waiting finishes them; at most
+ * max_launches launches (2..15) per intersection; intersections under min_rays rays run WHOLE. */
+int psm_rt_set_traverse_adaptive(psm_rt* rt, uint32_t min_live, uint32_t min_steps, uint32_t final_rays,
+                                 uint32_t max_launches, uint32_t min_rays);
+/* PERSISTENT parameters: finished slots per wave that trigger a refill pass (1..64); grid in workgroups (0 = resident) */
+int psm_rt_set_traverse_persistent(psm_rt* rt, uint32_t refill_min, uint32_t grid_blocks);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
 int psm_rt_reset_hits(psm_rt* rt);
 /* applyMaterials + shade, Pipeline.inl:407-436 -> surface.comp + rayshading.comp, then the

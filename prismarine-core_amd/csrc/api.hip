@@ -712,14 +712,38 @@ int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
     return PSM_OK;
 }
 
+int psm_rt_set_traverse_mode(psm_rt* r, int mode) {
+    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_PERSISTENT) return PSM_ERR_INVALID;
+    r->trav_mode = mode;
+    return PSM_OK;
+}
+
 int psm_rt_set_traverse_phases(psm_rt* r, const uint32_t* caps, uint32_t count, uint32_t min_rays) {
     if (!r || count > 7 || (count && !caps)) return PSM_ERR_INVALID;
-    for (uint32_t k = 0; k < count; k++) {
+    for (uint32_t k = 0; k < count; k++)
         if (caps[k] == 0) return PSM_ERR_INVALID;
-        r->phase_caps[k] = caps[k];
-    }
+    for (uint32_t k = 0; k < count; k++) r->phase_caps[k] = caps[k];
     r->phase_caps_n = (int)count;
     r->phase_min_rays = min_rays;
+    r->trav_mode = count ? PSM_TRAVERSE_PHASED : PSM_TRAVERSE_WHOLE;
+    return PSM_OK;
+}
+
+int psm_rt_set_traverse_adaptive(psm_rt* r, uint32_t min_live, uint32_t min_steps, uint32_t final_rays,
+                                 uint32_t max_launches, uint32_t min_rays) {
+    if (!r || min_live < 2 || min_live > 64 || max_launches < 2 || max_launches > 15) return PSM_ERR_INVALID;
+    r->adapt_min_live = min_live;
+    r->adapt_min_steps = min_steps;
+    r->adapt_final_rays = final_rays;
+    r->adapt_max_launches = max_launches;
+    r->phase_min_rays = min_rays;
+    return PSM_OK;
+}
+
+int psm_rt_set_traverse_persistent(psm_rt* r, uint32_t refill_min, uint32_t grid_blocks) {
+    if (!r || refill_min < 1 || refill_min > 64) return PSM_ERR_INVALID;
+    r->pt_refill_min = refill_min;
+    r->pt_grid = grid_blocks;
     return PSM_OK;
 }
 

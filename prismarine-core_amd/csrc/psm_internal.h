@@ -37,7 +37,10 @@ struct TravState {      // structure of arrays, `capacity` entries each
     uint32_t capacity;
 };
 struct Phase {
-    uint32_t cap;              // wave-steps this launch may take (0xFFFFFFFF: run to completion)
+    uint32_t cap;              // wave-steps this launch may take (0xFFFFFFFF: no cap)
+    uint32_t min_live;         // a wave hands its rays over once fewer than this many lanes have work left (0: never)
+    uint32_t min_steps;        // ... but not before this many wave-steps
+    uint32_t final_rays;       // resume: with no more than this many rays waiting the launch runs them to completion
     const uint32_t* in_count;  // resume: number of suspended rays (device), nullptr = fresh rays
     TravState in, out;
     uint32_t* out_count;
@@ -156,8 +159,11 @@ struct psm_rt {
     psm::TravState phase_state[2] = {};
     uint32_t* d_phase_cnt = nullptr;
     uint32_t phase_cap = 0;
-    uint32_t phase_caps[7] = {0};   // wave-step caps of the launches before the last one; n = 0: one launch
-    int phase_caps_n = -1;          // -1: automatic -- PSM_TRAV_PHASES or 96 while frames are in flight, one launch otherwise
+    uint32_t phase_caps[7] = {96};  // PSM_TRAVERSE_PHASED: wave-step caps of the launches before the last one
+    int phase_caps_n = 1;
+    int trav_mode = 0;              // PSM_TRAVERSE_* (psm_rt_set_traverse_mode); 0 = automatic
+    uint32_t adapt_min_live = 16, adapt_min_steps = 8, adapt_final_rays = 4096, adapt_max_launches = 8;
+    uint32_t pt_refill_min = 8, pt_grid = 0;  // PSM_TRAVERSE_PERSISTENT tuning
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
     uint32_t phase_min_rays = 1u << 20;
     // frames in flight (lanes.hip): pinned slot + events, created on first use

@@ -76,11 +76,14 @@ struct Baked {
 // search starts from the distance of the chain the ray already carries (traverse(), :335-346) and the hits
 // it bakes overwrite the front of that chain, the rest of the old chain staying linked behind them
 // (includeChain, :219-249). Triangle ids are tagged with the object's sequence number (bits 27..30).
-// PHASED: a traversal is cut into launches of at most `cap` wave-steps. A wave runs in lock step, so its
-// cost is its slowest ray (mean 56 steps per bounce ray, mean per-wave maximum 118): when the cap is hit, the
-// rays that are not done write their traversal state (node, stack, best hit) to a dense continuation queue and
-// the next launch resumes them packed 64 to a wave. Per ray nothing changes -- the same node steps and
-// triangle tests in the same order -- so hits, chains and counters are bit-exact; only the idle lanes go.
+// PHASED: wave64 ray compaction. A wave runs in lock step, so it costs as much as its slowest ray (mean 56
+// steps per bounce ray, mean per-wave maximum 118): most lanes idle behind a few long rays. A PHASED launch
+// lets a wave hand over: when fewer than `min_live` of its lanes still have work (__ballot / popcount, wave
+// uniform), or after `cap` wave-steps, the rays that are not done write their traversal state (node, stack,
+// best hit) to a dense continuation queue -- one atomic per wave, lanes ranked by __ballot -- and the next
+// launch resumes them packed 64 to a wave. Resume launches are persistent: a fixed grid of waves strides over
+// the continuation queue, 64 rays at a time. Per ray nothing changes -- the same node steps and triangle
+// tests in the same order -- so hits, chains and counters are bit-exact; only the idle lanes go.
 template <bool COUNT, bool CHAIN, bool PHASED>
 __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __restrict__ qA, const float4* __restrict__ qB,
                                                           uint32_t nrays, const uint4* __restrict__ node32,
@@ -90,26 +93,28 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                                                           uint32_t pool_cap, uint32_t* __restrict__ cnt,
                                                           DevCounters* __restrict__ ctr, uint32_t obj_tag, Phase ph) {
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
-    uint32_t i = blockIdx.x * TRAV_BLOCK + threadIdx.x;
     const int tid = threadIdx.x;
-    bool alive = i < nrays;
     const bool resume = PHASED && ph.in_count != nullptr;
-    uint32_t slot = i;
-    if (resume) {
-        alive = slot < *ph.in_count;
-        i = alive ? ph.in.idx[slot] : 0u;
-    }
+    const uint32_t total = resume ? *ph.in_count : nrays;
+    // with few rays left there is nothing to pack them with: the launch finishes them
+    const uint32_t min_live = (PHASED && !(resume && total <= ph.final_rays)) ? ph.min_live : 0u;
+    const uint32_t cap = (PHASED && !(resume && total <= ph.final_rays)) ? ph.cap : 0xFFFFFFFFu;
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
+    float M[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
+    const int root = (int)sm[SM_ROOT];
+    // fresh rays: one ray per thread of the grid. Resume: every wave strides over the continuation queue.
+    for (uint32_t batch = blockIdx.x * TRAV_BLOCK + (uint32_t)(tid & ~63); batch < total; batch += gridDim.x * TRAV_BLOCK) {
+    const uint32_t slot = batch + (uint32_t)(tid & 63);
+    bool alive = slot < total;
+    uint32_t i = slot;
+    if (resume) i = alive ? ph.in.idx[slot] : 0u;
 
     float4 A = alive ? qA[i] : make_float4(0, 0, 0, 0);
     float4 B = alive ? qB[i] : make_float4(1, 0, 0, 0);
     v3 origin = mk3(A.x, A.y, A.z);
     v3 direct = normalize3(mk3(B.x, B.y, B.z));  // :350
-
-    float M[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
-    int root = (int)sm[SM_ROOT];
 
     float to4[4], td4[4];
     mat_vec(M, origin.x, origin.y, origin.z, 1.0f, to4);   // :353
@@ -225,7 +230,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
         const bool parkedNow = (pl & pr) != -1;
         const unsigned long long pend = __ballot(parkedNow);
         const unsigned long long canStep = __ballot(validBox && !parkedNow);
-        const bool capHit = PHASED && (++wsteps >= ph.cap);  // wave-uniform
+        // wave-uniform: the cap, or too few lanes with work left (parked or able to step) to be worth a wave
+        const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && (uint32_t)__popcll(pend | canStep) < min_live));
         if (pend == 0ull) {
             if (canStep == 0ull) break;
             if (!capHit) continue;
@@ -375,6 +381,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
         else hit0[i] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
         hitN[i] = count | (off << 4);
     }
+    if (!resume) break;
+    }  // batches
     if (COUNT) {
         uint32_t v = wave_sum(nV), t = wave_sum(nT), d = wave_sum(nDrop), c = wave_sum(nCap), b = wave_sum(nBakedDrop);
         if (lane_id() == 0) {
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
 constexpr int PT_BLOCK = 256;
 constexpr int PT_WAVES = PT_BLOCK / 64;
 struct PtTune {
-    int refill_min, tri_min;
+    int refill_min;  // finished slots of a wave that trigger a finalise + refill pass
 };
 
 struct Slab2 {
@@ -680,34 +688,8 @@ __global__ __launch_bounds__(PT_BLOCK) void rt_traverse_pt(const float4* __restr
     }
 }
 
-static bool use_simple_traverse() {  // thread-safe (lanes issue from their own host threads)
-    static const bool simple = [] {
-        const char* e = getenv("PSM_TRAVERSE");
-        return !(e && std::strcmp(e, "persistent") == 0);  // see DESIGN.md "traversal": measured faster
-    }();
-    return simple;
-}
-
-constexpr size_t MAX_PHASES = 8;
-
-// wave-step caps of the phased traversal: PSM_TRAV_PHASES="96" (default; "64,64" = three launches), "" or "0" = one launch
-static const std::vector<uint32_t>& phase_caps() {
-    static const std::vector<uint32_t> caps = [] {
-        std::vector<uint32_t> c;
-        const char* e = getenv("PSM_TRAV_PHASES");
-        std::string v = e ? e : "96";
-        size_t pos = 0;
-        while (pos < v.size() && c.size() + 1 < MAX_PHASES) {
-            size_t q = v.find(',', pos);
-            if (q == std::string::npos) q = v.size();
-            int x = atoi(v.substr(pos, q - pos).c_str());
-            if (x > 0) c.push_back((uint32_t)x);
-            pos = q + 1;
-        }
-        return c;
-    }();
-    return caps;
-}
+constexpr size_t MAX_PHASES = 16;
+constexpr uint32_t RESUME_GRID_CAP = 256 * 16;  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
 static int ensure_phase_buffers(psm_rt* r) {
     psm_ctx* c = r->ctx;
@@ -734,6 +716,34 @@ static int ensure_phase_buffers(psm_rt* r) {
     return PSM_OK;
 }
 
+// One launch of a hand-over schedule: the wave-step cap (0xFFFFFFFF: none) and the live-lane threshold (0: none)
+struct PhasePlan {
+    uint32_t cap, min_live;
+};
+
+// Which kernel(s) an intersection() over n rays runs as (psm_rt_set_traverse_mode). Results never depend on it.
+static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<PhasePlan>& plan) {
+    plan.clear();
+    int mode = r->trav_mode;
+    if (chain) return PSM_TRAVERSE_WHOLE;  // later hierarchies of a multi-BVH queue: rt_traverse<*, CHAIN>
+    if (mode == PSM_TRAVERSE_AUTO) mode = PSM_TRAVERSE_ADAPTIVE;
+    if (mode == PSM_TRAVERSE_PERSISTENT) return mode;
+    if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
+    if (mode == PSM_TRAVERSE_PHASED) {
+        for (int k = 0; k < r->phase_caps_n; k++) plan.push_back(PhasePlan{r->phase_caps[k], 0u});
+    } else {
+        // adaptive: a wave that hands over leaves at most min_live - 1 rays behind, so launch k has at most
+        // n * ((min_live - 1) / 64)^k rays: stop planning where that bound is small enough to finish
+        uint64_t bound = n;
+        const uint32_t T = r->adapt_min_live;
+        while (plan.size() + 1 < r->adapt_max_launches && plan.size() + 2 < MAX_PHASES && bound > r->adapt_final_rays) {
+            plan.push_back(PhasePlan{0xFFFFFFFFu, T});
+            bound = ((bound + 63) / 64) * (T - 1);
+        }
+    }
+    return plan.empty() ? PSM_TRAVERSE_WHOLE : mode;
+}
+
 int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     psm_ctx* c = r->ctx;
     uint32_t n = r->ray_count;
@@ -744,14 +754,13 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     if (b->tri_count > (1u << OBJ_SHIFT)) return set_err(c, PSM_ERR_CAPACITY, "hierarchy too large for the object tag (2^27 triangles)");
     const uint32_t tag = (uint32_t)r->trav_n << OBJ_SHIFT;
     r->trav_objs[r->trav_n++] = b;
-    if (chain || use_simple_traverse()) {
+    std::vector<PhasePlan> plan;
+    const int mode = plan_traverse(r, n, chain, plan);
+    if (mode != PSM_TRAVERSE_PERSISTENT) {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
 #define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
                       r->pool_cap, r->d_cnt, c->d_counters, tag
-        // automatic: phases only pay when other frames' kernels fill the launch tails they add (lanes.hip)
-        std::vector<uint32_t> caps = r->phase_caps_n < 0 ? (r->in_flight > 1 ? phase_caps() : std::vector<uint32_t>())
-                                                         : std::vector<uint32_t>(r->phase_caps, r->phase_caps + r->phase_caps_n);
-        if (chain || caps.empty() || n < r->phase_min_rays) {
+        if (mode == PSM_TRAVERSE_WHOLE) {
             TimedScope ts(c, CAT_TRAVERSE);
             Phase none = {};
             none.cap = 0xFFFFFFFFu;
@@ -763,31 +772,42 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
                 else rt_traverse<false, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
             }
         } else {
-            // phased: launch p runs at most caps[p] wave-steps and hands unfinished rays to launch p+1 through a
-            // dense continuation queue; the last launch runs to completion. Resume launches are sized for the
-            // worst case (every ray suspended); blocks past the device-side count exit at once.
+            // launch p hands unfinished rays to launch p+1 through a dense continuation queue; the last launch runs
+            // to completion. Resume launches are persistent (a fixed grid strides over the queue), sized by the
+            // host's upper bound of the rays that can be waiting; the device count decides what they do.
             int rc = ensure_phase_buffers(r);
             if (rc != PSM_OK) return rc;
-            const size_t np = caps.size() + 1;
+            const size_t np = plan.size() + 1;
             PSM_HIP(c, hipMemsetAsync(r->d_phase_cnt, 0, sizeof(uint32_t) * MAX_PHASES, c->stream));
+            uint64_t bound = n;
             for (size_t p = 0; p < np; p++) {
                 Phase ph;
-                ph.cap = p < caps.size() ? caps[p] : 0xFFFFFFFFu;
+                ph.cap = p < plan.size() ? plan[p].cap : 0xFFFFFFFFu;
+                ph.min_live = p < plan.size() ? plan[p].min_live : 0u;
+                ph.min_steps = r->adapt_min_steps;
+                ph.final_rays = mode == PSM_TRAVERSE_ADAPTIVE ? r->adapt_final_rays : 0u;
                 ph.in_count = p == 0 ? nullptr : r->d_phase_cnt + (p - 1);
                 ph.in = r->phase_state[(p + 1) & 1];
                 ph.out = r->phase_state[p & 1];
                 ph.out_count = r->d_phase_cnt + p;
+                uint32_t g = grid;
+                if (p > 0) {
+                    uint64_t need = (bound + TRAV_BLOCK - 1) / TRAV_BLOCK;
+                    g = (uint32_t)(need < RESUME_GRID_CAP ? need : RESUME_GRID_CAP);
+                    if (g == 0) g = 1;
+                }
                 TimedScope ts(c, CAT_TRAVERSE);
-                if (c->counting) rt_traverse<true, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
-                else rt_traverse<false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
+                if (c->counting) rt_traverse<true, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
+                else rt_traverse<false, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
+                if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);
             }
         }
 #undef PSM_TRAV_ARGS
     } else {
-        // persistent grid: 256 CUs x 8 workgroups of 4 waves (one wave per SIMD each); fewer when the
-        // queue is short. Ray cursors cnt[3], cnt[4] alternate between launches (each launch zeroes
-        // the other one), so no memset sits between traversals.
-        static std::mutex pt_mutex;  // the lazily tuned statics below; lanes may issue from several host threads
+        // persistent-threads kernel: 256 CUs x the resident workgroups of 4 waves; fewer when the queue is
+        // short. Ray cursors cnt[3], cnt[4] alternate between launches (each launch zeroes the other one), so no
+        // memset sits between traversals.
+        static std::mutex pt_mutex;  // the lazily queried occupancy below; lanes may issue from several host threads
         std::lock_guard<std::mutex> pt_lock(pt_mutex);
         static int resident[2] = {0, 0};
         int& res = resident[c->counting ? 1 : 0];
@@ -798,19 +818,11 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
             hipError_t e = c->counting
                 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_traverse_pt<true>, PT_BLOCK, 0)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_traverse_pt<false>, PT_BLOCK, 0);
-            if (e != hipSuccess || per_cu <= 0) per_cu = 6;
+            if (e != hipSuccess || per_cu <= 0) per_cu = 4;
             res = per_cu * cus;
         }
-        static PtTune tune = {0, 0};
-        static int grid_override = 0;
-        if (tune.refill_min == 0) {
-            const char* e;
-            tune.refill_min = (e = getenv("PSM_PT_REFILL")) ? atoi(e) : 8;
-            tune.tri_min = (e = getenv("PSM_PT_TRI")) ? atoi(e) : 20;
-            grid_override = (e = getenv("PSM_PT_GRID")) ? atoi(e) : 0;
-            if (getenv("PSM_PT_VERBOSE")) fprintf(stderr, "psm: persistent traverse: resident blocks %d, refill %d, tri %d, grid override %d\n", res, tune.refill_min, tune.tri_min, grid_override);
-        }
-        uint32_t cap = grid_override > 0 ? (uint32_t)grid_override : (uint32_t)res;
+        PtTune tune = {(int)r->pt_refill_min};
+        uint32_t cap = r->pt_grid > 0 ? r->pt_grid : (uint32_t)res;
         uint32_t need = (n + PT_BLOCK - 1) / PT_BLOCK;
         uint32_t grid = need < cap ? need : cap;
         TimedScope ts(c, CAT_TRAVERSE);

@@ -19,17 +19,26 @@ def stats(path):
 
 
 def pmc(path):
+    """per kernel and counter: calls, total, per call (one CSV may hold several counters of one pass)"""
     agg = collections.defaultdict(lambda: [0, 0.0])
-    cname = None
+    counters = []
     for r in csv.DictReader(open(path)):
-        cname = r["Counter_Name"]
-        k = short(r["Kernel_Name"])
+        c = r["Counter_Name"]
+        if c not in counters:
+            counters.append(c)
+        k = (short(r["Kernel_Name"]), c)
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
-    print("counter %s (KB as reported by rocprofv3; gfx950: FETCH_SIZE under-reports wide streaming reads 2x)" % cname)
-    print("%-34s %6s %14s %14s" % ("kernel", "calls", "total_KB", "per_call_KB"))
-    for k, (n, v) in sorted(agg.items(), key=lambda x: -x[1][1]):
-        print("%-34s %6d %14.1f %14.2f" % (k[:34], n, v, v / n))
+    print("counters %s (rocprofv3 values summed over a kernel's dispatches; FETCH_SIZE / WRITE_SIZE in KB; gfx950: FETCH_SIZE "
+          "reports half the bytes of wide streaming reads)" % " ".join(counters))
+    kernels = sorted({k[0] for k in agg}, key=lambda k: -max(agg[(k, c)][1] for c in counters if (k, c) in agg))
+    for c in counters:
+        print("-- %s" % c)
+        print("%-40s %6s %16s %16s" % ("kernel", "calls", "total", "per_call"))
+        for k in kernels:
+            if (k, c) in agg:
+                n, v = agg[(k, c)]
+                print("%-40s %6d %16.1f %16.2f" % (k[:40], n, v, v / n))
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ invariants for the BVH, sampled bit-exact parity + determinism + conservation fo
 import numpy as np
 import pytest
 
-from util import box_union, canonical_nodes
+from util import bits, box_union, canonical_nodes
 
 pytestmark = pytest.mark.gpu
 
@@ -154,3 +154,94 @@ def test_full_1080p_frames_in_flight_radiance_vs_oracle(psm, oracle, scenes):
     assert st["rays"] > 12_000_000
     np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
     assert np.array_equal(img[..., 3], ref[..., 3])
+
+
+def test_c5_stress_10m_triangles_build_bit_exact_and_4k_frame(psm, ctx, oracle, scenes):
+    """BASELINE config 5: S-stress, ~10 M triangles (the reference's caps lifted: 2 Mi sort keys, Radix.hpp:34-35;
+    ~4.19 M triangles, TriangleHierarchy.inl:80; 4096^2 rays, Pipeline.inl:187-189 -- kept, it is the ray limit),
+    3840x2160. The oracle builds 10 M triangles in seconds, so the whole hierarchy is compared bit for bit (keys,
+    sort order, topology, fp16 boxes); the 4K frame is checked by sampled bit-exact traversal parity on the first
+    two rounds, conservation, and determinism of a second frame."""
+    sc = scenes.stress()
+    tris = sc["tris"]
+    assert tris.shape[0] > 9_900_000
+    ob = oracle.build_scene(tris)
+    n = ob["count"]
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(tris.shape[0])
+    th.loadTriangles(tris, sc["normals"], sc["mats"])
+    th.build()
+    info = th.info()
+    assert info.leaf_count == n
+    assert np.array_equal(bits(np.array(info.transform)), bits(ob["M"]))
+    keys = th.download(psm.BVH_KEYS, np.uint64, n)
+    assert np.array_equal(keys, ob["keys"])                                            # Morton codes, sorted
+    assert np.array_equal(th.download(psm.BVH_INDICES, np.uint32, n), ob["idx"].astype(np.uint32))  # stable order
+    link = th.download(psm.BVH_LINK, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+    pb = th.download(psm.BVH_PAIR_BOX, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
+    rg = th.download(psm.BVH_RANGE, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+    nodes = canonical_nodes(info.root, link, pb, rg, oracle.NODE_DT)
+    assert np.array_equal(nodes["pdata"], ob["nodes"]["pdata"])                        # topology, ranges, triangle ids
+    assert np.array_equal(nodes["box"], ob["nodes"]["box"])                            # fp16 boxes after refit
+    _invariants(nodes, n, keys)
+    del nodes, link, pb, rg
+
+    w, h = 3840, 2160
+    ms = psm.MaterialSet()
+    for m in sc["materials"]:
+        ms.addSubmat(m)
+    rt = psm.Pipeline(ctx, seed=55)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+
+    def frame(check):
+        rt.setSeed(55)
+        rt.clearSampler()
+        ctx.stats_enable(False, True)
+        ctx.stats_reset()
+        ms.loadToVGA()
+        th.markDirty()
+        th.build()                                  # per-frame rebuild, as the config says
+        rt.camera(sc["eye"], sc["view"])
+        total, rounds, checked = 0, 0, 0
+        for _ in range(16):
+            cnt = rt.getRayCount()
+            if cnt <= 0:
+                break
+            total += cnt
+            rays = rt.download_rays() if check and rounds < 2 else None
+            rt.intersection(th)
+            if rays is not None:
+                sel = np.arange(rounds, cnt, 97)
+                gh, gc = rt.download_hits(cnt)
+                oh, oc, _ = oracle.traverse(ob["nodes"], tris, ob["M"], rays["origin"][sel], rays["direct"][sel], 16)
+                assert np.array_equal(gc[sel], oc)
+                m = oc > 0
+                assert m.sum() > 1000
+                assert np.array_equal(gh["tri"][sel][m, 0], oh["tri"][m, 0])
+                for f in ("t", "u", "v"):
+                    assert np.array_equal(bits(gh[f][sel][m, 0]), bits(oh[f][m, 0])), f
+                checked += len(sel)
+                del gh, gc, rays
+            rt.applyMaterials(ms)
+            rt.shade()
+            rounds += 1
+        rt.sample()
+        st = ctx.stats()
+        s, c, f = rt.download_texels()
+        return rt.snapHdr(), st, total, rounds, s[:, 3].copy(), checked
+
+    img1, st1, total1, rounds1, dep1, checked = frame(True)
+    img2, st2, total2, rounds2, dep2, _ = frame(False)
+    assert checked > 150_000
+    assert st1.rays_traced == total1 and rounds1 >= 3 and total1 > 4 * w * h // 2
+    assert st1.iter_caps == 0 and st1.stack_drops < 1e-4 * total1
+    assert np.isfinite(img1).all() and (img1[..., :3] >= 0).all() and img1[..., :3].mean() > 0.05
+    assert (dep1 >= 1).all()
+    assert (total1, rounds1, st1.node_visits, st1.tri_tests, st1.ray_limit_drops) == (
+        total2, rounds2, st2.node_visits, st2.tri_tests, st2.ray_limit_drops)
+    assert np.array_equal(dep1, dep2)
+    np.testing.assert_allclose(img1[..., :3], img2[..., :3], rtol=1e-5, atol=1e-6)
+    ctx.stats_enable(False, False)
+    rt.close()
+    th.close()

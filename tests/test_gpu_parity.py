@@ -270,15 +270,42 @@ def test_traverse_scaled_scene_bit_exact(psm, ctx, oracle, scenes, scale):
     th.close()
 
 
-@pytest.mark.parametrize("caps", [[1], [3, 5, 7], [16, 16, 16, 16, 16, 16, 16], [40]])
-def test_phased_traversal_is_bit_exact(psm, ctx, oracle, scenes, caps):
-    """psm_rt_set_traverse_phases: rays suspended after a few wave-steps and resumed from the continuation queue
-    (up to seven times) give the hits, chains and counters of one uninterrupted launch."""
+TRAVERSE_SCHEDULES = [
+    ("whole", {}),
+    ("phased", {"caps": [1]}),
+    ("phased", {"caps": [3, 5, 7]}),
+    ("phased", {"caps": [16, 16, 16, 16, 16, 16, 16]}),
+    ("phased", {"caps": [40]}),
+    ("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 256, "max_launches": 8}),
+    ("adaptive", {"min_live": 64, "min_steps": 0, "final_rays": 0, "max_launches": 15}),   # hand over at the first idle lane
+    ("adaptive", {"min_live": 2, "min_steps": 1, "final_rays": 0, "max_launches": 3}),
+    ("adaptive", {"min_live": 24, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
+    ("persistent", {"refill_min": 8}),
+    ("persistent", {"refill_min": 1, "grid_blocks": 3}),
+    ("persistent", {"refill_min": 64, "grid_blocks": 1}),
+]
+
+
+def _select_schedule(rt, mode, kw):
+    if mode == "phased":
+        rt.setTraversePhases(kw["caps"], min_rays=0)
+    elif mode == "adaptive":
+        rt.setTraverseAdaptive(min_rays=0, **kw)
+    elif mode == "persistent":
+        rt.setTraversePersistent(**kw)
+    rt.setTraverseMode(mode)
+
+
+@pytest.mark.parametrize("mode,kw", TRAVERSE_SCHEDULES, ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()).replace(" ", ""))
+def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, kw):
+    """psm_rt_set_traverse_mode: every kernel schedule that ships -- one launch, fixed-cap phases, ballot-triggered
+    hand-over with persistent resume waves, persistent threads with per-lane refill -- gives the hits, chains and
+    V / T counters of the oracle's uninterrupted per-ray loop (directTraverse.comp:333-484)."""
     scene = scenes.sponza_like(n_tris=20011)
     w, h = 160, 90
     th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
     ob = oracle.build_scene(scene["tris"])
-    rt.setTraversePhases(caps, min_rays=0)
+    _select_schedule(rt, mode, kw)
     rt.camera_matrices(cam[0], cam[1], time=11)
     rt.applyMaterials(ms)
     for rnd in range(3):
@@ -293,6 +320,43 @@ def test_phased_traversal_is_bit_exact(psm, ctx, oracle, scenes, caps):
         _hits_equal(gh, gc, oh, oc)
         assert (st.node_visits, st.tri_tests) == (octr.node_visits, octr.tri_tests)
         rt.shade(time=40 + rnd)
+    rt.close()
+    th.close()
+
+
+@pytest.mark.parametrize("mode,kw", [("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 64, "max_launches": 8}),
+                                     ("persistent", {"refill_min": 8})], ids=["adaptive", "persistent"])
+def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes, mode, kw):
+    """Rays that carry an equal-distance chain of two or more hits cannot hand over (their chain lives in registers):
+    they finish in the launch they are in. Duplicated coplanar triangles make thousands of them."""
+    rng = np.random.RandomState(5)
+    base = scenes.sponza_like(n_tris=6007)["tris"]
+    tris = np.ascontiguousarray(np.concatenate([base, base[:1500]], 0))
+    sc = {"tris": tris, "normals": scenes.prepare_normals(tris), "mats": np.zeros(tris.shape[0], np.int32),
+          "materials": scenes.cornell()["materials"], "eye": np.zeros(3, np.float32), "view": np.ones(3, np.float32)}
+    th = _load(psm, ctx, sc)
+    th.build()
+    ob = oracle.build_scene(tris)
+    n = 20000
+    tid = rng.randint(0, tris.shape[0], n)
+    wgt = rng.dirichlet((1, 1, 1), n).astype(np.float32)
+    target = (tris[tid] * wgt[:, :, None]).sum(1)
+    origin = (target + rng.normal(0, 1, (n, 3)) * 3.0 + np.array([0, 4, 0])).astype(np.float32)
+    direct = (target - origin).astype(np.float32)
+    rays = np.zeros(n, psm.RAY_DT)
+    rays["origin"], rays["direct"], rays["color"] = origin, direct, 1.0
+    rays["bitfield"] = 1 | (3 << 8)
+    rays["texel"] = np.arange(n) % 100
+    rays["pkey"] = np.arange(n)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(128, 128)
+    _select_schedule(rt, mode, kw)
+    rt.upload_rays(rays)
+    assert rt.intersection(th) == 1
+    gh, gc = rt.download_hits(n)
+    oh, oc, _ = oracle.traverse(ob["nodes"], tris, ob["M"], origin, direct, 8)
+    assert (oc > 1).sum() > 100
+    _hits_equal(gh, gc, oh, oc)
     rt.close()
     th.close()
 
