@@ -8,7 +8,9 @@ full BVH rebuild (bounds, Morton, radix sort, emit) + camera + the bounce loop
 GltfViewer::process() (reference Source/Examples/Viewer.cpp:296-312).  4 spp = 4 steps.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1: either under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (python -m torch.distributed.run
+  --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...), or plainly as above: bench.py then starts the N ranks
+  itself as child processes (before it has touched a GPU) and rank 0 prints the line.
 
 Multi-GPU: the frame is sharded by screen rows; the BVH is rebuilt redundantly on every GPU; the
 per-texel radiance of each tile is gathered to rank 0 (RCCL over xGMI) which runs the sampler.
@@ -54,7 +56,13 @@ def parse():
     ap.add_argument("--lanes", type=int, default=4,
                     help="frames in flight per GPU (psm_lanes_render): each on its own HIP stream, folded into the "
                          "accumulating image in frame order; 1 = one frame after another")
-    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive", "persistent"],
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous check only: every rank builds its communicator (gloo, no GPU), proves the group works "
+                         "with one all-reduce, prints one line and exits")
+    ap.add_argument("--diag-clock", action="store_true",
+                    help="diagnosis only: a second pass of the timed region with the counting kernels on every lane; reports "
+                         "the shader clock the traversal waves ran at (s_memtime / s_memrealtime) and their wave-steps to stderr")
+    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive"],
                     help="tuning study: traversal kernel schedule (psm_rt_set_traverse_mode); results never depend on it")
     ap.add_argument("--trav-caps", default="96", help="phased: wave-step caps, comma separated")
     ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
@@ -260,8 +268,54 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this one, which
+    has not touched (and never touches) a GPU, with the rendezvous environment torch.distributed.run would have
+    set; the children's stdout is this process's, so rank 0's JSON line is the only output. Returns the worst exit
+    code; if a rank fails the others are ended (by the PIDs started here)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def dry_run(world):
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    comm = pdist.Comm(world, backend="gloo")
+    total = comm.sum_int(1)
+    comm.barrier()
+    print("bench.py dry run: rank %d of %d reached its communicator; all-reduce over the group = %d" % (comm.rank, world, total),
+          flush=True)
+    comm.close()
+    return 0 if total == world else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # nothing below runs in the parent: it never initialises a GPU
+    if args.dry_run:
+        sys.exit(dry_run(int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1))
     os.environ["NCCL_DEBUG"] = os.environ.get("PSM_NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
     # one hardware queue per frame in flight + the accumulating stream (the runtime's default of 4 makes two
     # streams share a queue); read by the HIP runtime when it initialises
@@ -334,6 +388,27 @@ def main():
     st = kst
     assert traced == Rr, (traced, Rr)
     total_rays = dist.sum_int(int(Rr))
+
+    if args.diag_clock and not dist.active:
+        reseed()
+        for ln in R.batch.lanes:
+            ln.ctx.stats_enable(False, True)
+            ln.ctx.stats_reset()
+        R.batch.sync()
+        d0 = time.perf_counter()
+        run_steps(args.steps)
+        R.batch.sync()
+        d_el = time.perf_counter() - d0
+        tick = real = wsteps = waves = 0
+        for ln in R.batch.lanes:
+            s_ = ln.ctx.stats()
+            tick, real, wsteps, waves = tick + s_.wave_clock_ticks, real + s_.wave_real_ticks, wsteps + s_.wave_steps, waves + s_.waves
+            ln.ctx.stats_enable(False, False)
+        sys.stderr.write("diag-clock: %d frames in %.3f ms (counting kernels); traversal waves %d, wave-steps %d (%.2f G/s), "
+                         "mean wave life %.1f us, shader clock while they ran %.3f GHz, resident traversal waves on average %.0f\n" % (
+                             args.steps, d_el * 1e3, waves, wsteps, wsteps / d_el / 1e9, real / max(waves, 1) / 100.0,
+                             tick / max(real, 1) * 0.1, real / 100e6 / d_el))
+        reseed()
 
     if dist.rank == 0:
         img = R.batch.snapHdr()

@@ -223,9 +223,8 @@ int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
  *   ADAPTIVE    the same hand-over, triggered per wave by __ballot / popcount: a wave hands over as soon as fewer
  *               than min_live of its lanes have work left; resume launches are persistent waves striding over the
  *               continuation queue (psm_rt_set_traverse_adaptive)
- *   PERSISTENT  persistent threads with per-lane refill from a launch-wide ray cursor (rt_traverse_pt)
  *   AUTO        the library's choice (default). Further hierarchies of a multi-BVH queue always run WHOLE. */
-enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3, PSM_TRAVERSE_PERSISTENT = 4 };
+enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3 };
 int psm_rt_set_traverse_mode(psm_rt* rt, int mode);
 /* PHASED: count caps (1..7) -> count + 1 launches, for intersections over at least min_rays rays; count = 0 selects
  * WHOLE. Selects PSM_TRAVERSE_PHASED. */
@@ -235,8 +234,6 @@ int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count,
  * max_launches launches (2..15) per intersection; intersections under min_rays rays run WHOLE. */
 int psm_rt_set_traverse_adaptive(psm_rt* rt, uint32_t min_live, uint32_t min_steps, uint32_t final_rays,
                                  uint32_t max_launches, uint32_t min_rays);
-/* PERSISTENT parameters: finished slots per wave that trigger a refill pass (1..64); grid in workgroups (0 = resident) */
-int psm_rt_set_traverse_persistent(psm_rt* rt, uint32_t refill_min, uint32_t grid_blocks);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
 int psm_rt_reset_hits(psm_rt* rt);
 /* applyMaterials + shade, Pipeline.inl:407-436 -> surface.comp + rayshading.comp, then the
@@ -331,6 +328,10 @@ typedef struct {
     float build_ms, sort_ms, shade_ms, camera_ms, sample_ms;
     uint32_t rounds;
     float bounds_ms, morton_ms, emit_ms; /* parts of build_ms: minmax + fit, Morton codes + leaves, node emission + link + refit */
+    /* clock diagnosis, counted with V and T: over all traversal waves, the sums of their lifetimes in shader-clock ticks
+     * (s_memtime) and in ticks of the constant 100 MHz clock (s_memrealtime) -- their ratio x 100 MHz is the clock the chip
+     * held while they ran -- the wave-steps they took and their number */
+    uint64_t wave_clock_ticks, wave_real_ticks, wave_steps, waves;
 } psm_stats;
 int psm_stats_enable(psm_ctx* ctx, int timing, int counting);
 int psm_stats_reset(psm_ctx* ctx);

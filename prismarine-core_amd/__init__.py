@@ -28,16 +28,15 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_persistent", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
 ]
 
-TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE, TRAVERSE_PERSISTENT = range(5)
-TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE,
-                  "persistent": TRAVERSE_PERSISTENT}
+TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)
+TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE}
 
 (BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
  BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS, BVH_TEXCOORDS) = range(12)
@@ -83,7 +82,8 @@ class Stats(C.Structure):
                 ("traverse_launches", C.c_uint32), ("traverse_ms", C.c_float), ("build_ms", C.c_float),
                 ("sort_ms", C.c_float), ("shade_ms", C.c_float), ("camera_ms", C.c_float),
                 ("sample_ms", C.c_float), ("rounds", C.c_uint32), ("bounds_ms", C.c_float), ("morton_ms", C.c_float),
-                ("emit_ms", C.c_float)]
+                ("emit_ms", C.c_float), ("wave_clock_ticks", C.c_uint64), ("wave_real_ticks", C.c_uint64),
+                ("wave_steps", C.c_uint64), ("waves", C.c_uint64)]
 
 
 _lib = None
@@ -518,7 +518,7 @@ class Pipeline:
 
     def setTraverseMode(self, mode):
         """Tuning knob (psm_rt_set_traverse_mode): which kernel schedule intersection() runs as -- "auto", "whole",
-        "phased", "adaptive", "persistent" or a TRAVERSE_* value. Results never depend on it."""
+        "phased", "adaptive" or a TRAVERSE_* value. Results never depend on it."""
         m = TRAVERSE_MODES[mode] if isinstance(mode, str) else int(mode)
         self.ctx.check(lib().psm_rt_set_traverse_mode(self._h, C.c_int(m)), "psm_rt_set_traverse_mode")
 
@@ -533,11 +533,6 @@ class Pipeline:
         self.ctx.check(lib().psm_rt_set_traverse_adaptive(self._h, C.c_uint32(min_live), C.c_uint32(min_steps),
                                                           C.c_uint32(final_rays), C.c_uint32(max_launches),
                                                           C.c_uint32(min_rays)), "psm_rt_set_traverse_adaptive")
-
-    def setTraversePersistent(self, refill_min=8, grid_blocks=0):
-        """psm_rt_set_traverse_persistent: parameters of the "persistent" schedule (does not select it)."""
-        self.ctx.check(lib().psm_rt_set_traverse_persistent(self._h, C.c_uint32(refill_min), C.c_uint32(grid_blocks)),
-                       "psm_rt_set_traverse_persistent")
 
     def resetHits(self):
         """Forget the hit chains of the current queue (ray.hit = -1): the next intersection() starts afresh."""

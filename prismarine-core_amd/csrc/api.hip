@@ -464,7 +464,7 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
 // ---- Pipeline -----------------------------------------------------------------------------------
 static void rt_free_grid(psm_rt* r) {
     for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); }
-    dev_free(r->sA); dev_free(r->sB); dev_free(r->sC); dev_free(r->d_block); dev_free(r->qT);
+    dev_free(r->sA); dev_free(r->sB); dev_free(r->sC); dev_free(r->d_block);
     dev_free(r->hit0); dev_free(r->hitN); dev_free(r->pool);
     dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag);
 }
@@ -529,7 +529,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     auto A = [&](int x) { if (rc == PSM_OK) rc = x; };
     for (int q = 0; q < 2; q++) { A(dev_alloc(c, &r->qA[q], L)); A(dev_alloc(c, &r->qB[q], L)); A(dev_alloc(c, &r->qC[q], L)); }
     A(dev_alloc(c, &r->sA, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sB, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sC, nb * SHADE_BLOCK * 4));
-    A(dev_alloc(c, &r->d_block, 2 * nb + 2));  // qT: allocated by the persistent-threads tracer when it is selected
+    A(dev_alloc(c, &r->d_block, 2 * nb + 2));
     A(dev_alloc(c, &r->hit0, L)); A(dev_alloc(c, &r->hitN, L));
     r->pool_cap = (uint32_t)std::max<size_t>(L / 2, 1024);  // hits buffer = L/2 in the reference, Pipeline.inl:193
     A(dev_alloc(c, &r->pool, (size_t)r->pool_cap));
@@ -713,7 +713,7 @@ int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
 }
 
 int psm_rt_set_traverse_mode(psm_rt* r, int mode) {
-    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_PERSISTENT) return PSM_ERR_INVALID;
+    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_ADAPTIVE) return PSM_ERR_INVALID;
     r->trav_mode = mode;
     return PSM_OK;
 }
@@ -737,13 +737,6 @@ int psm_rt_set_traverse_adaptive(psm_rt* r, uint32_t min_live, uint32_t min_step
     r->adapt_final_rays = final_rays;
     r->adapt_max_launches = max_launches;
     r->phase_min_rays = min_rays;
-    return PSM_OK;
-}
-
-int psm_rt_set_traverse_persistent(psm_rt* r, uint32_t refill_min, uint32_t grid_blocks) {
-    if (!r || refill_min < 1 || refill_min > 64) return PSM_ERR_INVALID;
-    r->pt_refill_min = refill_min;
-    r->pt_grid = grid_blocks;
     return PSM_OK;
 }
 
@@ -943,6 +936,10 @@ int psm_stats_get(psm_ctx* c, psm_stats* out) {
     out->bounds_ms = c->cat_ms[CAT_BOUNDS];
     out->morton_ms = c->cat_ms[CAT_MORTON];
     out->emit_ms = c->cat_ms[CAT_EMIT];
+    out->wave_clock_ticks = d.wave_clock_ticks;
+    out->wave_real_ticks = d.wave_real_ticks;
+    out->wave_steps = d.wave_steps;
+    out->waves = d.waves;
     return PSM_OK;
 }
 

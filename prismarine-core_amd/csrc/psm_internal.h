@@ -52,6 +52,8 @@ enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT
 struct DevCounters {
     unsigned long long node_visits, tri_tests, stack_drops, iter_caps, baked_drops, chain_pool_drops,
         ray_limit_drops, pad;
+    // clock diagnosis (counting builds): shader-clock and 100 MHz constant-clock ticks summed over traversal waves
+    unsigned long long wave_clock_ticks, wave_real_ticks, wave_steps, waves;
 };
 
 struct Buf {
@@ -125,13 +127,11 @@ struct psm_rt {
     float4* qA[2] = {nullptr, nullptr};  // origin.xyz, texel
     float4* qB[2] = {nullptr, nullptr};  // direct.xyz, bitfield
     float4* qC[2] = {nullptr, nullptr};  // color.xyz, pkey
-    float4* qT = nullptr;         // 4 x float4 per ray: projected traversal inputs (rt_project)
     float4* sA = nullptr;         // staging (4 outputs per input ray, block-compacted)
     float4* sB = nullptr;
     float4* sC = nullptr;
     uint32_t* d_block = nullptr;  // per-block output counts / bases
-    uint32_t* d_cnt = nullptr;    // [0] current count, [1] next count, [2] chain pool cursor, [3],[4] ray cursors
-    int cursor = 0;               // which ray cursor the next persistent traversal launch uses
+    uint32_t* d_cnt = nullptr;    // [0] current count, [1] next count, [2] chain pool cursor
     float4* hit0 = nullptr;       // head of chain per ray: u, v, t, tri
     uint32_t* hitN = nullptr;     // chain length | pool offset << 4
     float4* pool = nullptr;       // chain entries beyond the head
@@ -163,7 +163,6 @@ struct psm_rt {
     int phase_caps_n = 1;
     int trav_mode = 0;              // PSM_TRAVERSE_* (psm_rt_set_traverse_mode); 0 = automatic
     uint32_t adapt_min_live = 16, adapt_min_steps = 8, adapt_final_rays = 4096, adapt_max_launches = 8;
-    uint32_t pt_refill_min = 8, pt_grid = 0;  // PSM_TRAVERSE_PERSISTENT tuning
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
     uint32_t phase_min_rays = 1u << 20;
     // frames in flight (lanes.hip): pinned slot + events, created on first use

@@ -13,7 +13,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 
 #include "psm_common.h"
 #include "psm_internal.h"
@@ -26,24 +25,36 @@ constexpr int SM_ROOT = 25;
 constexpr int TRAV_BLOCK = 128;
 
 struct Slab {
-    float hit, near, far;
+    float hit, near;
+    bool cube;
 };
 
-// intersectCubeDual, include/mathlib.glsl:129-193, fp32 branch, one child
+// intersectCubeDual, include/mathlib.glsl:129-193, fp32 branch, one child. The reference returns near = far = INFINITY
+// for a missed box (:186-187), which then fails `hit <= INFINITY - PZERO` (directTraverse.comp:425): here the miss is
+// the flag `cube` and near / hit are the raw values, which is the same decision with two selects fewer.
 PSM_D Slab slab_child(v3 dr, v3 norig, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
-    v3 cmn = mk3(mnx, mny, mnz);
-    v3 cmx = mk3(mxx, mxy, mxz);
-    float tminx = fmaf(cmn.x, dr.x, norig.x), tmaxx = fmaf(cmx.x, dr.x, norig.x);
-    float tminy = fmaf(cmn.y, dr.y, norig.y), tmaxy = fmaf(cmx.y, dr.y, norig.y);
-    float tminz = fmaf(cmn.z, dr.z, norig.z), tmaxz = fmaf(cmx.z, dr.z, norig.z);
+    float tminx = fmaf(mnx, dr.x, norig.x), tmaxx = fmaf(mxx, dr.x, norig.x);
+    float tminy = fmaf(mny, dr.y, norig.y), tmaxy = fmaf(mxy, dr.y, norig.y);
+    float tminz = fmaf(mnz, dr.z, norig.z), tmaxz = fmaf(mxz, dr.z, norig.z);
     float tNear = smaxf(smaxf(sminf(tminx, tmaxx), sminf(tminy, tmaxy)), sminf(tminz, tmaxz));
     float tFar = sminf(sminf(smaxf(tminx, tmaxx), smaxf(tminy, tmaxy)), smaxf(tminz, tmaxz));
-    bool isCube = ((tFar + PZERO) >= tNear) && ((tFar + PZERO) >= 0.0f);
+    float tfp = tFar + PZERO;
     Slab s;
-    s.near = isCube ? sminf(tNear, tFar) : INF;
-    s.far = isCube ? smaxf(tNear, tFar) : INF;
-    s.hit = ((s.near + PZERO) <= 0.0f) ? s.far : s.near;
+    s.cube = (tfp >= tNear) & (tfp >= 0.0f);
+    s.near = sminf(tNear, tFar);
+    float far = smaxf(tNear, tFar);
+    s.hit = ((s.near + PZERO) <= 0.0f) ? far : s.near;
     return s;
+}
+
+// accepted child, directTraverse.comp:416-430. Of the reference's six tests two are implied by the others for every
+// input: near <= hit (hit is near or far), so `near <= INF - PZERO` follows from `hit <= INF - PZERO`; and dirlenInv is
+// in [0, 1e6] or NaN, so where `hit * dirlenInv <= INF - PZERO` holds, `near * dirlenInv <= INF - PZERO` can only fail
+// for near = -inf with dirlenInv = 0, where the predist test is NaN <= predist = false as well.
+PSM_D bool child_ok(const Slab& c, float dirlenInv, float toffset, float predist) {
+    const float IP = INF - PZERO;
+    return c.cube & (c.hit <= IP) & (c.hit * dirlenInv <= IP) & (c.hit > -PZERO) &
+           (((c.near + toffset) * dirlenInv - PZERO) <= predist);
 }
 
 // intersectTriangle, include/vertex.glsl:140-189 (e1, e2 precomputed by bvh_prepare_tris)
@@ -100,6 +111,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     const uint32_t min_live = (PHASED && !(resume && total <= ph.final_rays)) ? ph.min_live : 0u;
     const uint32_t cap = (PHASED && !(resume && total <= ph.final_rays)) ? ph.cap : 0xFFFFFFFFu;
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
+    unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
+    if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
     float M[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
@@ -159,7 +172,6 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     Baked head = {0.f, 0.f, INF, -1};
     Baked extra[BAKED_CAP - 1];
 
-    const float IP = INF - PZERO;
     int cur = root;
     int sp = 0;
     int it = 0;
@@ -185,10 +197,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     // issues the ~150-instruction triangle block for ~half its live lanes instead of for 3-4 of them.
     int pl = -1, pr = -1;
     bool pLeftNear = false;
+    bool parkedNow = false;  // pl >= 0 || pr >= 0 (both are -1 or a triangle id); false again once the tests have run
     for (;;) {
-        const bool parked = (pl & pr) != -1 ? true : false;  // pl >= 0 || pr >= 0 (both are -1 or a triangle id)
-        const bool ready = validBox && !parked;
-        if (ready) {
+        if (validBox & !parkedNow) {
             if (it >= MAX_ITERS) {
                 validBox = false;
                 if (COUNT) nCap++;
@@ -200,26 +211,23 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                 if (COUNT) nV++;
                 Slab L = slab_child(divident, norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
                 Slab R = slab_child(divident, norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
-                bool leftNear = lessEqualF(L.near, R.near);  // :414
-                bool ogL = (L.hit <= IP) && (L.hit * dirlenInv <= IP) && (L.hit > -PZERO) && (L.near <= IP) &&
-                           (L.near * dirlenInv <= IP) && (((L.near + toffset) * dirlenInv - PZERO) <= predist);
-                bool ogR = (R.hit <= IP) && (R.hit * dirlenInv <= IP) && (R.hit > -PZERO) && (R.near <= IP) &&
-                           (R.near * dirlenInv <= IP) && (((R.near + toffset) * dirlenInv - PZERO) <= predist);
-                bool leafL = ogL && lk.x < 0, leafR = ogR && lk.y < 0;
-                bool intL = ogL && lk.x >= 0, intR = ogR && lk.y >= 0;
-                pl = leafL ? ~lk.x : -1;   // :441-448, tested below
-                pr = leafR ? ~lk.y : -1;
+                // straight-line selects from here on (bitwise & on the flags: no short-circuit branches)
+                const bool leftNear = lessEqualF(L.near, R.near);  // :414 (only read when both children are accepted)
+                const bool ogL = child_ok(L, dirlenInv, toffset, predist), ogR = child_ok(R, dirlenInv, toffset, predist);
+                const bool lfL = lk.x < 0, lfR = lk.y < 0;
+                pl = (ogL & lfL) ? ~lk.x : -1;   // accepted leaves, :441-448: tested below
+                pr = (ogR & lfR) ? ~lk.y : -1;
                 pLeftNear = leftNear;
-                bool descend = intL || intR;
-                if (descend) {  // :451-462
-                    bool leftOrder = (intL && intR) ? leftNear : intL;
-                    int lr0 = intL ? lk.x : -1, lr1 = intR ? lk.y : -1;
-                    if (!leftOrder) { int t = lr0; lr0 = lr1; lr1 = t; }
-                    if (lr1 != -1 && lr0 != lr1) {
-                        if (sp < STACK_CAP) stack[sp++][tid] = lr1;
-                        else if (COUNT) nDrop++;
-                    }
-                    cur = lr0;
+                parkedNow = (ogL & lfL) | (ogR & lfR);
+                const bool intL = ogL & !lfL, intR = ogR & !lfR;
+                const bool leftFirst = intL & (leftNear | !intR);  // :451-462: both ? leftNear : intL
+                const int first = leftFirst ? lk.x : lk.y, second = leftFirst ? lk.y : lk.x;
+                if (intL & intR & (lk.x != lk.y)) {
+                    if (sp < STACK_CAP) stack[sp++][tid] = second;
+                    else if (COUNT) nDrop++;
+                }
+                if (intL | intR) {
+                    cur = first;
                 } else {  // :467-476
                     sp--;
                     if (sp >= 0) cur = stack[sp][tid];
@@ -227,9 +235,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                 }
             }
         }
-        const bool parkedNow = (pl & pr) != -1;
         const unsigned long long pend = __ballot(parkedNow);
         const unsigned long long canStep = __ballot(validBox && !parkedNow);
+        if (COUNT) dg_steps++;
         // wave-uniform: the cap, or too few lanes with work left (parked or able to step) to be worth a wave
         const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && (uint32_t)__popcll(pend | canStep) < min_live));
         if (pend == 0ull) {
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                 }
             }
             pl = -1; pr = -1;
+            parkedNow = false;
         }
         if (capHit) {
             // every parked test has just run. Rays with work left and a chain of at most one hit hand their state
@@ -386,299 +395,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     if (COUNT) {
         uint32_t v = wave_sum(nV), t = wave_sum(nT), d = wave_sum(nDrop), c = wave_sum(nCap), b = wave_sum(nBakedDrop);
         if (lane_id() == 0) {
-            if (v) atomicAdd(&ctr->node_visits, (unsigned long long)v);
-            if (t) atomicAdd(&ctr->tri_tests, (unsigned long long)t);
-            if (d) atomicAdd(&ctr->stack_drops, (unsigned long long)d);
-            if (c) atomicAdd(&ctr->iter_caps, (unsigned long long)c);
-            if (b) atomicAdd(&ctr->baked_drops, (unsigned long long)b);
-        }
-    }
-}
-
-// ---- persistent-threads traversal ------------------------------------------------------------------
-//
-// One wave = 64 ray slots. Waves are persistent: a slot whose ray has finished is refilled from the
-// launch-wide ray cursor (one wave-aggregated atomic per refill), so lanes do not idle behind the
-// longest ray of their wave (measured VALU lane utilisation of the one-thread-per-ray kernel above
-// on the Sponza-class scene: 56 % for primary rays, 26 % for bounce rays; the kernel is VALU-issue
-// bound, so idle lanes are lost time). The per-ray setup of traverse() (:350-378: normalise, project
-// into the unit cube, root slab test) is hoisted into rt_project, a fully occupied pass, so a refill
-// is four 16-byte loads. The per-ray operation sequence is unchanged: results are bit-identical.
-// Node record: 32 bytes (bvh_emit): 12 fp16 box coordinates + 2 links.
-constexpr int PT_BLOCK = 256;
-constexpr int PT_WAVES = PT_BLOCK / 64;
-struct PtTune {
-    int refill_min;  // finished slots of a wave that trigger a finalise + refill pass
-};
-
-struct Slab2 {
-    float hit, near;
-};
-// intersectCubeDual (mathlib.glsl:129-193, fp32 branch) for one child given its 6 fp16 coordinates
-PSM_D Slab2 slab6(v3 dr, v3 norig, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
-    float a0 = fmaf(mnx, dr.x, norig.x), a1 = fmaf(mxx, dr.x, norig.x);
-    float b0 = fmaf(mny, dr.y, norig.y), b1 = fmaf(mxy, dr.y, norig.y);
-    float c0 = fmaf(mnz, dr.z, norig.z), c1 = fmaf(mxz, dr.z, norig.z);
-    float tNear = smaxf(smaxf(sminf(a0, a1), sminf(b0, b1)), sminf(c0, c1));
-    float tFar = sminf(sminf(smaxf(a0, a1), smaxf(b0, b1)), smaxf(c0, c1));
-    bool isCube = ((tFar + PZERO) >= tNear) && ((tFar + PZERO) >= 0.0f);
-    float nr = isCube ? sminf(tNear, tFar) : INF;
-    float fr = isCube ? smaxf(tNear, tFar) : INF;
-    Slab2 s;
-    s.near = nr;
-    s.hit = ((nr + PZERO) <= 0.0f) ? fr : nr;
-    return s;
-}
-
-// traverse() :350-378 for every queued ray, written as two 32-byte halves (see below)
-__global__ __launch_bounds__(256) void rt_project(const float4* __restrict__ qA, const float4* __restrict__ qB,
-                                                  uint32_t nrays, uint32_t nrays_cap,
-                                                  const uint32_t* __restrict__ sm, float4* __restrict__ T) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nrays) return;
-    float M[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
-    const int root = (int)sm[SM_ROOT];
-    float4 A = qA[i], B = qB[i];
-    v3 origin = mk3(A.x, A.y, A.z);
-    v3 direct = normalize3(mk3(B.x, B.y, B.z));  // :350
-    float to4[4], td4[4];
-    mat_vec(M, origin.x, origin.y, origin.z, 1.0f, to4);   // :353
-    matT_vec(M, direct.x, direct.y, direct.z, 1.0f, td4);  // :354
-    v3 torig = mk3(to4[0], to4[1], to4[2]);
-    v3 tdir = mk3(td4[0], td4[1], td4[2]);
-    float dirlen = len3(tdir) / pmax(len3(direct), 0.000001f);
-    float dirlenInv = 1.f / pmax(dirlen, 0.000001f);
-    v3 dirproj = normalize3(tdir);
-    v3 dr = mk3(1.0f / dirproj.x, 1.0f / dirproj.y, 1.0f / dirproj.z);
-    // root: intersectCubeSingle (mathlib.glsl:107-126) against [-1e-5, 1+1e-5]^3, :365
-    v3 no = mk3(-torig.x * dr.x, -torig.y * dr.y, -torig.z * dr.z);
-    const float lo = -0.00001f, hi = 1.00001f;
-    float a0 = fmaf(lo, dr.x, no.x), a1 = fmaf(hi, dr.x, no.x);
-    float b0 = fmaf(lo, dr.y, no.y), b1 = fmaf(hi, dr.y, no.y);
-    float c0 = fmaf(lo, dr.z, no.z), c1 = fmaf(hi, dr.z, no.z);
-    float tNear = smaxf(smaxf(sminf(a0, a1), sminf(b0, b1)), sminf(c0, c1));
-    float tFar = sminf(sminf(smaxf(a0, a1), smaxf(b0, b1)), smaxf(c0, c1));
-    bool isCube = greaterEqualF(tFar, tNear) && greaterEqualF(tFar, 0.0f);
-    float nr = isCube ? sminf(tNear, tFar) : INF;
-    float fr = isCube ? smaxf(tNear, tFar) : INF;
-    float rootD = isCube ? (lessF(nr, 0.0f) ? fr : nr) : INF;
-    float toffset = smaxf(nr, 0.f);
-    v3 origined = mk3(torig.x + dirproj.x * toffset, torig.y + dirproj.y * toffset, torig.z + dirproj.z * toffset);
-    v3 norig = mk3(-origined.x * dr.x, -origined.y * dr.y, -origined.z * dr.z);
-    bool valid = root >= 0 && lessF(rootD, INF) && lessF(rootD * dirlenInv, INF) && greaterEqualF(rootD, 0.0f);
-    // box half (read at refill): -origined/dirproj | toffset ; 1/dirproj | +-dirlenInv (sign = !validBox)
-    T[2 * (size_t)i + 0] = make_float4(norig.x, norig.y, norig.z, toffset);
-    T[2 * (size_t)i + 1] = make_float4(dr.x, dr.y, dr.z, valid ? dirlenInv : -dirlenInv);
-    // triangle half (read only when a leaf is tested): world origin, normalised direction
-    float4* Ta = T + 2 * (size_t)nrays_cap;
-    Ta[2 * (size_t)i + 0] = make_float4(origin.x, origin.y, origin.z, 0.f);
-    Ta[2 * (size_t)i + 1] = make_float4(direct.x, direct.y, direct.z, 0.f);
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void rt_traverse_pt(const float4* __restrict__ T, uint32_t nrays, uint32_t nrays_cap,
-                                                           const uint4* __restrict__ node32,
-                                                           const float4* __restrict__ tri48,
-                                                           const uint32_t* __restrict__ sm, float4* __restrict__ hit0,
-                                                           uint32_t* __restrict__ hitN, float4* __restrict__ pool,
-                                                           uint32_t pool_cap, uint32_t* __restrict__ cnt,
-                                                           DevCounters* __restrict__ ctr, PtTune tune, int cursor) {
-    __shared__ int stack_all[PT_WAVES][STACK_CAP][64];
-    // two ray cursors, used by alternate launches: this launch zeroes the one the next launch uses
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[3 + (cursor ^ 1)] = 0;
-    const int REFILL_MIN = tune.refill_min;
-    const int lane = lane_id();
-    int (*stack)[64] = stack_all[threadIdx.x >> 6];
-    const uint64_t lt = lanemask_lt();
-    const int root = (int)sm[SM_ROOT];
-    const float IP = INF - PZERO;
-    const float4* __restrict__ Ta = T + 2 * (size_t)nrays_cap;
-    uint32_t* cursor_p = &cnt[3 + cursor];
-
-    bool busy = false;     // slot holds a ray that is not finalised
-    bool walking = false;  // validBox: there is a node to visit (cur)
-    bool loading = false;  // refill loads issued last pass, committed at the top of this one
-    uint32_t ray = 0;
-    v3 divident = mk3(1, 1, 1), norig = mk3(0, 0, 0);
-    float toffset = 0.f, dirlenInv = 1.f, predist = INF;
-    float4 nt0 = make_float4(0, 0, 0, 0), nt1 = make_float4(0, 0, 0, 0);
-    int lastTri = -1, bakedCount = 0, cur = 0, sp = 0, iters = 0;
-    Baked head = {0.f, 0.f, INF, -1};
-    Baked extra[BAKED_CAP - 1];
-    uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
-
-    // ray indices are reserved 64 at a time, one reservation ahead, so a refill never waits on an atomic
-    uint32_t resBase = 0, resUsed = 64, nextBase = 0;  // wave-uniform
-    if (lane == 0) nextBase = atomicAdd(cursor_p, 64u);
-    bool exhausted = false;
-
-    for (;;) {
-        // ---- commit the rays whose loads were issued in the previous pass --------------------------
-        if (loading) {
-            norig = mk3(nt0.x, nt0.y, nt0.z); toffset = nt0.w;
-            divident = mk3(nt1.x, nt1.y, nt1.z);
-            walking = nt1.w > 0.0f;
-            dirlenInv = pabs(nt1.w);
-            predist = INF; lastTri = -1; bakedCount = 0; cur = root; sp = 0; iters = 0;
-            head.u = 0.f; head.v = 0.f; head.t = INF; head.tri = -1;
-            loading = false;
-        }
-        // ---- hand-over event: finished slots are finalised and refilled together, and only when enough
-        // of them have piled up (or nothing else can run), so the partly filled finalise / refill code
-        // does not execute on every pass ---------------------------------------------------------------
-        bool done = busy && !walking && !loading;
-        uint64_t idleMask = __ballot(done || !busy);
-        uint64_t stepMask = __ballot(busy && walking && !loading);
-        if (__popcll(idleMask) >= REFILL_MIN || (stepMask == 0 && __ballot(loading) == 0)) {
-                // finalise (reorderTriangles :74-112 + includeChain :219-250)
-            if (busy && !walking && !loading) {
-                uint32_t count = 0, off = 0;
-                if (bakedCount <= 1) {
-                    count = (uint32_t)bakedCount;
-                } else {
-                    Baked bk[BAKED_CAP];
-                    int n = bakedCount > BAKED_CAP ? BAKED_CAP : bakedCount;
-                    bk[0] = head;
-                    for (int k = 1; k < n; k++) bk[k] = extra[k - 1];
-                    for (int iround = 1; iround < n; iround++) {
-                        for (int index = 0; index < n - iround; index++) {
-                            Baked a = bk[index], b = bk[index + 1];
-                            bool lessIdx = a.tri <= b.tri;
-                            bool deeper = lessF(a.t, b.t);
-                            if (lessIdx || deeper) { bk[index] = b; bk[index + 1] = a; }
-                        }
-                    }
-                    int clean = 0;
-                    for (int iround = 0; iround < BAKED_CAP; iround++) {
-                        if (iround >= n - 1) break;
-                        if (bk[iround + 1].tri != bk[iround].tri) bk[clean++] = bk[iround];
-                    }
-                    if (n > 0 && clean <= BAKED_CAP) bk[clean++] = bk[n - 1];
-                    head = bk[0];
-                    count = (uint32_t)clean;
-                    if (count > 1) {
-                        off = atomicAdd(&cnt[2], count - 1);
-                        if (off + (count - 1) > pool_cap) {
-                            if (COUNT) atomicAdd(&ctr->chain_pool_drops, 1ull);
-                            count = 1;
-                        } else {
-                            for (uint32_t k = 1; k < count; k++)
-                                pool[off + k - 1] = make_float4(bk[k].u, bk[k].v, bk[k].t, __int_as_float(bk[k].tri));
-                        }
-                    }
-                }
-                if (count == 0) hit0[ray] = make_float4(0.f, 0.f, INF, __int_as_float(-1));
-                else hit0[ray] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
-                hitN[ray] = count | (off << 4);
-                busy = false;
-            }
-            // refill
-            uint64_t freeMask = __ballot(!busy);
-            int nFree = __popcll(freeMask);
-            if (!exhausted && nFree > 0) {
-                if (resUsed >= 64u) {  // switch to the reservation made earlier, reserve the next one
-                    resBase = __shfl(nextBase, 0, 64);
-                    resUsed = 0;
-                    if (resBase >= nrays) exhausted = true;
-                    else if (lane == 0) nextBase = atomicAdd(cursor_p, 64u);
-                }
-                if (!exhausted) {
-                    uint32_t avail = 64u - resUsed;
-                    uint32_t rank = (uint32_t)__popcll(freeMask & lt);
-                    uint32_t mine = resBase + resUsed + rank;
-                    if (!busy && rank < avail && mine < nrays) {
-                        ray = mine;
-                        const float4* tp = T + 2 * (size_t)mine;
-                        nt0 = tp[0];
-                        nt1 = tp[1];
-                        busy = true;
-                        loading = true;
-                        walking = false;
-                    }
-                    resUsed += min((uint32_t)nFree, avail);
-                }
-            }
-        }
-        if (__ballot(busy) == 0) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- box step (:388-476) + leaf tests (:261-309) ------------------------------------------
-        if (busy && walking && !loading) {
-            if (iters >= MAX_ITERS) {
-                if (COUNT) nCap++;
-                walking = false;
-            } else {
-                iters++;
-                const uint4* np = node32 + 2 * (size_t)cur;
-                uint4 n0 = np[0], n1 = np[1];
-                if (COUNT) nV++;
-                Slab2 L = slab6(divident, norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
-                Slab2 R = slab6(divident, norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
-                int lkx = (int)n1.z, lky = (int)n1.w;
-                bool leftNear = lessEqualF(L.near, R.near);  // :414
-                bool ogL = (L.hit <= IP) && (L.hit * dirlenInv <= IP) && (L.hit > -PZERO) && (L.near <= IP) &&
-                           (L.near * dirlenInv <= IP) && (((L.near + toffset) * dirlenInv - PZERO) <= predist);
-                bool ogR = (R.hit <= IP) && (R.hit * dirlenInv <= IP) && (R.hit > -PZERO) && (R.near <= IP) &&
-                           (R.near * dirlenInv <= IP) && (((R.near + toffset) * dirlenInv - PZERO) <= predist);
-                bool leafL = ogL && lkx < 0, leafR = ogR && lky < 0;
-                bool intL = ogL && lkx >= 0, intR = ogR && lky >= 0;
-                if (leafL || leafR) {  // :441-448
-                    bool leftOrder = (leafL && leafR) ? leftNear : leafL;
-                    int triL = leafL ? ~lkx : -1, triR = leafR ? ~lky : -1;
-                    int tx = leftOrder ? triL : triR, ty = leftOrder ? triR : triL;
-                    bool validx = (tx >= 0) && (tx != lastTri);
-                    bool validy = (ty >= 0) && (ty != lastTri) && (tx != ty);
-                    if (!validx) { tx = ty; validx = validy; validy = false; }
-                    v3 origin = mk3(0, 0, 0), direct = mk3(0, 0, 1);
-                    if (validx) {
-                        float4 o4 = Ta[2 * (size_t)ray + 0], d4 = Ta[2 * (size_t)ray + 1];
-                        origin = mk3(o4.x, o4.y, o4.z);
-                        direct = mk3(d4.x, d4.y, d4.z);
-                    }
-#pragma unroll 1
-                    for (int pass = 0; pass < 2; pass++) {
-                        int tri = pass == 0 ? tx : ty;
-                        bool valid = pass == 0 ? validx : validy;
-                        if (valid) {
-                            float u = 0.f, v = 0.f;
-                            float d = tri_test(tri48, tri, origin, direct, u, v);
-                            if (COUNT) nT++;
-                            bool near = lessF(d, INF) && lessEqualF(d, predist) && greaterEqualF(d, 0.0f);
-                            if (near) {
-                                if (!equalF(d, predist)) bakedCount = 0;
-                                predist = d;
-                                lastTri = tri;
-                                int at = bakedCount++;
-                                if (at == 0) { head.u = u; head.v = v; head.t = d; head.tri = tri; }
-                                else if (at < BAKED_CAP) { extra[at - 1].u = u; extra[at - 1].v = v; extra[at - 1].t = d; extra[at - 1].tri = tri; }
-                                else if (COUNT) nBakedDrop++;
-                            }
-                        }
-                    }
-                }
-                if (intL || intR) {  // :451-462
-                    bool leftOrder = (intL && intR) ? leftNear : intL;
-                    int lr0 = intL ? lkx : -1, lr1 = intR ? lky : -1;
-                    if (!leftOrder) { int t = lr0; lr0 = lr1; lr1 = t; }
-                    if (lr1 != -1 && lr0 != lr1) {
-                        if (sp < STACK_CAP) stack[sp++][lane] = lr1;
-                        else if (COUNT) nDrop++;
-                    }
-                    cur = lr0;
-                } else {  // :467-476
-                    sp--;
-                    if (sp >= 0) cur = stack[sp][lane];
-                    else walking = false;
-                }
-            }
-        }
-    }
-    if (COUNT) {
-        uint32_t v = wave_sum(nV), t = wave_sum(nT), d = wave_sum(nDrop), c = wave_sum(nCap), b = wave_sum(nBakedDrop);
-        if (lane == 0) {
+            atomicAdd(&ctr->wave_clock_ticks, (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
+            atomicAdd(&ctr->wave_real_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dg_r0));
+            atomicAdd(&ctr->wave_steps, dg_steps);
+            atomicAdd(&ctr->waves, 1ull);
             if (v) atomicAdd(&ctr->node_visits, (unsigned long long)v);
             if (t) atomicAdd(&ctr->tri_tests, (unsigned long long)t);
             if (d) atomicAdd(&ctr->stack_drops, (unsigned long long)d);
@@ -727,7 +447,6 @@ static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<Ph
     int mode = r->trav_mode;
     if (chain) return PSM_TRAVERSE_WHOLE;  // later hierarchies of a multi-BVH queue: rt_traverse<*, CHAIN>
     if (mode == PSM_TRAVERSE_AUTO) mode = PSM_TRAVERSE_ADAPTIVE;
-    if (mode == PSM_TRAVERSE_PERSISTENT) return mode;
     if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_PHASED) {
         for (int k = 0; k < r->phase_caps_n; k++) plan.push_back(PhasePlan{r->phase_caps[k], 0u});
@@ -756,7 +475,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     r->trav_objs[r->trav_n++] = b;
     std::vector<PhasePlan> plan;
     const int mode = plan_traverse(r, n, chain, plan);
-    if (mode != PSM_TRAVERSE_PERSISTENT) {
+    {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
 #define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
                       r->pool_cap, r->d_cnt, c->d_counters, tag
@@ -803,38 +522,6 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
             }
         }
 #undef PSM_TRAV_ARGS
-    } else {
-        // persistent-threads kernel: 256 CUs x the resident workgroups of 4 waves; fewer when the queue is
-        // short. Ray cursors cnt[3], cnt[4] alternate between launches (each launch zeroes the other one), so no
-        // memset sits between traversals.
-        static std::mutex pt_mutex;  // the lazily queried occupancy below; lanes may issue from several host threads
-        std::lock_guard<std::mutex> pt_lock(pt_mutex);
-        static int resident[2] = {0, 0};
-        int& res = resident[c->counting ? 1 : 0];
-        if (res == 0) {
-            int per_cu = 0, cus = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
-            hipError_t e = c->counting
-                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_traverse_pt<true>, PT_BLOCK, 0)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_traverse_pt<false>, PT_BLOCK, 0);
-            if (e != hipSuccess || per_cu <= 0) per_cu = 4;
-            res = per_cu * cus;
-        }
-        PtTune tune = {(int)r->pt_refill_min};
-        uint32_t cap = r->pt_grid > 0 ? r->pt_grid : (uint32_t)res;
-        uint32_t need = (n + PT_BLOCK - 1) / PT_BLOCK;
-        uint32_t grid = need < cap ? need : cap;
-        TimedScope ts(c, CAT_TRAVERSE);
-        if (!r->qT) PSM_HIP(c, hipMalloc((void**)&r->qT, sizeof(float4) * 4 * (size_t)r->limit));  // freed with the ray grid
-        rt_project<<<(n + 255) / 256, 256, 0, c->stream>>>(r->qA[r->cur], r->qB[r->cur], n, r->limit, b->d_small, r->qT);
-        if (c->counting)
-            rt_traverse_pt<true><<<grid, PT_BLOCK, 0, c->stream>>>(r->qT, n, r->limit, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN,
-                                                                   r->pool, r->pool_cap, r->d_cnt, c->d_counters, tune, r->cursor);
-        else
-            rt_traverse_pt<false><<<grid, PT_BLOCK, 0, c->stream>>>(r->qT, n, r->limit, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN,
-                                                                    r->pool, r->pool_cap, r->d_cnt, c->d_counters, tune, r->cursor);
-        r->cursor ^= 1;
     }
     PSM_HIP(c, hipGetLastError());
     c->rays_traced += n;

@@ -92,5 +92,91 @@ def main():
                 name, tot, 100.0 * ideal / max(tot, 1), saves / n, launches))
 
 
+
+
+def sim_refill(steps, thr, resident_waves, drain="inplace"):
+    """persistent waves with wave-level refill: a wave whose live lanes drop below `thr` finalises its finished
+    rays and pulls fresh rays (queue order) into the free lanes; survivors keep their lanes. When the queue is
+    exhausted a wave drains in place ("inplace") or hands its survivors over for packed resume launches
+    ("handover": simulated with sim_live on the leftovers). Event-driven over wave-step time."""
+    import heapq
+    n = len(steps)
+    cursor = 0
+    total = 0
+    leftovers = []
+    heap = []  # (time of next event, wave id)
+    lanes = {}
+    for w in range(resident_waves):
+        if cursor >= n:
+            break
+        take = steps[cursor:cursor + 64].copy()
+        cursor += len(take)
+        lanes[w] = take
+        heapq.heappush(heap, (0, w))
+    refills = 0
+    while heap:
+        t, w = heapq.heappop(heap)
+        rem = lanes[w]
+        rem = rem[rem > 0]
+        if cursor < n:
+            free = 64 - len(rem)
+            take = steps[cursor:cursor + free]
+            cursor += len(take)
+            rem = np.concatenate([rem, take])
+            refills += 1
+        if len(rem) == 0:
+            continue
+        if cursor >= n:  # exhausted: drain or hand over
+            if drain == "inplace" or len(rem) >= thr:
+                # run until fewer than thr are live, then decide again (or to the end when draining in place)
+                if drain == "inplace":
+                    total += rem.max()
+                    continue
+                srt = np.sort(rem)[::-1]
+                stop = srt[thr - 1] if len(srt) >= thr else 0
+                total += stop
+                left = rem - stop
+                leftovers.append(left[left > 0])
+                continue
+            leftovers.append(rem)
+            continue
+        srt = np.sort(rem)[::-1]
+        stop = srt[thr - 1] if len(srt) >= thr else srt[0]  # steps until fewer than thr lanes are live
+        stop = max(int(stop), 1)
+        total += stop
+        lanes[w] = rem - stop
+        heapq.heappush(heap, (t + stop, w))
+    extra = (0, 0, 0)
+    if leftovers:
+        lo = np.concatenate(leftovers)
+        if len(lo):
+            extra = sim_live(lo, thr, 0, final_rays=1024)
+    return total + extra[0], refills, 1 + extra[2], len(np.concatenate(leftovers)) if leftovers else 0
+
+
+def refill_report():
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 960
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 540
+    sc = scenes.sponza_like()
+    ob = O.build_scene(sc["tris"])
+    rec = []
+    O.render_frames(sc, W, H, frames=1, seed=1000, nthreads=8, built=ob, record=rec, frame_streams=True)
+    res_waves = 8192 * (W * H) // (1920 * 1080)
+    for r in rec:
+        rays = r["rays"]
+        v, _ = O.traverse_visits(ob["nodes"], sc["tris"], ob["M"], rays["origin"], rays["direct"], 8)
+        steps = v.astype(np.int64)
+        ideal = steps.sum() / 64.0
+        print("round %d: %d rays; whole %d wave-steps (util %.1f %%)" % (r["round"], len(steps), sim_cap(steps, [])[0], 100 * ideal / sim_cap(steps, [])[0]))
+        for thr in (8, 16, 24, 32, 40, 48):
+            for drain in ("inplace", "handover"):
+                tot, refills, launches, left = sim_refill(steps, thr, res_waves, drain)
+                print("   refill<%d %-8s wave-steps %9d  util %5.1f %%  refills/wave-batch %.2f  launches %d  handed over %d" % (
+                    thr, drain, tot, 100.0 * ideal / tot, refills / (len(steps) / 64.0), launches, left))
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("REFILL"):
+        refill_report()
+    else:
+        main()

@@ -260,3 +260,20 @@ def test_two_rank_gloo_frame_equals_unsharded(tmp_path, oracle, scenes):
     # the oracle adds deposits in queue order, which differs between 1 and 2 tiles: compare to 1e-5
     np.testing.assert_allclose(merged[:, :3], full.tsum[:, :3], rtol=1e-5, atol=1e-6)
     assert np.array_equal(merged[:, 3], full.tsum[:, 3])
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (no RANK in the environment) must not sit in init_process_group
+    waiting for peers nobody started: it spawns the two ranks itself. --dry-run stops each rank after its
+    communicator works (gloo, no GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("bench.py dry run")]
+    assert len(lines) == 2
+    assert {ln.split("rank ")[1].split(" ")[0] for ln in lines} == {"0", "1"}
+    assert all(ln.endswith("= 2") for ln in lines)

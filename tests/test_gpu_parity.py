@@ -280,9 +280,6 @@ TRAVERSE_SCHEDULES = [
     ("adaptive", {"min_live": 64, "min_steps": 0, "final_rays": 0, "max_launches": 15}),   # hand over at the first idle lane
     ("adaptive", {"min_live": 2, "min_steps": 1, "final_rays": 0, "max_launches": 3}),
     ("adaptive", {"min_live": 24, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
-    ("persistent", {"refill_min": 8}),
-    ("persistent", {"refill_min": 1, "grid_blocks": 3}),
-    ("persistent", {"refill_min": 64, "grid_blocks": 1}),
 ]
 
 
@@ -291,15 +288,13 @@ def _select_schedule(rt, mode, kw):
         rt.setTraversePhases(kw["caps"], min_rays=0)
     elif mode == "adaptive":
         rt.setTraverseAdaptive(min_rays=0, **kw)
-    elif mode == "persistent":
-        rt.setTraversePersistent(**kw)
     rt.setTraverseMode(mode)
 
 
 @pytest.mark.parametrize("mode,kw", TRAVERSE_SCHEDULES, ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()).replace(" ", ""))
 def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, kw):
     """psm_rt_set_traverse_mode: every kernel schedule that ships -- one launch, fixed-cap phases, ballot-triggered
-    hand-over with persistent resume waves, persistent threads with per-lane refill -- gives the hits, chains and
+    hand-over with persistent resume waves -- gives the hits, chains and
     V / T counters of the oracle's uninterrupted per-ray loop (directTraverse.comp:333-484)."""
     scene = scenes.sponza_like(n_tris=20011)
     w, h = 160, 90
@@ -325,7 +320,7 @@ def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, k
 
 
 @pytest.mark.parametrize("mode,kw", [("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 64, "max_launches": 8}),
-                                     ("persistent", {"refill_min": 8})], ids=["adaptive", "persistent"])
+                                     ("phased", {"caps": [5, 9]})], ids=["adaptive", "phased"])
 def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes, mode, kw):
     """Rays that carry an equal-distance chain of two or more hits cannot hand over (their chain lives in registers):
     they finish in the launch they are in. Duplicated coplanar triangles make thousands of them."""

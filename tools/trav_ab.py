@@ -38,7 +38,6 @@ CONFIGS = [
     ("live16f16k", "adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 16384}),
     ("live16f1k", "adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 1024}),
     ("live16l4", "adaptive", {"min_live": 16, "min_steps": 8, "max_launches": 4}),
-    ("pt8", "persistent", {"refill_min": 8}),
 ]
 if args.configs:
     want = args.configs.split(",")
@@ -75,8 +74,6 @@ def select(mode, kw):
         rt.setTraversePhases(kw["caps"], min_rays=0)
     elif mode == "adaptive":
         rt.setTraverseAdaptive(min_rays=0, **kw)
-    elif mode == "persistent":
-        rt.setTraversePersistent(**kw)
     rt.setTraverseMode(mode)
 
 

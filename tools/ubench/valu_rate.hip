@@ -1,0 +1,92 @@
+// valu_rate.hip -- how many cycles does one SIMD of gfx950 need per wave64 VALU instruction, as a function of the
+// waves resident on it and of the instruction kind? (MI355X_MICROARCH.md says 2 for v_fma_f32 with several waves,
+// the traversal kernel's counters look like 4.)  Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+template <int KIND>
+__global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int iters) {
+    float a0 = threadIdx.x * 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = 1.0001f, c = 0.5f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (KIND == 0) {
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 1) {
+                asm volatile("v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                             "v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_max_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 2) {
+                asm volatile("v_fma_mix_f32 %0, %8, %0, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %1, %9 op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %2, %8, %2, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %3, %9 op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %4, %8, %4, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %5, %9 op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %6, %8, %6, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %7, %9 op_sel_hi:[1,0,0]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 3) {
+                asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+            } else if (KIND == 4) {
+                asm volatile("v_min3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
+                             "v_min3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 5) {  // VALU / SALU mix as the traversal loop has it: v_cmp -> sgpr, s_and, v_cndmask from sgpr
+                asm volatile("v_cmp_lt_f32 s[20:21], %0, %8\n v_cmp_gt_f32 s[22:23], %1, %8\n s_and_b64 s[20:21], s[20:21], s[22:23]\n v_cndmask_b32 %2, %2, %8, s[20:21]\n"
+                             "v_cmp_lt_f32 s[24:25], %4, %8\n v_cmp_gt_f32 s[26:27], %5, %8\n s_and_b64 s[24:25], s[24:25], s[26:27]\n v_cndmask_b32 %6, %6, %8, s[24:25]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
+                             : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+            } else {
+                asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int KIND>
+static void run(const char* name, int vinst_per_group) {
+    const int iters = 2000;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, 256 * 4 * 8 * 64 * 4 * 2);
+    hipMalloc(&cyc, 256 * 4 * 8 * 8 * 2);
+    printf("%-28s", name);
+    for (int wps : {1, 2, 4, 8}) {       // waves per SIMD: grid = 256 CUs x 4 SIMDs x wps one-wave blocks
+        int grid = 256 * 4 * wps;
+        k<KIND><<<grid, 64>>>(out, cyc, 10);  // warm
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        k<KIND><<<grid, 64>>>(out, cyc, iters);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(grid);
+        hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
+        double sum = 0; for (auto v : h) sum += (double)v;
+        double per_wave = sum / grid;                                   // memtime ticks (100 MHz? or shader clock) per wave
+        double insts = (double)iters * 8 * vinst_per_group;            // VALU instructions per wave
+        // wall-clock based: SIMD-cycles per instruction at 2.4 GHz = ms * 2.4e6 / (insts * wps)
+        printf("  wps %d: %.2f cyc/inst/SIMD @2.4GHz (%.3f ms, memtime/inst %.2f)", wps, ms * 2.4e6 / (insts * wps), ms, per_wave / insts);
+    }
+    printf("\n");
+}
+
+int main() {
+    run<0>("v_fma_f32", 8);
+    run<6>("v_mul/v_add_f32", 8);
+    run<1>("v_min/v_max_f32", 8);
+    run<2>("v_fma_mix_f32", 8);
+    run<4>("v_min3/v_max3_f32", 8);
+    run<3>("v_cmp(vcc)+v_cndmask", 8);
+    run<5>("2 v_cmp(sgpr)+s_and+v_cndmask", 6);
+    return 0;
+}
