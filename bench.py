@@ -255,17 +255,74 @@ def cpu_baseline(scene, ray_sets, args):
                       "best of 2; oracle BVH build %.2f s on 1 core" % (rays.shape[0], n, max(1, n // max(rays.shape[0], 1)), build_s)}
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/collect.sh):
-    bench.py cannot run the profiler on itself, so the figure comes from the last collected profile."""
-    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    try:
-        d = json.load(open(path))
-        if d.get("kernel") == kernel:
-            return float(d["traffic_bytes_per_launch"]), d.get("source")
-    except (OSError, ValueError, KeyError):
-        pass
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md: L2 aggregate, streaming
+MALL_GATHER_GBS = 8600.0     # MI355X_MICROARCH.md: uniformly random rows of a 38 MB table (Infinity Cache), chip-wide
+VALU_QUAD_CYCLES = 4.0       # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md cycle constants)
+SIMDS = 1024
+
+
+def pmc_entry(scene, width, height, kernel):
+    """Per-launch PMC figures of `kernel` for this workload from the committed rocprofv3 passes (profiles/collect.sh ->
+    profiles/make_traffic.py): bench.py cannot run the profiler on itself."""
+    for name in ("traffic_r02.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        for e in d.get("entries", []):
+            if (e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel):
+                return e, "profiles/" + name
     return None, None
+
+
+def roofline(st, Rr, V, T, copy_gbs, scene, width, height, lanes_mode):
+    """What bounds the dominant kernel (traversal). `achieved` / `frac` keep SURVEY 8(d)'s algorithmic figure
+    (R*44 + V*64 + T*36 over the launch time) against the HBM peak; `bound` is decided by the counters: when the
+    HBM-side traffic of a launch is a small part of that figure the data is cache-resident and the kernel is priced
+    by VALU issue and by its own records (V*32 + T*48 + R*44) against the cache ceilings instead."""
+    launches = max(st.traverse_launches, 1)
+    avg_ms = st.traverse_ms / launches
+    sec = avg_ms * 1e-3
+    alg = (Rr * 44 + V * 64 + T * 36) / launches
+    own = (Rr * 44 + V * 32 + T * 48) / launches
+    achieved = alg / sec / 1e9 if sec > 0 else 0.0
+    kernel = "rt_traverse<false, false, false>"
+    e, src = pmc_entry(scene, width, height, kernel)
+    out = {"bound": "unknown: no committed PMC pass for this workload", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "launches": int(st.traverse_launches),
+           "avg_launch_ms": avg_ms,
+           "measured": ("kernel pass: the timed region's frames one after another, HIP events per launch on the launching "
+                        "stream (with frames in flight launches of different streams overlap)") if lanes_mode
+                       else "timed region, HIP events per launch",
+           "algorithmic_bytes_per_launch": alg, "own_record_bytes_per_launch": own,
+           "own_record_gbs": own / sec / 1e9 if sec > 0 else 0.0,
+           "own_record_frac_of_l2_peak": own / sec / 1e9 / L2_PEAK_GBS if sec > 0 else None,
+           "own_record_frac_of_infinity_cache_gather": own / sec / 1e9 / MALL_GATHER_GBS if sec > 0 else None,
+           "node_visits_per_s": V / (st.traverse_ms * 1e-3) if st.traverse_ms > 0 else None,
+           "measured_copy_gbs": copy_gbs, "R": int(Rr), "V": int(V), "T": int(T), "rank": 0}
+    if e is None:
+        return out
+    traffic = e.get("traffic_bytes_per_launch")
+    out["traffic"] = traffic
+    out["traffic_source"] = src + ": " + e.get("source", "")
+    out["traffic_fetch_raw"] = e.get("fetch_bytes_per_launch_raw")
+    hbm_frac = traffic / sec / 1e9 / HBM_PEAK_GBS if (traffic and sec > 0) else None
+    out["hbm_frac"] = hbm_frac                                    # HBM-side bytes of the counters over the launch time
+    out["hbm_frac_of_measured_copy"] = (traffic / sec / 1e9 / copy_gbs) if (traffic and sec > 0 and copy_gbs > 0) else None
+    out["traffic_over_own_record_bytes"] = traffic / own if (traffic and own) else None
+    if e.get("l2_hit") is not None:
+        out["l2_hit"] = e["l2_hit"]
+    sq = e.get("sq_per_launch") or {}
+    if sq.get("SQ_ACTIVE_INST_VALU") and e.get("kernel_trace_avg_us"):
+        # share of the launch during which a SIMD's VALU is executing an instruction (profiled launch, 2.4 GHz nominal)
+        out["valu_issue_utilisation"] = sq["SQ_ACTIVE_INST_VALU"] * VALU_QUAD_CYCLES / SIMDS / (e["kernel_trace_avg_us"] * 1e-6 * 2.4e9)
+        out["valu_lane_utilisation"] = e.get("valu_lane_utilisation")
+        out["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU")
+    if hbm_frac is not None and traffic >= 0.5 * own:
+        out["bound"] = "hbm" if hbm_frac >= 0.4 else "hbm latency (HBM-resident records, divergent 32-byte gathers)"
+    else:
+        out["bound"] = "cache/VALU: records served by L2 + Infinity Cache, VALU issue under divergence"
+    return out
 
 
 def spawn_ranks(n):
@@ -412,13 +469,8 @@ def main():
 
     if dist.rank == 0:
         img = R.batch.snapHdr()
-        alg_bytes = Rr * 44 + V * 64 + T * 36
-        launches = max(st.traverse_launches, 1)
-        traffic, traffic_src = pmc_traffic("rt_traverse") if (world == 1 and args.scene == "sponza_like" and
-                                                                (args.width, args.height) == (1920, 1080)) else (None, None)
-        avg_ms = st.traverse_ms / launches
-        achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         copy_gbs = ctx.copy_bandwidth(1 << 30, 5)  # the box's achievable ceiling next to the vendor peak
+        roof = roofline(st, Rr, V, T, copy_gbs, args.scene, args.width, args.height, lanes_mode)  # rank 0's launches
         out = {
             "metric": "Mrays/sec + ms/frame, Sponza 1920x1080 4spp",
             "value": total_rays / elapsed / 1e6,
@@ -438,21 +490,15 @@ def main():
                        "parallelism": "tile%d" % world, "frames_in_flight": R.lanes},
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
-            "stage_ms_per_frame_measured": "kernel pass (one frame after another)" if lanes_mode else "timed region",
+            "stage_ms_per_frame_measured": ("kernel pass: the same frames one after another on one stream (serial path; with "
+                                            "frames in flight the stages of different frames overlap, so these do not add "
+                                            "up to ms_per_step)") if lanes_mode else "timed region",
             "stage_ms_per_frame": {"build": st.build_ms / args.steps, "bounds": st.bounds_ms / args.steps,
                                    "morton": st.morton_ms / args.steps, "sort": st.sort_ms / args.steps,
                                    "emit_refit": st.emit_ms / args.steps,
                                    "camera": st.camera_ms / args.steps, "traverse": st.traverse_ms / args.steps,
                                    "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "measured_copy_gbs": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs > 0 else None,
-                         "kernel": "rt_traverse", "launches": int(st.traverse_launches), "avg_launch_ms": avg_ms,
-                         "measured": ("kernel pass: the timed region's frames one after another, HIP events per launch "
-                                      "(launch durations overlap when several frames are in flight)") if lanes_mode
-                                     else "timed region, HIP events per launch",
-                         "algorithmic_bytes_per_launch": alg_bytes / launches,
-                         "R": int(Rr), "V": int(V), "T": int(T), "rank": 0},
+            "roofline": roof,
             "image_mean": float(img[..., :3].mean()),
         }
         if ray_sets is not None and world == 1:

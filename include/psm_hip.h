@@ -179,7 +179,9 @@ int psm_rt_resize(psm_rt* rt, uint32_t display_width, uint32_t display_height);
 /* tile sharding (new): this context owns ray-grid rows [y0,y1). Default all rows. */
 int psm_rt_set_tile(psm_rt* rt, uint32_t y0, uint32_t y1);
 /* interleaved sharding: this context owns the global 8-row bands g with g % world == rank (balances
- * sky rows against geometry rows; 1.01 max/mean on the Sponza-class view vs 1.21 for 8 contiguous strips) */
+ * sky rows against geometry rows; 1.01 max/mean on the Sponza-class view vs 1.21 for 8 contiguous strips).
+ * camera() then touches only the owned texels -- except on rank 0, the rank the tiles are gathered to, which
+ * also prepares the jitter positions / flags of all other texels because its sample() reads the whole image. */
 int psm_rt_set_tile_interleaved(psm_rt* rt, uint32_t rank, uint32_t world);
 /* lightColor/lightVector/lightOffset/lightAmbient + setLightCount, Pipeline.hpp:103-121 */
 int psm_rt_set_lights(psm_rt* rt, const psm_light* lights, uint32_t count);

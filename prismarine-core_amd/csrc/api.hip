@@ -519,7 +519,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     (void)hipSetDevice(c->device);
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     rt_free_grid(r);
-    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0;
+    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0; r->tile_root = true;
     uint64_t wr = (uint64_t)w * h;
     uint64_t lim = std::min<uint64_t>(wr * 4, 4096ull * 4096ull);  // Pipeline.inl:187-189
     r->limit = (uint32_t)lim;
@@ -570,11 +570,13 @@ int psm_rt_set_tile(psm_rt* r, uint32_t y0, uint32_t y1) {
     if (!r || y0 > y1 || y1 > r->h) return PSM_ERR_INVALID;
     r->y0 = y0; r->y1 = y1;
     r->tile_mode = 0;
+    r->tile_root = true;
     return PSM_OK;
 }
 int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) {
     if (!r || world == 0 || rank >= world) return PSM_ERR_INVALID;
     r->tile_mode = 1; r->tile_rank = rank; r->tile_world = world;
+    r->tile_root = rank == 0;  // tiles are gathered to rank 0 (psm_rt_unpack_texels_dev), which runs sample()
     return PSM_OK;
 }
 int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {

@@ -130,7 +130,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         return queue_round(ln);
     };
     // PSM_LANES_PROFILE=1: how much of the wall time the scheduler thread spends issuing work
-    static const bool profile = getenv("PSM_LANES_PROFILE") != nullptr;
+    const bool profile = getenv("PSM_LANES_PROFILE") != nullptr;  // debug print only, read per call
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
     double issue_s = 0.0, gpu_wait_s = 0.0, react_s = 0.0;  // profile: issue -> count seen, count seen -> next issue

@@ -26,15 +26,16 @@ struct ObjGeom {  // what interpolateMeshData reads of one hierarchy (directTrav
 };
 
 // state of a suspended traversal (trace.hip, phased launches)
-struct TravState {      // structure of arrays, `capacity` entries each
-    uint32_t* idx;      // ray index in the queue
-    int32_t* cur;
-    uint32_t* misc;     // sp | it << 8 | bakedCount << 24
-    float* predist;
-    int32_t* lastTri;
-    float4* head;       // u, v, t, tri of the chain head
-    int32_t* stack;     // [STACK_CAP][capacity]
-    uint32_t capacity;
+struct TravState {      // structure of arrays in ONE allocation, `capacity` entries each (one pointer: the kernel is
+    char* base;         // short of scalar registers): head float4 | idx u32 | cur i32 | misc u32 | predist f32 |
+    uint32_t capacity;  // lastTri i32 | stack i32[STACK_CAP][capacity]; misc = sp | it << 8 | bakedCount << 24
+    __host__ __device__ float4* head() const { return (float4*)base; }
+    __host__ __device__ uint32_t* idx() const { return (uint32_t*)(base + (size_t)16 * capacity); }
+    __host__ __device__ int32_t* cur() const { return (int32_t*)(base + (size_t)20 * capacity); }
+    __host__ __device__ uint32_t* misc() const { return (uint32_t*)(base + (size_t)24 * capacity); }
+    __host__ __device__ float* predist() const { return (float*)(base + (size_t)28 * capacity); }
+    __host__ __device__ int32_t* lastTri() const { return (int32_t*)(base + (size_t)32 * capacity); }
+    __host__ __device__ int32_t* stack() const { return (int32_t*)(base + (size_t)36 * capacity); }
 };
 struct Phase {
     uint32_t cap;              // wave-steps this launch may take (0xFFFFFFFF: no cap)
@@ -120,6 +121,7 @@ struct psm_rt {
     psm_ctx* ctx = nullptr;
     uint32_t w = 0, h = 0, dw = 0, dh = 0, y0 = 0, y1 = 0;
     uint32_t tile_mode = 0, tile_rank = 0, tile_world = 1;  // 0: rows [y0,y1); 1: 8-row bands g % world == rank
+    bool tile_root = true;        // this Pipeline samples the whole image: camera() also fills the texels it does not own
     uint32_t limit = 0;           // currentRayLimit
     int cur = 0;                  // current queue index
     uint32_t ray_count = 0;       // host mirror of the current queue length (valid after sync points)

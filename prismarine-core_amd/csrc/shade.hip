@@ -74,27 +74,40 @@ PSM_HD TileRow tile_row(Tile t, uint32_t y) {
     return r;
 }
 
+// owned texel k (row-major over the owned rows) -> its row; the inverse of tile_row().local_base
+PSM_HD uint32_t tile_owned_row(Tile t, uint32_t local_row) {
+    if (t.mode == 0) return t.a + local_row;
+    return ((local_row >> 3) * t.b + t.a) * 8 + (local_row & 7u);
+}
+
+// jittered sample position of a texel, camera.comp:27-35: a pure function of (texel, time)
+PSM_D float2 texel_coord(uint32_t idx, uint32_t x, uint32_t y, uint32_t time, float invw, float invh) {
+    Rng g{idx, 0u, time << 5};
+    float rx = g.next();
+    float ry = g.next();
+    return make_float2(((float)x + pclamp(rx, 0.00001f, 0.99999f)) * invw,   // :35
+                       ((float)y + pclamp(ry, 0.00001f, 0.99999f)) * invh);
+}
+
 // ---- camera, raytracing/camera.comp:22-101 ------------------------------------------------------
+// One thread per OWNED texel: a rank of a tile-sharded frame touches only its own rows (texel arrays and ray queue).
 __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, uint32_t time, uint32_t w, uint32_t h,
                                                  Tile tile, uint32_t nrays, float4* __restrict__ qA,
                                                  float4* __restrict__ qB, float4* __restrict__ qC,
                                                  float2* __restrict__ t_coord, float4* __restrict__ t_sum,
                                                  int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt, int enable360) {
-    uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx == 0) { cnt[0] = nrays; cnt[1] = 0; cnt[2] = 0; }
-    if (idx >= w * h) return;
-    uint32_t x = idx % w, y = idx / w;
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) { cnt[0] = nrays; cnt[1] = 0; cnt[2] = 0; }
+    if (k >= nrays) return;
+    uint32_t x = k % w, y = tile_owned_row(tile, k / w);
+    uint32_t idx = y * w + x;
     float invw = 1.0f / (float)w, invh = 1.0f / (float)h;
-    Rng g{idx, 0u, time << 5};
-    float rx = g.next();
-    float ry = g.next();
-    float cx = ((float)x + pclamp(rx, 0.00001f, 0.99999f)) * invw;  // :35
-    float cy = ((float)y + pclamp(ry, 0.00001f, 0.99999f)) * invh;
-    t_coord[idx] = make_float2(cx, cy);
+    float2 cxy = texel_coord(idx, x, y, time, invw, invh);
+    float cx = cxy.x, cy = cxy.y;
+    t_coord[idx] = cxy;
     t_sum[idx] = make_float4(0.f, 0.f, 0.f, 1.f);  // pre-collected zero sample (:99)
     t_flag[idx] = 1;
     TileRow tr = tile_row(tile, y);
-    if (!tr.owned) return;
     float nx = cx * 2.0f - 1.0f, ny = cy * 2.0f - 1.0f;
     float t0[4], co[4], orig[4];
     mat_vec(projInv.m, nx, ny, 0.999f, 1.0f, t0);
@@ -135,6 +148,20 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
     qA[q] = make_float4(orig[0], orig[1], orig[2], __int_as_float((int)idx));
     qB[q] = make_float4(dir.x, dir.y, dir.z, __int_as_float(bf));
     qC[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(idx));
+}
+
+// The gathering rank of a sharded frame samples the whole image (sampler.comp reads every texel's jitter position and
+// flag): it fills the texels it does not own here; their sums arrive with the gather (psm_rt_unpack_texels_dev).
+__global__ __launch_bounds__(256) void rt_camera_rest(uint32_t time, uint32_t w, uint32_t h, Tile tile,
+                                                      float2* __restrict__ t_coord, float4* __restrict__ t_sum,
+                                                      int32_t* __restrict__ t_flag) {
+    uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= w * h) return;
+    uint32_t x = idx % w, y = idx / w;
+    if (tile_row(tile, y).owned) return;
+    t_coord[idx] = texel_coord(idx, x, y, time, 1.0f / (float)w, 1.0f / (float)h);
+    t_sum[idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+    t_flag[idx] = 1;
 }
 
 // ---- surface: interpolateMeshData (directTraverse.comp:116-217) + surface.comp:165-195 -----------
@@ -784,8 +811,13 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
     uint32_t n = r->w * r->h;
     TimedScope ts(c, CAT_CAMERA);
     uint32_t nrays = tile_texel_count(r);
-    rt_camera<<<(n + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, make_tile(r), nrays, r->qA[r->cur], r->qB[r->cur],
-                                                      r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt, r->enable360);
+    if (nrays)
+        rt_camera<<<(nrays + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, make_tile(r), nrays, r->qA[r->cur], r->qB[r->cur],
+                                                          r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt, r->enable360);
+    else
+        PSM_HIP(c, hipMemsetAsync(r->d_cnt, 0, 3 * sizeof(uint32_t), c->stream));
+    if (r->tile_root && nrays < n)
+        rt_camera_rest<<<(n + 255) / 256, 256, 0, c->stream>>>(time, r->w, r->h, make_tile(r), r->t_coord, r->t_sum, r->t_flag);
     PSM_HIP(c, hipGetLastError());
     r->ray_count = nrays;
     r->count_valid = true;

@@ -113,22 +113,22 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
-    float M[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
     const int root = (int)sm[SM_ROOT];
     // fresh rays: one ray per thread of the grid. Resume: every wave strides over the continuation queue.
     for (uint32_t batch = blockIdx.x * TRAV_BLOCK + (uint32_t)(tid & ~63); batch < total; batch += gridDim.x * TRAV_BLOCK) {
     const uint32_t slot = batch + (uint32_t)(tid & 63);
     bool alive = slot < total;
     uint32_t i = slot;
-    if (resume) i = alive ? ph.in.idx[slot] : 0u;
+    if (resume) i = alive ? ph.in.idx()[slot] : 0u;
 
     float4 A = alive ? qA[i] : make_float4(0, 0, 0, 0);
     float4 B = alive ? qB[i] : make_float4(1, 0, 0, 0);
     v3 origin = mk3(A.x, A.y, A.z);
     v3 direct = normalize3(mk3(B.x, B.y, B.z));  // :350
 
+    float M[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
     float to4[4], td4[4];
     mat_vec(M, origin.x, origin.y, origin.z, 1.0f, to4);   // :353
     matT_vec(M, direct.x, direct.y, direct.z, 1.0f, td4);  // :354
@@ -176,16 +176,16 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     int sp = 0;
     int it = 0;
     if (resume && alive) {  // pick the ray up where the previous launch left it
-        uint32_t m = ph.in.misc[slot];
-        cur = ph.in.cur[slot];
+        uint32_t m = ph.in.misc()[slot];
+        cur = ph.in.cur()[slot];
         sp = (int)(m & 255u);
         it = (int)((m >> 8) & 0xFFFFu);
         bakedCount = (int)(m >> 24);
-        predist = ph.in.predist[slot];
-        lastTri = ph.in.lastTri[slot];
-        float4 hd = ph.in.head[slot];
+        predist = ph.in.predist()[slot];
+        lastTri = ph.in.lastTri()[slot];
+        float4 hd = ph.in.head()[slot];
         head.u = hd.x; head.v = hd.y; head.t = hd.z; head.tri = __float_as_int(hd.w);
-        for (int k = 0; k < sp; k++) stack[k][tid] = ph.in.stack[(size_t)k * ph.in.capacity + slot];
+        for (int k = 0; k < sp; k++) stack[k][tid] = ph.in.stack()[(size_t)k * ph.in.capacity + slot];
         validBox = true;
     }
     uint32_t wsteps = 0;
@@ -292,13 +292,13 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
                 base = __shfl(base, leader);
                 if (susp) {
                     const uint32_t o = base + (uint32_t)__popcll(sb & ((1ull << lane_id()) - 1ull));
-                    ph.out.idx[o] = i;
-                    ph.out.cur[o] = cur;
-                    ph.out.misc[o] = (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24);
-                    ph.out.predist[o] = predist;
-                    ph.out.lastTri[o] = lastTri;
-                    ph.out.head[o] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
-                    for (int k = 0; k < sp; k++) ph.out.stack[(size_t)k * ph.out.capacity + o] = stack[k][tid];
+                    ph.out.idx()[o] = i;
+                    ph.out.cur()[o] = cur;
+                    ph.out.misc()[o] = (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24);
+                    ph.out.predist()[o] = predist;
+                    ph.out.lastTri()[o] = lastTri;
+                    ph.out.head()[o] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
+                    for (int k = 0; k < sp; k++) ph.out.stack()[(size_t)k * ph.out.capacity + o] = stack[k][tid];
                     validBox = false;
                     suspended = true;
                 }
@@ -420,16 +420,8 @@ static int ensure_phase_buffers(psm_rt* r) {
     PSM_HIP(c, hipMalloc(&r->d_phase_mem, 2 * per + sizeof(uint32_t) * MAX_PHASES));
     char* base = (char*)r->d_phase_mem;
     for (int k = 0; k < 2; k++) {
-        char* p = base + k * per;
-        TravState& t = r->phase_state[k];
-        t.head = (float4*)p; p += L * 16;
-        t.idx = (uint32_t*)p; p += L * 4;
-        t.cur = (int32_t*)p; p += L * 4;
-        t.misc = (uint32_t*)p; p += L * 4;
-        t.predist = (float*)p; p += L * 4;
-        t.lastTri = (int32_t*)p; p += L * 4;
-        t.stack = (int32_t*)p;
-        t.capacity = (uint32_t)L;
+        r->phase_state[k].base = base + k * per;
+        r->phase_state[k].capacity = (uint32_t)L;
     }
     r->d_phase_cnt = (uint32_t*)(base + 2 * per);
     r->phase_cap = r->limit;
@@ -446,7 +438,10 @@ static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<Ph
     plan.clear();
     int mode = r->trav_mode;
     if (chain) return PSM_TRAVERSE_WHOLE;  // later hierarchies of a multi-BVH queue: rt_traverse<*, CHAIN>
-    if (mode == PSM_TRAVERSE_AUTO) mode = PSM_TRAVERSE_ADAPTIVE;
+    // AUTO: one launch. Measured on MI355X: the hand-over schedules cut the VALU instructions of a
+    // frame by a quarter and lift lane utilisation from 36 % to 52 %, but every schedule ends at the same ~115 G
+    // node visits / s (the divergent 32-byte gathers), and their extra launches serialise the long rays' tails.
+    if (mode == PSM_TRAVERSE_AUTO) mode = PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_PHASED) {
         for (int k = 0; k < r->phase_caps_n; k++) plan.push_back(PhasePlan{r->phase_caps[k], 0u});
