@@ -60,24 +60,30 @@ template <typename T> inline tmat4<T> operator*(const tmat4<T>& a, const tmat4<T
 }
 template <typename T> inline tmat4<T>& operator*=(tmat4<T>& a, const tmat4<T>& b) { a = a * b; return a; }
 template <typename T> inline tmat4<T> transpose(const tmat4<T>& m) { tmat4<T> r(T(0)); for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r[i][j] = m[j][i]; return r; }
+template <typename T> inline tvec4<T> operator*(const tvec4<T>& a, const tvec4<T>& b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+template <typename T> inline tvec4<T> operator+(const tvec4<T>& a, const tvec4<T>& b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+template <typename T> inline tvec4<T> operator-(const tvec4<T>& a, const tvec4<T>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+template <typename T> inline tvec4<T> operator*(const tvec4<T>& a, T s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+// the operation order of glm's own 4x4 inverse (cofactors in six 2x2 groups, determinant from column 0), so that the
+// matrices the host layer uploads are bit for bit glm's (tests/golden/glm_host_formulas.npz)
 template <typename T> inline tmat4<T> inverse(const tmat4<T>& m) {
-    // cofactor expansion on the row-major view a[r][c] = m[c][r]
-    T a[16]; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) a[4 * r + c] = m[c][r];
-    T b00 = a[0] * a[5] - a[1] * a[4], b01 = a[0] * a[6] - a[2] * a[4], b02 = a[0] * a[7] - a[3] * a[4];
-    T b03 = a[1] * a[6] - a[2] * a[5], b04 = a[1] * a[7] - a[3] * a[5], b05 = a[2] * a[7] - a[3] * a[6];
-    T b06 = a[8] * a[13] - a[9] * a[12], b07 = a[8] * a[14] - a[10] * a[12], b08 = a[8] * a[15] - a[11] * a[12];
-    T b09 = a[9] * a[14] - a[10] * a[13], b10 = a[9] * a[15] - a[11] * a[13], b11 = a[10] * a[15] - a[11] * a[14];
-    T id = T(1) / (b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06);
-    T o[16] = {(a[5] * b11 - a[6] * b10 + a[7] * b09) * id, (-a[1] * b11 + a[2] * b10 - a[3] * b09) * id,
-               (a[13] * b05 - a[14] * b04 + a[15] * b03) * id, (-a[9] * b05 + a[10] * b04 - a[11] * b03) * id,
-               (-a[4] * b11 + a[6] * b08 - a[7] * b07) * id, (a[0] * b11 - a[2] * b08 + a[3] * b07) * id,
-               (-a[12] * b05 + a[14] * b02 - a[15] * b01) * id, (a[8] * b05 - a[10] * b02 + a[11] * b01) * id,
-               (a[4] * b10 - a[5] * b08 + a[7] * b06) * id, (-a[0] * b10 + a[1] * b08 - a[3] * b06) * id,
-               (a[12] * b04 - a[13] * b02 + a[15] * b00) * id, (-a[8] * b04 + a[9] * b02 - a[11] * b00) * id,
-               (-a[4] * b09 + a[5] * b07 - a[6] * b06) * id, (a[0] * b09 - a[1] * b07 + a[2] * b06) * id,
-               (-a[12] * b03 + a[13] * b01 - a[14] * b00) * id, (a[8] * b03 - a[9] * b01 + a[10] * b00) * id};
-    tmat4<T> r(T(0)); for (int rr = 0; rr < 4; rr++) for (int cc = 0; cc < 4; cc++) r[cc][rr] = o[4 * rr + cc];
-    return r;
+    T c00 = m[2][2] * m[3][3] - m[3][2] * m[2][3], c02 = m[1][2] * m[3][3] - m[3][2] * m[1][3], c03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    T c04 = m[2][1] * m[3][3] - m[3][1] * m[2][3], c06 = m[1][1] * m[3][3] - m[3][1] * m[1][3], c07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    T c08 = m[2][1] * m[3][2] - m[3][1] * m[2][2], c10 = m[1][1] * m[3][2] - m[3][1] * m[1][2], c11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    T c12 = m[2][0] * m[3][3] - m[3][0] * m[2][3], c14 = m[1][0] * m[3][3] - m[3][0] * m[1][3], c15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    T c16 = m[2][0] * m[3][2] - m[3][0] * m[2][2], c18 = m[1][0] * m[3][2] - m[3][0] * m[1][2], c19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    T c20 = m[2][0] * m[3][1] - m[3][0] * m[2][1], c22 = m[1][0] * m[3][1] - m[3][0] * m[1][1], c23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+    tvec4<T> f0(c00, c00, c02, c03), f1(c04, c04, c06, c07), f2(c08, c08, c10, c11), f3(c12, c12, c14, c15), f4(c16, c16, c18, c19), f5(c20, c20, c22, c23);
+    tvec4<T> v0(m[1][0], m[0][0], m[0][0], m[0][0]), v1(m[1][1], m[0][1], m[0][1], m[0][1]), v2(m[1][2], m[0][2], m[0][2], m[0][2]), v3(m[1][3], m[0][3], m[0][3], m[0][3]);
+    tvec4<T> i0(v1 * f0 - v2 * f1 + v3 * f2), i1(v0 * f0 - v2 * f3 + v3 * f4), i2(v0 * f1 - v1 * f3 + v3 * f5), i3(v0 * f2 - v1 * f4 + v2 * f5);
+    tvec4<T> sa(T(1), T(-1), T(1), T(-1)), sb(T(-1), T(1), T(-1), T(1));
+    tmat4<T> inv(T(0));
+    inv[0] = i0 * sa; inv[1] = i1 * sb; inv[2] = i2 * sa; inv[3] = i3 * sb;
+    tvec4<T> row0(inv[0][0], inv[1][0], inv[2][0], inv[3][0]);
+    tvec4<T> d0(m[0] * row0);
+    T one_over_det = T(1) / ((d0.x + d0.y) + (d0.z + d0.w));
+    for (int c = 0; c < 4; c++) inv[c] = inv[c] * one_over_det;
+    return inv;
 }
 template <typename T> inline tmat4<T> translate(const tvec3<T>& v) { tmat4<T> r(T(1)); r[3].x = v.x; r[3].y = v.y; r[3].z = v.z; return r; }
 template <typename T> inline tmat4<T> scale(const tvec3<T>& v) { tmat4<T> r(T(1)); r[0].x = v.x; r[1].y = v.y; r[2].z = v.z; return r; }

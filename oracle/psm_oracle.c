@@ -102,73 +102,97 @@ void psmo_minmax(const float* tris, int n, const float M[16], float mn[4], float
     for (int c = 0; c < 4; c++) { mn[c] = mn[c] - 0.00001f; mx[c] = mx[c] + 0.00001f; }
 }
 
-/* general 4x4 inverse in double by cofactors (what glm::inverse does structurally) */
-static void inverse4d(const double* m, double* o) {
-    /* m row-major */
-    double a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3];
-    double a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
-    double a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11];
-    double a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
-    double b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10;
-    double b02 = a00 * a13 - a03 * a10, b03 = a01 * a12 - a02 * a11;
-    double b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
-    double b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30;
-    double b08 = a20 * a33 - a23 * a30, b09 = a21 * a32 - a22 * a31;
-    double b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
-    double det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
-    double id = 1.0 / det;
-    o[0] = (a11 * b11 - a12 * b10 + a13 * b09) * id;
-    o[1] = (-a01 * b11 + a02 * b10 - a03 * b09) * id;
-    o[2] = (a31 * b05 - a32 * b04 + a33 * b03) * id;
-    o[3] = (-a21 * b05 + a22 * b04 - a23 * b03) * id;
-    o[4] = (-a10 * b11 + a12 * b08 - a13 * b07) * id;
-    o[5] = (a00 * b11 - a02 * b08 + a03 * b07) * id;
-    o[6] = (-a30 * b05 + a32 * b02 - a33 * b01) * id;
-    o[7] = (a20 * b05 - a22 * b02 + a23 * b01) * id;
-    o[8] = (a10 * b10 - a11 * b08 + a13 * b06) * id;
-    o[9] = (-a00 * b10 + a01 * b08 - a03 * b06) * id;
-    o[10] = (a30 * b04 - a31 * b02 + a33 * b00) * id;
-    o[11] = (-a20 * b04 + a21 * b02 - a23 * b00) * id;
-    o[12] = (-a10 * b09 + a11 * b07 - a12 * b06) * id;
-    o[13] = (a00 * b09 - a01 * b07 + a02 * b06) * id;
-    o[14] = (-a30 * b03 + a31 * b01 - a32 * b00) * id;
-    o[15] = (a20 * b03 - a21 * b01 + a22 * b00) * id;
+/* ---- the host formulas of TriangleHierarchy.inl:226-232,257-267 with glm's own operation order --------------------
+ * g-matrices are glm's dmat4 in memory: column-major, g[4*c + r]. Every function below restates the arithmetic of the
+ * glm the reference vendors (detail/func_matrix.inl compute_inverse<4,4>, detail/type_mat4x4.inl operator*,
+ * gtc/matrix_transform.inl translate / scale), operation by operation, so signs of zeros come out the same too;
+ * pinned against that glm by tests/golden/glm_host_formulas.npz. */
+static void glm_mul4d(const double* a, const double* b, double* o) { /* Result[c] = A0*B[c][0] + A1*B[c][1] + A2*B[c][2] + A3*B[c][3] */
+    double t[16];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            t[4 * c + r] = ((a[0 + r] * b[4 * c + 0] + a[4 + r] * b[4 * c + 1]) + a[8 + r] * b[4 * c + 2]) + a[12 + r] * b[4 * c + 3];
+    memcpy(o, t, sizeof(t));
 }
-static void mul4d(const double* a, const double* b, double* o) {
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = 0.0;
-            for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
-            o[4 * i + j] = s;
-        }
+static void glm_inverse4d(const double* m, double* o) {
+#define G(c, r) m[4 * (c) + (r)]
+    double c00 = G(2,2) * G(3,3) - G(3,2) * G(2,3), c02 = G(1,2) * G(3,3) - G(3,2) * G(1,3), c03 = G(1,2) * G(2,3) - G(2,2) * G(1,3);
+    double c04 = G(2,1) * G(3,3) - G(3,1) * G(2,3), c06 = G(1,1) * G(3,3) - G(3,1) * G(1,3), c07 = G(1,1) * G(2,3) - G(2,1) * G(1,3);
+    double c08 = G(2,1) * G(3,2) - G(3,1) * G(2,2), c10 = G(1,1) * G(3,2) - G(3,1) * G(1,2), c11 = G(1,1) * G(2,2) - G(2,1) * G(1,2);
+    double c12 = G(2,0) * G(3,3) - G(3,0) * G(2,3), c14 = G(1,0) * G(3,3) - G(3,0) * G(1,3), c15 = G(1,0) * G(2,3) - G(2,0) * G(1,3);
+    double c16 = G(2,0) * G(3,2) - G(3,0) * G(2,2), c18 = G(1,0) * G(3,2) - G(3,0) * G(1,2), c19 = G(1,0) * G(2,2) - G(2,0) * G(1,2);
+    double c20 = G(2,0) * G(3,1) - G(3,0) * G(2,1), c22 = G(1,0) * G(3,1) - G(3,0) * G(1,1), c23 = G(1,0) * G(2,1) - G(2,0) * G(1,1);
+    const double f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+    const double f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+    const double v0[4] = {G(1,0), G(0,0), G(0,0), G(0,0)}, v1[4] = {G(1,1), G(0,1), G(0,1), G(0,1)};
+    const double v2[4] = {G(1,2), G(0,2), G(0,2), G(0,2)}, v3[4] = {G(1,3), G(0,3), G(0,3), G(0,3)};
+    const double sa[4] = {1, -1, 1, -1}, sb[4] = {-1, 1, -1, 1};
+    double inv[16];
+    for (int k = 0; k < 4; k++) {
+        inv[0 + k] = ((v1[k] * f0[k] - v2[k] * f1[k]) + v3[k] * f2[k]) * sa[k];
+        inv[4 + k] = ((v0[k] * f0[k] - v2[k] * f3[k]) + v3[k] * f4[k]) * sb[k];
+        inv[8 + k] = ((v0[k] * f1[k] - v1[k] * f3[k]) + v3[k] * f5[k]) * sa[k];
+        inv[12 + k] = ((v0[k] * f2[k] - v1[k] * f4[k]) + v2[k] * f5[k]) * sb[k];
+    }
+    double d0 = G(0,0) * inv[0], d1 = G(0,1) * inv[4], d2 = G(0,2) * inv[8], d3 = G(0,3) * inv[12];
+    double one_over_det = 1.0 / ((d0 + d1) + (d2 + d3));
+    for (int i = 0; i < 16; i++) o[i] = inv[i] * one_over_det;
+#undef G
+}
+static void glm_identity4d(double* g) {
+    for (int i = 0; i < 16; i++) g[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+static void glm_from_rowmajor(const double* r, double* g) {
+    for (int c = 0; c < 4; c++) for (int q = 0; q < 4; q++) g[4 * c + q] = r[4 * q + c];
+}
+/* float(g) read back row-major: what value_ptr(transpose(mat4(g))) uploads */
+static void glm_to_rowmajor_f(const double* g, float* M) {
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) M[4 * r + c] = (float)g[4 * c + r];
 }
 
-/* first-pass transform: inverse(optimization), TriangleHierarchy.inl:226-232 */
+/* first-pass transform, TriangleHierarchy.inl:226-232: dmat4 mat(1.0); mat *= inverse(optimization) */
 void psmo_inverse_opt(const double opt[16], float M[16]) {
-    double inv[16];
-    inverse4d(opt, inv);
-    for (int i = 0; i < 16; i++) M[i] = (float)inv[i];
+    double go[16], gi[16], mat[16];
+    glm_from_rowmajor(opt, go);
+    glm_inverse4d(go, gi);
+    glm_identity4d(mat);
+    glm_mul4d(mat, gi, mat);
+    glm_to_rowmajor_f(mat, M);
 }
 
 /* TriangleHierarchy.inl:257-267: scale = mx-mn, offset = mn (float);
- * mat = inverse(translate(offset) * scale(scale)) * inverse(opt) in double, cast to float. */
+ * mat(1.0); mat *= inverse(translate(dvec3(offset)) * scale(dvec3(scale))); mat *= inverse(dmat4(opt)); cast to float.
+ * transformInv = inverse(mat4(mat)) in float (:266): computed here in double from the float matrix -- it is not read
+ * by any kernel of the path. */
 void psmo_fit_transform(const float mn[4], const float mx[4], const double opt[16], float M[16],
                         float Minv[16]) {
     float scale[3], offset[3];
     for (int c = 0; c < 3; c++) { scale[c] = mx[c] - mn[c]; offset[c] = mn[c]; }
-    double TS[16] = {(double)scale[0], 0, 0, (double)offset[0],
-                     0, (double)scale[1], 0, (double)offset[1],
-                     0, 0, (double)scale[2], (double)offset[2],
-                     0, 0, 0, 1};
-    double iTS[16], iopt[16], mat[16], imat[16];
-    inverse4d(TS, iTS);
-    inverse4d(opt, iopt);
-    mul4d(iTS, iopt, mat);
-    for (int i = 0; i < 16; i++) M[i] = (float)mat[i];
-    double Md[16];
-    for (int i = 0; i < 16; i++) Md[i] = (double)M[i];
-    inverse4d(Md, imat);
-    for (int i = 0; i < 16; i++) Minv[i] = (float)imat[i];
+    double I[16], T[16], S[16], TS[16], iTS[16], go[16], iopt[16], mat[16];
+    glm_identity4d(I);
+    /* translate(m, v): Result = m; Result[3] = m[0]*v[0] + m[1]*v[1] + m[2]*v[2] + m[3] */
+    memcpy(T, I, sizeof(T));
+    for (int r = 0; r < 4; r++)
+        T[12 + r] = ((I[0 + r] * (double)offset[0] + I[4 + r] * (double)offset[1]) + I[8 + r] * (double)offset[2]) + I[12 + r];
+    /* scale(m, v): Result[i] = m[i] * v[i], Result[3] = m[3] */
+    for (int r = 0; r < 4; r++) {
+        S[0 + r] = I[0 + r] * (double)scale[0];
+        S[4 + r] = I[4 + r] * (double)scale[1];
+        S[8 + r] = I[8 + r] * (double)scale[2];
+        S[12 + r] = I[12 + r];
+    }
+    glm_mul4d(T, S, TS);
+    glm_inverse4d(TS, iTS);
+    glm_from_rowmajor(opt, go);
+    glm_inverse4d(go, iopt);
+    glm_identity4d(mat);
+    glm_mul4d(mat, iTS, mat);
+    glm_mul4d(mat, iopt, mat);
+    glm_to_rowmajor_f(mat, M);
+    double gm[16], gim[16];
+    for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) gm[4 * c + r] = (double)M[4 * r + c];
+    glm_inverse4d(gm, gim);
+    glm_to_rowmajor_f(gim, Minv);
 }
 
 /* hlbvh/aabbmaker.comp:142-232 at splitLimit = 0 (:139-140).

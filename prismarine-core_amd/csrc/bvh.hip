@@ -36,9 +36,10 @@ PSM_D float ordered_to_float(int32_t i) { return u2f((uint32_t)(i >= 0 ? i : (i 
 
 __global__ void bvh_init_bounds(uint32_t* sm, const double* opt) {
     if (threadIdx.x == 0) {
-        double inv[16];
-        inverse4d(opt, inv);  // TriangleHierarchy.inl:226-232
-        for (int i = 0; i < 16; i++) sm[SM_M0 + i] = f2u((float)inv[i]);
+        double mat[16];
+        gm_first_pass(opt, mat);  // TriangleHierarchy.inl:226-232
+        for (int r = 0; r < 4; r++)
+            for (int cc = 0; cc < 4; cc++) sm[SM_M0 + 4 * r + cc] = f2u((float)mat[4 * cc + r]);
         for (int c = 0; c < 4; c++) {
             sm[SM_BOUNDS + c] = (uint32_t)float_to_ordered(100000.f);       // minmax.comp:56
             sm[SM_BOUNDS + 4 + c] = (uint32_t)float_to_ordered(-100000.f);
@@ -101,13 +102,10 @@ __global__ void bvh_fit_transform(uint32_t* sm, const double* opt) {
     }
     float scale[3], offset[3];
     for (int c = 0; c < 3; c++) { scale[c] = mx[c] - mn[c]; offset[c] = mn[c]; }
-    double TS[16] = {(double)scale[0], 0, 0, (double)offset[0], 0, (double)scale[1], 0, (double)offset[1],
-                     0, 0, (double)scale[2], (double)offset[2], 0, 0, 0, 1};
-    double iTS[16], iopt[16], mat[16];
-    inverse4d(TS, iTS);
-    inverse4d(opt, iopt);
-    mul4d(iTS, iopt, mat);
-    for (int i = 0; i < 16; i++) sm[SM_M + i] = f2u((float)mat[i]);
+    double mat[16];
+    gm_fit(scale, offset, opt, mat);
+    for (int r = 0; r < 4; r++)
+        for (int cc = 0; cc < 4; cc++) sm[SM_M + 4 * r + cc] = f2u((float)mat[4 * cc + r]);
 }
 
 // traversal layout: v0, e1 = v1 - v0, e2 = v2 - v0 (the first three operations of

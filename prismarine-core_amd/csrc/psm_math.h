@@ -228,44 +228,74 @@ PSM_HD float pasin(float x) {
     return patan2(c, sqrtf((1.0f - c) * (1.0f + c)));
 }
 
-// ---- double 4x4 helpers for the fit transform (TriangleHierarchy.inl:257-267) ---------------
-PSM_HD void inverse4d(const double* m, double* o) {
-    double a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3];
-    double a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
-    double a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11];
-    double a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
-    double b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10;
-    double b02 = a00 * a13 - a03 * a10, b03 = a01 * a12 - a02 * a11;
-    double b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
-    double b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30;
-    double b08 = a20 * a33 - a23 * a30, b09 = a21 * a32 - a22 * a31;
-    double b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
-    double det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
-    double id = 1.0 / det;
-    o[0] = (a11 * b11 - a12 * b10 + a13 * b09) * id;
-    o[1] = (-a01 * b11 + a02 * b10 - a03 * b09) * id;
-    o[2] = (a31 * b05 - a32 * b04 + a33 * b03) * id;
-    o[3] = (-a21 * b05 + a22 * b04 - a23 * b03) * id;
-    o[4] = (-a10 * b11 + a12 * b08 - a13 * b07) * id;
-    o[5] = (a00 * b11 - a02 * b08 + a03 * b07) * id;
-    o[6] = (-a30 * b05 + a32 * b02 - a33 * b01) * id;
-    o[7] = (a20 * b05 - a22 * b02 + a23 * b01) * id;
-    o[8] = (a10 * b10 - a11 * b08 + a13 * b06) * id;
-    o[9] = (-a00 * b10 + a01 * b08 - a03 * b06) * id;
-    o[10] = (a30 * b04 - a31 * b02 + a33 * b00) * id;
-    o[11] = (-a20 * b04 + a21 * b02 - a23 * b00) * id;
-    o[12] = (-a10 * b09 + a11 * b07 - a12 * b06) * id;
-    o[13] = (a00 * b09 - a01 * b07 + a02 * b06) * id;
-    o[14] = (-a30 * b03 + a31 * b01 - a32 * b00) * id;
-    o[15] = (a20 * b03 - a21 * b01 + a22 * b00) * id;
+// ---- double 4x4 helpers for the fit transform (TriangleHierarchy.inl:226-232,257-267) ----------------------
+// The reference evaluates these formulas on the host with glm in double. gmat = glm's dmat4 memory (column-major,
+// g[4c + r]); gm_mul / gm_inverse follow glm's operation order (type_mat4x4.inl operator*, func_matrix.inl
+// compute_inverse<4,4>) so the float matrix the kernels read is bit for bit the one the reference uploads.
+PSM_HD void gm_mul(const double* a, const double* b, double* o) {
+    double t[16];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            t[4 * c + r] = ((a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1]) + a[8 + r] * b[4 * c + 2]) + a[12 + r] * b[4 * c + 3];
+    for (int i = 0; i < 16; i++) o[i] = t[i];
 }
-PSM_HD void mul4d(const double* a, const double* b, double* o) {
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = 0.0;
-            for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
-            o[4 * i + j] = s;
-        }
+PSM_HD void gm_inverse(const double* m, double* o) {
+    double c00 = m[10] * m[15] - m[14] * m[11], c02 = m[6] * m[15] - m[14] * m[7], c03 = m[6] * m[11] - m[10] * m[7];
+    double c04 = m[9] * m[15] - m[13] * m[11], c06 = m[5] * m[15] - m[13] * m[7], c07 = m[5] * m[11] - m[9] * m[7];
+    double c08 = m[9] * m[14] - m[13] * m[10], c10 = m[5] * m[14] - m[13] * m[6], c11 = m[5] * m[10] - m[9] * m[6];
+    double c12 = m[8] * m[15] - m[12] * m[11], c14 = m[4] * m[15] - m[12] * m[7], c15 = m[4] * m[11] - m[8] * m[7];
+    double c16 = m[8] * m[14] - m[12] * m[10], c18 = m[4] * m[14] - m[12] * m[6], c19 = m[4] * m[10] - m[8] * m[6];
+    double c20 = m[8] * m[13] - m[12] * m[9], c22 = m[4] * m[13] - m[12] * m[5], c23 = m[4] * m[9] - m[8] * m[5];
+    const double f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+    const double f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+    const double v0[4] = {m[4], m[0], m[0], m[0]}, v1[4] = {m[5], m[1], m[1], m[1]};
+    const double v2[4] = {m[6], m[2], m[2], m[2]}, v3[4] = {m[7], m[3], m[3], m[3]};
+    double inv[16];
+    for (int k = 0; k < 4; k++) {
+        const double sa = (k & 1) ? -1.0 : 1.0, sb = -sa;
+        inv[k] = ((v1[k] * f0[k] - v2[k] * f1[k]) + v3[k] * f2[k]) * sa;
+        inv[4 + k] = ((v0[k] * f0[k] - v2[k] * f3[k]) + v3[k] * f4[k]) * sb;
+        inv[8 + k] = ((v0[k] * f1[k] - v1[k] * f3[k]) + v3[k] * f5[k]) * sa;
+        inv[12 + k] = ((v0[k] * f2[k] - v1[k] * f4[k]) + v2[k] * f5[k]) * sb;
+    }
+    double one_over_det = 1.0 / ((m[0] * inv[0] + m[1] * inv[4]) + (m[2] * inv[8] + m[3] * inv[12]));
+    for (int i = 0; i < 16; i++) o[i] = inv[i] * one_over_det;
+}
+PSM_HD void gm_identity(double* g) {
+    for (int i = 0; i < 16; i++) g[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+// row-major double[16] (the C ABI's convention) -> glm memory, and glm memory -> the float matrix uploaded row-major
+PSM_HD void gm_from_rowmajor(const double* r, double* g) {
+    for (int c = 0; c < 4; c++) for (int q = 0; q < 4; q++) g[4 * c + q] = r[4 * q + c];
+}
+// dmat4 mat(1.0); mat *= inverse(optimization)   (TriangleHierarchy.inl:229-230)
+PSM_HD void gm_first_pass(const double* opt_rowmajor, double* mat) {
+    double go[16], gi[16];
+    gm_from_rowmajor(opt_rowmajor, go);
+    gm_inverse(go, gi);
+    gm_identity(mat);
+    gm_mul(mat, gi, mat);
+}
+// dmat4 mat(1.0); mat *= inverse(translate(dvec3(offset)) * scale(dvec3(scale))); mat *= inverse(dmat4(optimization))
+PSM_HD void gm_fit(const float* scale, const float* offset, const double* opt_rowmajor, double* mat) {
+    double I[16], T[16], S[16], TS[16], iTS[16], go[16], iopt[16];
+    gm_identity(I);
+    for (int i = 0; i < 16; i++) T[i] = I[i];
+    for (int r = 0; r < 4; r++)  // translate(m, v): Result[3] = m[0] v0 + m[1] v1 + m[2] v2 + m[3]
+        T[12 + r] = ((I[r] * (double)offset[0] + I[4 + r] * (double)offset[1]) + I[8 + r] * (double)offset[2]) + I[12 + r];
+    for (int r = 0; r < 4; r++) {  // scale(m, v): Result[i] = m[i] v[i]
+        S[r] = I[r] * (double)scale[0];
+        S[4 + r] = I[4 + r] * (double)scale[1];
+        S[8 + r] = I[8 + r] * (double)scale[2];
+        S[12 + r] = I[12 + r];
+    }
+    gm_mul(T, S, TS);
+    gm_inverse(TS, iTS);
+    gm_from_rowmajor(opt_rowmajor, go);
+    gm_inverse(go, iopt);
+    gm_identity(mat);
+    gm_mul(mat, iTS, mat);
+    gm_mul(mat, iopt, mat);
 }
 
 }  // namespace psm

@@ -477,37 +477,88 @@ def textured(scene, scale=1.5):
 # camera matrices (Pipeline.inl:298-312: perspective(pi/3, aspect, 0.001, 1000) x lookAt)
 # ---------------------------------------------------------------------------
 
+# The reference computes its camera matrices on the host with glm in single precision (Pipeline.inl:283-284,298-312):
+# lookAt, perspective and inverse below restate glm's operation order (gtc/matrix_transform.inl lookAtRH /
+# perspectiveRH with the -1..1 depth range, detail/func_matrix.inl compute_inverse<4,4>) in float32, so the
+# matrices are bit-for-bit the ones the reference would upload (pinned by tests/golden/glm_host_formulas.npz,
+# generated with the reference's vendored glm).
+_F = np.float32
+
+
+def _dot3(a, b):
+    return _F(_F(_F(a[0] * b[0]) + _F(a[1] * b[1])) + _F(a[2] * b[2]))
+
+
+def _cross3(x, y):
+    return np.array([_F(_F(x[1] * y[2]) - _F(y[1] * x[2])), _F(_F(x[2] * y[0]) - _F(y[2] * x[0])),
+                     _F(_F(x[0] * y[1]) - _F(y[0] * x[1]))], np.float32)
+
+
+def _normalize3(v):
+    inv = _F(_F(1.0) / _F(np.sqrt(_dot3(v, v))))
+    return np.array([_F(v[0] * inv), _F(v[1] * inv), _F(v[2] * inv)], np.float32)
+
+
 def look_at(eye, center, up=(0.0, 1.0, 0.0)):
+    """glm::lookAt (right-handed) as the row-major matrix M with M @ (p, 1) = view-space p."""
     eye, center, up = (np.asarray(v, np.float32) for v in (eye, center, up))
-    f = center - eye
-    f = f / np.float32(np.sqrt((f * f).sum()))
-    s = np.cross(f, up).astype(np.float32)
-    s = s / np.float32(np.sqrt((s * s).sum()))
-    u = np.cross(s, f).astype(np.float32)
+    f = _normalize3((center - eye).astype(np.float32))
+    s = _normalize3(_cross3(f, up))
+    u = _cross3(s, f)
     m = np.eye(4, dtype=np.float32)
     m[0, :3], m[1, :3], m[2, :3] = s, u, -f
-    m[0, 3], m[1, 3], m[2, 3] = -np.dot(s, eye), -np.dot(u, eye), np.dot(f, eye)
+    m[0, 3], m[1, 3], m[2, 3] = -_dot3(s, eye), -_dot3(u, eye), _dot3(f, eye)
     return m
 
 
 def perspective(fovy, aspect, znear, zfar):
-    t = np.float32(math.tan(fovy / 2.0))
+    """glm::perspective (right-handed, depth -1..1), row-major, all in float32 as glm evaluates it."""
+    fovy, aspect, znear, zfar = _F(fovy), _F(aspect), _F(znear), _F(zfar)
+    t = _F(math.tan(float(_F(fovy / _F(2.0)))))  # std::tan(float): correctly rounded on the platforms checked
     m = np.zeros((4, 4), np.float32)
-    m[0, 0] = 1.0 / (aspect * t)
-    m[1, 1] = 1.0 / t
-    m[2, 2] = -(zfar + znear) / (zfar - znear)
+    m[0, 0] = _F(_F(1.0) / _F(aspect * t))
+    m[1, 1] = _F(_F(1.0) / t)
+    m[2, 2] = -_F(_F(zfar + znear) / _F(zfar - znear))
     m[3, 2] = -1.0
-    m[2, 3] = -(2.0 * zfar * znear) / (zfar - znear)
+    m[2, 3] = -_F(_F(_F(_F(2.0) * zfar) * znear) / _F(zfar - znear))
     return m
 
 
+def inverse4(mat):
+    """glm::inverse(mat4) in float32 with glm's operation order; `mat` and the result are row-major."""
+    m = np.ascontiguousarray(np.asarray(mat, np.float32).T)  # m[c][r] = glm's column-major indexing
+
+    def d(a, b, c, e):
+        return _F(_F(a * b) - _F(c * e))
+    c00 = d(m[2][2], m[3][3], m[3][2], m[2][3]); c02 = d(m[1][2], m[3][3], m[3][2], m[1][3]); c03 = d(m[1][2], m[2][3], m[2][2], m[1][3])
+    c04 = d(m[2][1], m[3][3], m[3][1], m[2][3]); c06 = d(m[1][1], m[3][3], m[3][1], m[1][3]); c07 = d(m[1][1], m[2][3], m[2][1], m[1][3])
+    c08 = d(m[2][1], m[3][2], m[3][1], m[2][2]); c10 = d(m[1][1], m[3][2], m[3][1], m[1][2]); c11 = d(m[1][1], m[2][2], m[2][1], m[1][2])
+    c12 = d(m[2][0], m[3][3], m[3][0], m[2][3]); c14 = d(m[1][0], m[3][3], m[3][0], m[1][3]); c15 = d(m[1][0], m[2][3], m[2][0], m[1][3])
+    c16 = d(m[2][0], m[3][2], m[3][0], m[2][2]); c18 = d(m[1][0], m[3][2], m[3][0], m[1][2]); c19 = d(m[1][0], m[2][2], m[2][0], m[1][2])
+    c20 = d(m[2][0], m[3][1], m[3][0], m[2][1]); c22 = d(m[1][0], m[3][1], m[3][0], m[1][1]); c23 = d(m[1][0], m[2][1], m[2][0], m[1][1])
+    f0 = np.array([c00, c00, c02, c03], np.float32); f1 = np.array([c04, c04, c06, c07], np.float32)
+    f2 = np.array([c08, c08, c10, c11], np.float32); f3 = np.array([c12, c12, c14, c15], np.float32)
+    f4 = np.array([c16, c16, c18, c19], np.float32); f5 = np.array([c20, c20, c22, c23], np.float32)
+    v0 = np.array([m[1][0], m[0][0], m[0][0], m[0][0]], np.float32); v1 = np.array([m[1][1], m[0][1], m[0][1], m[0][1]], np.float32)
+    v2 = np.array([m[1][2], m[0][2], m[0][2], m[0][2]], np.float32); v3 = np.array([m[1][3], m[0][3], m[0][3], m[0][3]], np.float32)
+    i0 = (v1 * f0 - v2 * f1) + v3 * f2   # numpy float32 arrays: every product and sum rounds to float32, left to right
+    i1 = (v0 * f0 - v2 * f3) + v3 * f4
+    i2 = (v0 * f1 - v1 * f3) + v3 * f5
+    i3 = (v0 * f2 - v1 * f4) + v2 * f5
+    sa = np.array([1, -1, 1, -1], np.float32); sb = np.array([-1, 1, -1, 1], np.float32)
+    inv = np.stack([i0 * sa, i1 * sb, i2 * sa, i3 * sb]).astype(np.float32)  # inv[c][r]
+    row0 = np.array([inv[0][0], inv[1][0], inv[2][0], inv[3][0]], np.float32)
+    dot0 = (m[0] * row0).astype(np.float32)
+    det = _F(_F(dot0[0] + dot0[1]) + _F(dot0[2] + dot0[3]))
+    return np.ascontiguousarray((inv * _F(_F(1.0) / det)).astype(np.float32).T)
+
+
 def camera_matrices(eye, view, width, height):
-    """Row-major (camInv, projInv) = inverse(lookAt), inverse(perspective) as float32[16]."""
+    """Row-major (camInv, projInv) = inverse(lookAt), inverse(perspective) as float32[16]: cameraUniformData.camInv /
+    projInv as Pipeline::camera(eye, view) uploads them (Pipeline.inl:283-284,298-312)."""
     cam = look_at(eye, view)
-    proj = perspective(math.pi / 3.0, float(width) / float(height), 0.001, 1000.0)
-    cam_inv = np.linalg.inv(cam.astype(np.float64)).astype(np.float32)
-    proj_inv = np.linalg.inv(proj.astype(np.float64)).astype(np.float32)
-    return np.ascontiguousarray(cam_inv.reshape(16)), np.ascontiguousarray(proj_inv.reshape(16))
+    proj = perspective(_F(math.pi) / _F(3.0), _F(width) / _F(height), 0.001, 1000.0)
+    return np.ascontiguousarray(inverse4(cam).reshape(16)), np.ascontiguousarray(inverse4(proj).reshape(16))
 
 
 # ---------------------------------------------------------------------------
