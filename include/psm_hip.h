@@ -69,6 +69,14 @@ int psm_buf_ptr(psm_ctx* ctx, uint32_t handle, void** dev_ptr, size_t* bytes);
  * ------------------------------------------------------------------------------------------- */
 int psm_sort_u64_u32(psm_ctx* ctx, uint32_t keys_handle, uint32_t vals_handle, uint32_t n);
 int psm_sort_u64_u32_dev(psm_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, size_t n);
+/* Which implementation the sort (and the hierarchy build's sort stage) runs. 0 (default) = per pass a histogram, a
+ * scan (pfx-work.comp:34-70 as its own launch) and a scatter kernel: 256 B/key, 24 launches. 1 = ONE histogram sweep
+ * over the keys for all eight digits (histogram.comp:80-116 once instead of per pass) + one scatter launch per pass
+ * that finds its tile's bases by decoupled look-back: 200 B/key, 10 launches -- measured slower on MI355X at every
+ * size, kept selectable and under the same parity tests. Results are identical. A look-back spin that
+ * times out is reported as PSM_ERR_STATE by the next synchronising call on the context (psm_ctx_sync,
+ * psm_buf_download, psm_bvh_get_info, psm_bvh_download): the sort never hangs silently. */
+int psm_sort_set_algorithm(psm_ctx* ctx, int algorithm);
 
 /* ---------------------------------------------------------------------------------------------
  * psm::TriangleHierarchy, Include/Prismarine/TriangleHierarchy.{hpp,inl}

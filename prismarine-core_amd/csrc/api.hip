@@ -171,7 +171,7 @@ int psm_ctx_copy_bandwidth(psm_ctx* c, size_t bytes, int reps, double* gb_per_s)
 int psm_ctx_sync(psm_ctx* c) {
     if (!c) return PSM_ERR_INVALID;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
-    return PSM_OK;
+    return sort_check(c);  // the radix sort's look-back raises a device word instead of hanging
 }
 void* psm_ctx_stream(psm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 const char* psm_last_error(psm_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -219,7 +219,7 @@ int psm_buf_download(psm_ctx* c, uint32_t h, size_t offset, void* dst, size_t by
     if (!b || !dst || offset + bytes > b->bytes) return c ? set_err(c, PSM_ERR_INVALID, "psm_buf_download: bad handle or range") : PSM_ERR_INVALID;
     PSM_HIP(c, hipMemcpyAsync(dst, (char*)b->ptr + offset, bytes, hipMemcpyDeviceToHost, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
-    return PSM_OK;
+    return sort_check(c);
 }
 int psm_buf_ptr(psm_ctx* c, uint32_t h, void** p, size_t* bytes) {
     Buf* b = get_buf(c, h);
@@ -230,6 +230,11 @@ int psm_buf_ptr(psm_ctx* c, uint32_t h, void** p, size_t* bytes) {
 }
 
 // ---- sort -----------------------------------------------------------------------------------------
+int psm_sort_set_algorithm(psm_ctx* c, int algorithm) {
+    if (!c || algorithm < 0 || algorithm > 1) return PSM_ERR_INVALID;
+    c->sort_algorithm = algorithm;
+    return PSM_OK;
+}
 int psm_sort_u64_u32_dev(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n) {
     if (!c || (n && (!d_keys || !d_vals))) return PSM_ERR_INVALID;
     (void)hipSetDevice(c->device);
@@ -425,6 +430,8 @@ int psm_bvh_get_info(psm_bvh* b, psm_bvh_info* info) {
     uint32_t sm[SM_WORDS];
     PSM_HIP(c, hipMemcpyAsync(sm, b->d_small, sizeof(sm), hipMemcpyDeviceToHost, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
+    int se = sort_check(c);
+    if (se != PSM_OK) return se;
     info->triangle_count = b->tri_count;
     info->leaf_count = sm[SM_COUNT];
     info->root = (int32_t)sm[SM_ROOT];
@@ -458,7 +465,7 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
     if (bytes > b->cap * elem) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_download: too many bytes");
     PSM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
-    return PSM_OK;
+    return sort_check(c);
 }
 
 // ---- Pipeline -----------------------------------------------------------------------------------

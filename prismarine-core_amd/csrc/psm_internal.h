@@ -87,6 +87,8 @@ struct psm_ctx {
     uint32_t* sort_vals_tmp = nullptr;
     uint32_t* sort_hist = nullptr;
     size_t sort_cap = 0, sort_hist_cap = 0;
+    int sort_algorithm = 0;             // 0: histogram / scan / scatter kernels per pass (default: measured faster); 1: one-sweep
+    uint32_t* sort_error_word = nullptr; // device word the look-back raises on a spin timeout
 };
 
 struct psm_bvh {
@@ -194,6 +196,7 @@ struct TimedScope {
 
 // kernels (launch wrappers) ------------------------------------------------------------------------
 int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n);
+int sort_check(psm_ctx* c);
 int launch_bvh_bounds(psm_bvh* b);
 int launch_bvh_morton(psm_bvh* b);
 int launch_bvh_emit(psm_bvh* b);

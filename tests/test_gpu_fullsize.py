@@ -10,14 +10,20 @@ from util import bits, box_union, canonical_nodes
 pytestmark = pytest.mark.gpu
 
 
-def test_sort_10m_keys_properties(psm, ctx):
-    """C5-scale key count (reference cap: 2 Mi keys, Radix.hpp:34-35)."""
+@pytest.mark.parametrize("algo", [0, 1], ids=["three-kernel", "onesweep"])
+def test_sort_10m_keys_properties(psm, ctx, algo):
+    """C5-scale key count (reference cap: 2 Mi keys, Radix.hpp:34-35), both sort implementations."""
     n = 10_000_019
     rng = np.random.RandomState(5)
     keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
     keys[rng.randint(0, n, n // 4)] &= np.uint64(0xFFFFF)  # many ties
     vals = np.arange(n, dtype=np.uint32)
-    gk, gv = psm.RadixSort(ctx).sort_arrays(keys, vals)
+    rs = psm.RadixSort(ctx)
+    rs.setAlgorithm(algo)
+    try:
+        gk, gv = rs.sort_arrays(keys, vals)
+    finally:
+        rs.setAlgorithm(0)
     assert (gk[1:] >= gk[:-1]).all()                                  # sorted
     ties = gk[1:] == gk[:-1]
     assert (gv[1:][ties] > gv[:-1][ties]).all()                      # stable

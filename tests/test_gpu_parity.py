@@ -34,15 +34,23 @@ def _scene(scenes, name):
 
 
 # ---------------------------------------------------------------------------- sort
-@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 4097, 100003, 2 ** 21 + 77])
-def test_sort_matches_oracle(psm, ctx, oracle, n):
+@pytest.mark.parametrize("algo", [0, 1], ids=["three-kernel", "onesweep"])
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 1024, 1025, 4097, 100003, 2 ** 21 + 77])
+def test_sort_matches_oracle(psm, ctx, oracle, n, algo):
+    """Both sort implementations (psm_sort_set_algorithm): one histogram sweep + look-back scatter, and the
+    histogram / scan / scatter kernels per pass."""
     rng = np.random.RandomState(n + 1)
     keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
     if n > 10:
         keys[rng.randint(0, n, n // 3)] = keys[rng.randint(0, n, n // 3)]  # ties: stability matters
         keys[: n // 8] &= np.uint64(0xFFFF)                                # short keys
     vals = np.arange(n, dtype=np.uint32)
-    gk, gv = psm.RadixSort(ctx).sort_arrays(keys, vals)
+    rs = psm.RadixSort(ctx)
+    rs.setAlgorithm(algo)
+    try:
+        gk, gv = rs.sort_arrays(keys, vals)
+    finally:
+        rs.setAlgorithm(0)
     ok, ov = oracle.radix_sort(keys, vals.astype(np.int32))
     assert np.array_equal(gk, ok)
     assert np.array_equal(gv, ov.astype(np.uint32))
