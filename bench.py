@@ -53,9 +53,11 @@ def parse():
     ap.add_argument("--emulate-tile", default=None, help="R/W: render only the tile of rank R of W on one GPU, no communication (Amdahl study)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path even on 1 GPU (rehearsal)")
     ap.add_argument("--no-rebuild", action="store_true", help="study only, not the headline workload: build the BVH once")
-    ap.add_argument("--lanes", type=int, default=4,
+    ap.add_argument("--lanes", type=int, default=0,
                     help="frames in flight per GPU (psm_lanes_render): each on its own HIP stream, folded into the "
-                         "accumulating image in frame order; 1 = one frame after another")
+                         "accumulating image in frame order; 1 = one frame after another; 0 (default) = 4 on one GPU, "
+                         "8 / 12 / 16 per GPU on 2 / 4 / 8 GPUs (a tile's launches are small and latency-bound: more "
+                         "frames in flight fill the chip, measured with --emulate-tile)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous check only: every rank builds its communicator (gloo, no GPU), proves the group works "
                          "with one all-reduce, prints one line and exits")
@@ -75,12 +77,18 @@ class Renderer:
         self.scene = scene
         self.pdist = importlib.import_module("prismarine-core_amd.dist")
         stream = None
-        if dist.active and dist.backend == "nccl":
-            # run the kernels on torch's stream: RCCL calls and kernels are ordered without host syncs
+        self.native = None
+        # the C ABI's own RCCL communicator carries the collectives unless PSM_DIST_NATIVE=0 (or the one-GPU rehearsal of
+        # another rank's tile, whose tile is not this rank's)
+        use_native = (dist.active and dist.backend == "nccl" and os.environ.get("PSM_DIST_NATIVE", "1") != "0" and
+                      not (args.emulate_tile and dist.world == 1))
+        if dist.active and dist.backend == "nccl" and not use_native:
+            # torch.distributed collectives: run the kernels on torch's stream, so RCCL calls and kernels are ordered
+            # without host syncs. (Default: the C ABI's own communicator, psm_dist_*, ordered by events.)
             stream = dist.torch.cuda.current_stream().cuda_stream
             dist.same_stream = True
         w, h = args.width, args.height
-        self.lanes = max(1, args.lanes)
+        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else 8 if dist.world == 2 else 12 if dist.world <= 4 else 16)
         self.lane_streams = None
         streams = None
         if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
@@ -116,7 +124,9 @@ class Renderer:
             self.batch.each(lambda r: r.setTileInterleaved(r_, w_))
             dist.initial_total = self.rt.tile_texels()
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
-        if dist.active:
+        if use_native:
+            self.native = dist.attach_native(self.ctx)  # collective: every rank creates its RCCL communicator here
+        if dist.active and self.native is None:
             torch = dist.torch
             gdev = torch.device("cuda", dist.device_index)
             self.per = self.pdist.interleaved_texels(0, dist.world, w, h) * 4  # rank 0 owns the most bands
@@ -162,6 +172,11 @@ class Renderer:
                                             initial_totals=[dist.initial_total] * len(lanes))
             traced += sum(ln.ctx.stats().rays_traced - b for ln, b in zip(lanes, before))
             for s, ln in enumerate(lanes):  # frame order
+                if self.native is not None:  # ONE collective per frame, in the C ABI (psm_dist_gather_tiles)
+                    self.native.gather_tiles(ln.rays)
+                    if dist.rank == 0:
+                        batch.fold_one(ln)
+                    continue
                 if dist.backend == "nccl" and self.gather_done[s] is not None:
                     self.lane_streams[s].wait_event(self.gather_done[s])  # the previous gather has read this tile buffer
                 ln.rays.pack_texels_dev(self.lane_tiles[s].data_ptr())
@@ -208,6 +223,9 @@ class Renderer:
         """ONE collective per frame: per-texel radiance of every tile -> rank 0 (RCCL gather over xGMI)."""
         dist = self.dist
         if not dist.active:
+            return
+        if self.native is not None:
+            self.native.gather_tiles(self.rt)
             return
         torch = dist.torch
         self.rt.pack_texels_dev(self.tile_dev.data_ptr())

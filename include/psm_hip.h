@@ -326,6 +326,30 @@ int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lan
                           uint32_t depth, int start, int rebuild, const double* opt, int32_t* counts_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * tile-sharded frames across the GPUs of one node (new; SURVEY 8(b) "proposed C ABI", 8(e); the reference has no
+ * multi-GPU path). One process per GPU. The path has ONE data-path collective per frame: the gather of every tile's
+ * per-texel radiance to rank 0 (RCCL over xGMI), which runs sample() on the whole image. psm_dist_allgather_i32
+ * carries the (round, ray count) pairs psm_lanes_run_sharded asks the host to exchange.
+ *   rank 0:   psm_dist_unique_id(id);  ... hand `id` to the other ranks (any side channel) ...
+ *   all:      psm_dist_init(ctx, rank, world, id, &dist);  psm_rt_set_tile_interleaved(rt, rank, world);
+ *   a frame:  camera / rounds on rt ...; psm_dist_gather_tiles(dist, rt);  rank 0: psm_rt_sample(rt)
+ * Every rank makes the same psm_dist_* calls in the same order. Collectives run on the communicator's own stream,
+ * ordered against the Pipeline's stream by events: no host synchronisation in psm_dist_gather_tiles.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct psm_dist psm_dist;
+int psm_dist_unique_id(uint8_t id[128]);                        /* ncclGetUniqueId */
+int psm_dist_init(psm_ctx* ctx, int rank, int world, const uint8_t id[128], psm_dist** out); /* ncclCommInitRank on ctx's device; collective */
+int psm_dist_destroy(psm_dist* dist);
+int psm_dist_rank(const psm_dist* dist);
+int psm_dist_world(const psm_dist* dist);
+/* pack rt's owned texels, ncclGather them to rank 0, and there unpack the tiles of ranks 1..world-1 into rt's image
+ * (rt must carry psm_rt_set_tile_interleaved(rank, world) of this communicator). 16 B per texel; 1080p: 33 MB in all. */
+int psm_dist_gather_tiles(psm_dist* dist, psm_rt* rt);
+/* n ints from every rank to every rank (host arrays: recv holds world * n); synchronises */
+int psm_dist_allgather_i32(psm_dist* dist, const int32_t* send, int32_t* recv, uint32_t n);
+int psm_dist_barrier(psm_dist* dist);
+
+/* ---------------------------------------------------------------------------------------------
  * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing
  * ------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -33,6 +33,8 @@ EXPORTS = [
     "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
+    "psm_dist_unique_id", "psm_dist_init", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
+    "psm_dist_allgather_i32", "psm_dist_barrier",
 ]
 
 TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)

@@ -20,6 +20,45 @@ def tile_rows(rank, world, height):
     return y0, min(y0 + per, height), per
 
 
+class NativeDist:
+    """The C ABI's own communicator (psm_dist_*, RCCL directly from libpsm_hip.so): the path's one data-path
+    collective per frame (gather of the tiles' per-texel radiance to rank 0) and the small all-gather of
+    (round, count) pairs, with no torch tensor in between. `bcast_id(bytes or None) -> bytes` hands rank 0's
+    ncclUniqueId to the other ranks over whatever side channel the launcher has (here: torch.distributed)."""
+
+    def __init__(self, ctx, rank, world, bcast_id):
+        import ctypes as C
+        from . import lib
+        self._C, self._lib, self.ctx, self.rank, self.world = C, lib(), ctx, rank, world
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            ctx.check(self._lib.psm_dist_unique_id(ident), "psm_dist_unique_id")
+        raw = bcast_id(bytes(ident) if rank == 0 else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self._h = C.c_void_p()
+        ctx.check(self._lib.psm_dist_init(ctx._h, C.c_int(rank), C.c_int(world), ident, C.byref(self._h)), "psm_dist_init")
+
+    def gather_tiles(self, rays):
+        """ONE collective: rays' owned texels -> rank 0's image (stream-ordered against rays' context, no host sync)."""
+        rays.ctx.check(self._lib.psm_dist_gather_tiles(self._h, rays._h), "psm_dist_gather_tiles")
+
+    def allgather_i32(self, values):
+        C = self._C
+        n = len(values)
+        send = (C.c_int32 * n)(*[int(v) for v in values])
+        recv = (C.c_int32 * (n * self.world))()
+        self.ctx.check(self._lib.psm_dist_allgather_i32(self._h, send, recv, C.c_uint32(n)), "psm_dist_allgather_i32")
+        return [list(recv[r * n:(r + 1) * n]) for r in range(self.world)]
+
+    def barrier(self):
+        self.ctx.check(self._lib.psm_dist_barrier(self._h), "psm_dist_barrier")
+
+    def close(self):
+        if self._h:
+            self._lib.psm_dist_destroy(self._h)
+            self._h = None
+
+
 class Comm:
     def __init__(self, world=1, backend=None, init=True, force=False):
         """force=True runs the distributed code path even for world == 1 (single-GPU rehearsal of the
@@ -50,6 +89,23 @@ class Comm:
                 self.dev = torch.device("cpu")
             if init and not dist.is_initialized():
                 dist.init_process_group(backend=self.backend, rank=self.rank, world_size=world)
+
+    def attach_native(self, ctx):
+        """Create the C ABI's RCCL communicator on ctx's device (backend nccl only); rank 0's id travels by a
+        torch.distributed broadcast. PSM_DIST_NATIVE=0 keeps every collective on torch.distributed."""
+        self.native = None
+        if not self.active or self.backend != "nccl" or os.environ.get("PSM_DIST_NATIVE", "1") == "0":
+            return None
+
+        def bcast(raw):
+            t = self.torch.zeros(128, dtype=self.torch.uint8, device=self.dev)
+            if raw is not None:
+                t.copy_(self.torch.frombuffer(bytearray(raw), dtype=self.torch.uint8))
+            if self.world > 1:
+                self.dist.broadcast(t, src=0)
+            return bytes(t.cpu().numpy().tobytes())
+        self.native = NativeDist(ctx, self.rank, self.world, bcast)
+        return self.native
 
     def barrier(self):
         if self.active:
@@ -92,6 +148,9 @@ class Comm:
         return None
 
     def close(self):
+        if getattr(self, "native", None) is not None:
+            self.native.close()
+            self.native = None
         if self.active and self.dist.is_initialized():
             self.dist.destroy_process_group()
 
@@ -233,11 +292,16 @@ def run_batch_sharded(comm, batch, cam_inv, proj_inv, seeds, depth):
     k = len(seeds)
     rounds, counts = batch.run_sharded(seeds, cam_inv, proj_inv, depth=depth)
     over = [False] * k
+    native = getattr(comm, "native", None)
     while True:
-        mine = torch.tensor([rounds, counts], dtype=torch.int32).to(comm.dev)
-        allv = torch.empty(comm.world * 2 * k, dtype=torch.int32, device=comm.dev)
-        dist.all_gather_into_tensor(allv, mine.view(-1))
-        allv = allv.cpu().view(comm.world, 2, k).tolist()
+        if native is not None:  # the C ABI's own all-gather (psm_dist_allgather_i32)
+            flat = native.allgather_i32(list(rounds) + list(counts))
+            allv = [[f[:k], f[k:]] for f in flat]
+        else:
+            mine = torch.tensor([rounds, counts], dtype=torch.int32).to(comm.dev)
+            allv = torch.empty(comm.world * 2 * k, dtype=torch.int32, device=comm.dev)
+            dist.all_gather_into_tensor(allv, mine.view(-1))
+            allv = allv.cpu().view(comm.world, 2, k).tolist()
         verdict = decide_sharded([a[0] for a in allv], [a[1] for a in allv], depth)
         force = []
         for s in range(k):

@@ -1014,3 +1014,35 @@ def test_cpp_header_layer_viewer_call_order(psm, ctx, oracle, scenes, tmp_path):
     assert abs(float(img2[..., :3].mean()) - float(ref2[..., :3].mean())) < 0.02 * float(ref2[..., :3].mean())
     close2 = np.abs(img2[..., :3] - ref2[..., :3]).max(-1) < 2e-3 + 1e-2 * ref2[..., :3].max(-1)
     assert close2.mean() > 0.9
+
+
+def test_native_rccl_communicator_single_rank(psm, ctx, scenes):
+    """psm_dist_* (RCCL from the C ABI, no torch): a one-rank communicator on the GPU box -- init, the per-frame tile
+    gather (pack -> ncclGather -> nothing to unpack at world 1) leaving the image untouched, the int all-gather the
+    sharded scheduler uses, barrier, destroy. The N > 1 data flow is the same calls with more peers."""
+    pdist = __import__("importlib").import_module("prismarine-core_amd.dist")
+    scene = scenes.cornell(open_top=True)
+    w, h = 72, 52
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    nd = pdist.NativeDist(ctx, 0, 1, lambda raw: raw)
+    rt.setTileInterleaved(0, 1)
+    rt.camera_matrices(cam[0], cam[1], time=9)
+    rt.applyMaterials(ms)
+    for _ in range(3):
+        if rt.intersection(th) == 0:
+            break
+        rt.shade(time=5)
+    before, _, _ = rt.download_texels()
+    nd.gather_tiles(rt)
+    nd.gather_tiles(rt)
+    after, _, _ = rt.download_texels()
+    assert before[:, :3].max() > 0.1 and np.array_equal(before, after)
+    assert nd.allgather_i32([3, 1, 4, 1, 5]) == [[3, 1, 4, 1, 5]]
+    nd.barrier()
+    # a Pipeline whose tile is not this communicator's is refused, not gathered wrongly
+    rt.setTileInterleaved(1, 3)
+    with pytest.raises(psm.PsmError):
+        nd.gather_tiles(rt)
+    nd.close()
+    rt.close()
+    th.close()
