@@ -159,6 +159,10 @@ class Renderer:
             seeds = batch.frame_seeds(min(self.lanes, k - f0))
             lanes = batch.lanes[: len(seeds)]
             before = [ln.ctx.stats().rays_traced for ln in lanes]
+            if self.native is not None:  # the whole batch in the C ABI: rounds, exchanges, one gather per frame, fold
+                batch.render_batch_sharded(self.native, seeds, self.cam[0], self.cam[1], depth=self.args.depth)
+                traced += sum(ln.ctx.stats().rays_traced - b for ln, b in zip(lanes, before))
+                continue
             if dist.backend == "nccl":
                 self.pdist.run_batch_sharded(dist, batch, self.cam[0], self.cam[1], seeds, self.args.depth)
             else:  # host-exchange rehearsal path (gloo)

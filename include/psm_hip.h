@@ -348,6 +348,18 @@ int psm_dist_gather_tiles(psm_dist* dist, psm_rt* rt);
 /* n ints from every rank to every rank (host arrays: recv holds world * n); synchronises */
 int psm_dist_allgather_i32(psm_dist* dist, const int32_t* send, int32_t* recv, uint32_t n);
 int psm_dist_barrier(psm_dist* dist);
+/* the global `fewer than 32 rays -> stop` rule (Pipeline.inl:459-461) from every rank's answers: all = [world][2][lanes]
+ * (rounds done, local rays waiting) as gathered after psm_lanes_run_sharded -> per lane: over (the frame has ended) and
+ * force_until (the round every rank must reach next). Pure host arithmetic; needs no device. */
+int psm_dist_decide(uint32_t world, uint32_t lanes, const int32_t* all, uint32_t depth, int32_t* over, uint32_t* force_until);
+/* `lanes` tile-sharded frames in flight, start to finish, on this rank (every rank makes the same call): build (if
+ * rebuild) + camera + rounds on lanes that run free and park on their local counts (psm_lanes_run_sharded), the
+ * all-gathers + psm_dist_decide until every frame has ended, then per frame, in frame order, psm_dist_gather_tiles and on
+ * rank 0 psm_rt_sample_from(fold_into, lane). rts[s] must carry psm_rt_set_tile_interleaved(rank, world); fold_into is
+ * rank 0's accumulating Pipeline (ignored elsewhere); rounds_out[lanes] may be NULL. */
+int psm_dist_render_batch(psm_dist* dist, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                          const float proj_inv[16], const uint32_t* frame_seeds, uint32_t depth, int rebuild, const double* opt,
+                          psm_rt* fold_into, uint32_t* rounds_out);
 
 /* ---------------------------------------------------------------------------------------------
  * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing

@@ -34,7 +34,7 @@ EXPORTS = [
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
     "psm_dist_unique_id", "psm_dist_init", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
-    "psm_dist_allgather_i32", "psm_dist_barrier",
+    "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch",
 ]
 
 TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)
@@ -802,6 +802,24 @@ class FrameBatch:
                 ln.th._dirty = False
                 ln.rays._obj = ln.th
         return list(self._rounds), list(counts)
+
+    def render_batch_sharded(self, native, seeds, cam_inv, proj_inv, depth=16, rebuild=True):
+        """len(seeds) tile-sharded frames in flight, start to finish, in the C ABI (psm_dist_render_batch): rounds,
+        the (round, count) exchanges, one tile gather per frame and, on rank 0, the fold in frame order."""
+        k = len(seeds)
+        rts = (C.c_void_p * k)(*[ln.rays._h for ln in self.lanes[:k]])
+        bvhs = (C.c_void_p * k)(*[ln.th._h for ln in self.lanes[:k]])
+        sd = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
+        rounds = (C.c_uint32 * k)()
+        ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
+        pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
+        rc = lib().psm_dist_render_batch(native._h, rts, bvhs, C.c_uint32(k), _p(ci), _p(pi), sd, C.c_uint32(depth), C.c_int(int(rebuild)),
+                                         None, self.master._h, rounds)
+        self.lanes[0].ctx.check(rc, "psm_dist_render_batch")
+        for ln in self.lanes[:k]:
+            ln.th._dirty = False
+            ln.rays._obj = ln.th
+        return list(rounds)
 
     def fold_one(self, lane):
         self.master.ctx.check(lib().psm_rt_sample_from(self.master._h, lane.rays._h), "psm_rt_sample_from")

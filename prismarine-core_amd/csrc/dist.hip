@@ -12,6 +12,7 @@
 // Pipeline's stream waits for that (event), so folding the frame afterwards needs no host synchronisation.
 #include <rccl/rccl.h>
 
+#include <climits>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -162,6 +163,65 @@ int psm_dist_allgather_i32(psm_dist* d, const int32_t* send, int32_t* recv, uint
     PSM_HIP(c, hipMemcpyAsync(recv, d->d_i32 + n, (size_t)n * d->world * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
     PSM_HIP(c, hipStreamSynchronize(d->stream));
     return PSM_OK;
+}
+
+// The global `fewer than 32 rays -> stop` rule (Pipeline.inl:459-461) from every rank's (rounds done, local rays
+// waiting) per lane. all: [world][2][lanes] (rounds, then counts). A rank behind the furthest one catches up (any round
+// below the furthest rank's had >= 32 rays there alone); with every rank at the same round the global count decides.
+int psm_dist_decide(uint32_t world, uint32_t lanes, const int32_t* all, uint32_t depth, int32_t* over, uint32_t* force_until) {
+    if (!all || !over || !force_until || world == 0) return PSM_ERR_INVALID;
+    for (uint32_t s = 0; s < lanes; s++) {
+        int32_t pmax = INT32_MIN, pmin = INT32_MAX;
+        int64_t total = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            const int32_t rd = all[((size_t)r * 2 + 0) * lanes + s];
+            pmax = rd > pmax ? rd : pmax;
+            pmin = rd < pmin ? rd : pmin;
+            total += all[((size_t)r * 2 + 1) * lanes + s];
+        }
+        if (pmin < pmax) { over[s] = 0; force_until[s] = (uint32_t)pmax; }
+        else if ((uint32_t)pmax >= depth || total < 32) { over[s] = 1; force_until[s] = (uint32_t)pmax; }
+        else { over[s] = 0; force_until[s] = (uint32_t)pmax + 1u; }
+    }
+    return PSM_OK;
+}
+
+// `lanes` tile-sharded frames in flight on this rank, start to finish (every rank calls it with the same arguments but
+// its own objects): the lanes run free until their LOCAL counts park them (psm_lanes_run_sharded), one small
+// all-gather per decision applies the stop rule to each frame's GLOBAL count, and every frame ends with the path's one
+// data-path collective, the tile gather to rank 0, which folds it into `fold_into` in frame order.
+int psm_dist_render_batch(psm_dist* d, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                          const float proj_inv[16], const uint32_t* frame_seeds, uint32_t depth, int rebuild, const double* opt,
+                          psm_rt* fold_into, uint32_t* rounds_out) {
+    if (!d || !rts || !bvhs || !frame_seeds || lanes == 0 || lanes > 64) return PSM_ERR_INVALID;
+    if (d->rank == 0 && !fold_into) return PSM_ERR_INVALID;
+    std::vector<uint32_t> state(frame_seeds, frame_seeds + lanes), rounds(lanes, 0u), force(lanes, 0u);
+    std::vector<int32_t> counts(lanes, 0), over(lanes, 0), verdict(lanes, 0);
+    std::vector<int32_t> mine(2 * (size_t)lanes), all(2 * (size_t)lanes * (size_t)d->world);
+    int rc = psm_lanes_run_sharded(rts, bvhs, lanes, cam_inv, proj_inv, state.data(), rounds.data(), force.data(), depth, 1, rebuild, opt,
+                                   counts.data());
+    while (rc == PSM_OK) {
+        for (uint32_t s = 0; s < lanes; s++) { mine[s] = (int32_t)rounds[s]; mine[lanes + s] = counts[s]; }
+        rc = psm_dist_allgather_i32(d, mine.data(), all.data(), 2 * lanes);
+        if (rc != PSM_OK) break;
+        rc = psm_dist_decide((uint32_t)d->world, lanes, all.data(), depth, verdict.data(), force.data());
+        if (rc != PSM_OK) break;
+        bool done = true;
+        for (uint32_t s = 0; s < lanes; s++) {
+            over[s] = over[s] | verdict[s];
+            if (over[s]) force[s] = rounds[s];  // a finished frame's lane stays parked
+            done = done && over[s];
+        }
+        if (done) break;
+        rc = psm_lanes_run_sharded(rts, bvhs, lanes, cam_inv, proj_inv, state.data(), rounds.data(), force.data(), depth, 0, rebuild, opt,
+                                   counts.data());
+    }
+    for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {  // frame order
+        rc = psm_dist_gather_tiles(d, rts[s]);
+        if (rc == PSM_OK && d->rank == 0) rc = psm_rt_sample_from(fold_into, rts[s]);
+    }
+    if (rounds_out) for (uint32_t s = 0; s < lanes; s++) rounds_out[s] = rounds[s];
+    return rc;
 }
 
 int psm_dist_barrier(psm_dist* d) {

@@ -277,3 +277,28 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert len(lines) == 2
     assert {ln.split("rank ")[1].split(" ")[0] for ln in lines} == {"0", "1"}
     assert all(ln.endswith("= 2") for ln in lines)
+
+
+def test_native_decide_equals_python_protocol():
+    """psm_dist_decide (the C ABI's host-side restatement of the global `< 32 rays -> stop` rule used by
+    psm_dist_render_batch) against dist.decide_sharded (the protocol the gloo tests above exercise) on random
+    states: ranks at unequal rounds, everybody level with few / many rays, depth reached."""
+    import ctypes as C
+    psm = importlib.import_module("prismarine-core_amd")
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    L = psm.lib()
+    rng = np.random.RandomState(3)
+    for _ in range(500):
+        world, lanes, depth = int(rng.randint(1, 9)), int(rng.randint(1, 7)), int(rng.randint(1, 6))
+        base = rng.randint(0, depth + 1, lanes)
+        rounds = [[int(max(0, b - rng.randint(0, 2) * rng.randint(0, 3))) for b in base] for _ in range(world)]
+        counts = [[int(rng.choice([0, 3, 10, 31, 32, 500])) for _ in range(lanes)] for _ in range(world)]
+        want = pdist.decide_sharded(rounds, counts, depth)
+        flat = []
+        for r in range(world):
+            flat += rounds[r] + counts[r]
+        arr = (C.c_int32 * len(flat))(*flat)
+        over = (C.c_int32 * lanes)()
+        force = (C.c_uint32 * lanes)()
+        assert L.psm_dist_decide(C.c_uint32(world), C.c_uint32(lanes), arr, C.c_uint32(depth), over, force) == 0
+        assert [(bool(over[s]), int(force[s])) for s in range(lanes)] == [(bool(o), int(f)) for o, f in want]
