@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0,
                     help="frames in flight per GPU (psm_lanes_render): each on its own HIP stream, folded into the "
                          "accumulating image in frame order; 1 = one frame after another; 0 (default) = 4 on one GPU, "
-                         "8 / 12 / 16 per GPU on 2 / 4 / 8 GPUs (a tile's launches are small and latency-bound: more "
-                         "frames in flight fill the chip, measured with --emulate-tile)")
+                         "8 per GPU on several (a tile's launches are small and latency-bound: more frames in flight "
+                         "fill the chip; measured with --force-dist --emulate-tile R/W, profiles/r02_tile_emulation.txt)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous check only: every rank builds its communicator (gloo, no GPU), proves the group works "
                          "with one all-reduce, prints one line and exits")
@@ -80,15 +80,14 @@ class Renderer:
         self.native = None
         # the C ABI's own RCCL communicator carries the collectives unless PSM_DIST_NATIVE=0 (or the one-GPU rehearsal of
         # another rank's tile, whose tile is not this rank's)
-        use_native = (dist.active and dist.backend == "nccl" and os.environ.get("PSM_DIST_NATIVE", "1") != "0" and
-                      not (args.emulate_tile and dist.world == 1))
+        use_native = dist.active and dist.backend == "nccl" and os.environ.get("PSM_DIST_NATIVE", "1") != "0"
         if dist.active and dist.backend == "nccl" and not use_native:
             # torch.distributed collectives: run the kernels on torch's stream, so RCCL calls and kernels are ordered
             # without host syncs. (Default: the C ABI's own communicator, psm_dist_*, ordered by events.)
             stream = dist.torch.cuda.current_stream().cuda_stream
             dist.same_stream = True
         w, h = args.width, args.height
-        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else 8 if dist.world == 2 else 12 if dist.world <= 4 else 16)
+        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else 8)
         self.lane_streams = None
         streams = None
         if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
@@ -126,6 +125,8 @@ class Renderer:
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if use_native:
             self.native = dist.attach_native(self.ctx)  # collective: every rank creates its RCCL communicator here
+            if args.emulate_tile and dist.world == 1:
+                self.native.emulate_tile(r_, w_)
         if dist.active and self.native is None:
             torch = dist.torch
             gdev = torch.device("cuda", dist.device_index)
@@ -155,6 +156,11 @@ class Renderer:
         torch = dist.torch
         w, h = self.args.width, self.args.height
         traced = 0
+        if self.native is not None and os.environ.get("PSM_DIST_PIPELINE", "1") != "0":
+            # all k frames in the C ABI: rounds, exchanges, ONE gather per frame, fold -- no drain between batches
+            before = [ln.ctx.stats().rays_traced for ln in batch.lanes]
+            batch.render_frames_sharded(self.native, batch.frame_seeds(k), self.cam[0], self.cam[1], depth=self.args.depth)
+            return sum(ln.ctx.stats().rays_traced - b for ln, b in zip(batch.lanes, before))
         for f0 in range(0, k, self.lanes):
             seeds = batch.frame_seeds(min(self.lanes, k - f0))
             lanes = batch.lanes[: len(seeds)]

@@ -360,6 +360,16 @@ int psm_dist_decide(uint32_t world, uint32_t lanes, const int32_t* all, uint32_t
 int psm_dist_render_batch(psm_dist* dist, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
                           const float proj_inv[16], const uint32_t* frame_seeds, uint32_t depth, int rebuild, const double* opt,
                           psm_rt* fold_into, uint32_t* rounds_out);
+/* `frames` tile-sharded frames with `lanes` of them in flight and NO drain between batches: the lanes form two groups
+ * that alternate batches of lanes / 2 frames -- while one group exchanges, gathers and folds, the other group's frames
+ * keep the chip busy -- with the same collective sequence on every rank (one communicator). Same arguments and result
+ * as psm_dist_render_batch called ceil(frames / lanes) times; frame_seeds[frames], rounds_out[frames] or NULL. */
+int psm_dist_render_frames(psm_dist* dist, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                           const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth, int rebuild,
+                           const double* opt, psm_rt* fold_into, uint32_t* rounds_out);
+/* one-GPU rehearsal of a worker rank's per-frame cost: gathers pack tile (tile_rank, tile_world) instead of the
+ * communicator's own (rank, world) and unpack nothing (the image is then not a complete frame) */
+int psm_dist_emulate_tile(psm_dist* dist, int tile_rank, int tile_world);
 
 /* ---------------------------------------------------------------------------------------------
  * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing

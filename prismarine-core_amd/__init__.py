@@ -34,7 +34,7 @@ EXPORTS = [
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
     "psm_dist_unique_id", "psm_dist_init", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
-    "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch",
+    "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile",
 ]
 
 TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)
@@ -820,6 +820,23 @@ class FrameBatch:
             ln.th._dirty = False
             ln.rays._obj = ln.th
         return list(rounds)
+
+    def render_frames_sharded(self, native, seeds, cam_inv, proj_inv, depth=16, rebuild=True):
+        """len(seeds) tile-sharded frames with all lanes in flight and no drain between batches (psm_dist_render_frames)."""
+        k, n = len(seeds), self.n
+        rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes])
+        bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes])
+        sd = (C.c_uint32 * max(k, 1))(*[v & 0xFFFFFFFF for v in seeds])
+        rounds = (C.c_uint32 * max(k, 1))()
+        ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
+        pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
+        rc = lib().psm_dist_render_frames(native._h, rts, bvhs, C.c_uint32(n), _p(ci), _p(pi), sd, C.c_uint32(k), C.c_uint32(depth),
+                                          C.c_int(int(rebuild)), None, self.master._h, rounds)
+        self.lanes[0].ctx.check(rc, "psm_dist_render_frames")
+        for ln in self.lanes:
+            ln.th._dirty = False
+            ln.rays._obj = ln.th
+        return list(rounds)[:k]
 
     def fold_one(self, lane):
         self.master.ctx.check(lib().psm_rt_sample_from(self.master._h, lane.rays._h), "psm_rt_sample_from")

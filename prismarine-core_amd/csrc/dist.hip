@@ -25,6 +25,7 @@ struct psm_dist {
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int rank = 0, world = 1;
+    int tile_rank = 0, tile_world = 1;  // the tile geometry gathers use: (rank, world) unless psm_dist_emulate_tile changed it
     float* d_send = nullptr;   // per_floats
     float* d_recv = nullptr;   // rank 0: world * per_floats
     size_t per_floats = 0;
@@ -85,6 +86,7 @@ int psm_dist_init(psm_ctx* ctx, int rank, int world, const uint8_t id[128], psm_
     psm_dist* d = new (std::nothrow) psm_dist();
     if (!d) return PSM_ERR_INVALID;
     d->ctx = ctx; d->rank = rank; d->world = world;
+    d->tile_rank = rank; d->tile_world = world;
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d->ev_out, hipEventDisableTiming) != hipSuccess) {
@@ -106,14 +108,24 @@ int psm_dist_init(psm_ctx* ctx, int rank, int world, const uint8_t id[128], psm_
 int psm_dist_rank(const psm_dist* d) { return d ? d->rank : -1; }
 int psm_dist_world(const psm_dist* d) { return d ? d->world : -1; }
 
+// One-GPU rehearsal of another rank's share (bench.py --emulate-tile R/W --force-dist): the communicator keeps its real
+// ranks, but gathers pack the tile (tile_rank, tile_world) and skip the unpack / let the caller skip the fold, i.e. they
+// cost what a WORKER rank of a tile_world-GPU run pays per frame. The image is then not a complete frame.
+int psm_dist_emulate_tile(psm_dist* d, int tile_rank, int tile_world) {
+    if (!d || tile_world < 1 || tile_rank < 0 || tile_rank >= tile_world) return PSM_ERR_INVALID;
+    d->tile_rank = tile_rank; d->tile_world = tile_world;
+    return PSM_OK;
+}
+
 int psm_dist_gather_tiles(psm_dist* d, psm_rt* rt) {
     if (!d || !rt || !rt->t_sum) return PSM_ERR_INVALID;
     psm_ctx* c = rt->ctx;
     if (c->device != d->ctx->device) return set_err(c, PSM_ERR_INVALID, "psm_dist_gather_tiles: Pipeline and communicator live on different devices");
-    if (rt->tile_mode != 1 || (int)rt->tile_world != d->world || (int)rt->tile_rank != d->rank)
+    const bool emulated = d->tile_world != d->world || d->tile_rank != d->rank;
+    if (rt->tile_mode != 1 || (int)rt->tile_world != d->tile_world || (int)rt->tile_rank != d->tile_rank)
         return set_err(c, PSM_ERR_STATE, "psm_dist_gather_tiles: the Pipeline's tile is not psm_rt_set_tile_interleaved(rank, world) of this communicator");
     (void)hipSetDevice(c->device);
-    const size_t per = (size_t)interleaved_texels(0, (uint32_t)d->world, rt->w, rt->h) * 4;  // rank 0 owns the most bands
+    const size_t per = (size_t)interleaved_texels(0, (uint32_t)d->tile_world, rt->w, rt->h) * 4;  // rank 0 owns the most bands
     if (per != d->per_floats) {
         PSM_HIP(c, hipStreamSynchronize(d->stream));
         if (d->d_send) (void)hipFree(d->d_send);
@@ -130,12 +142,12 @@ int psm_dist_gather_tiles(psm_dist* d, psm_rt* rt) {
     PSM_HIP(c, hipStreamWaitEvent(d->stream, d->ev_in, 0));
     hipStream_t keep = c->stream;
     c->stream = d->stream;  // launch_rt_pack launches on the context's stream
-    int rc = launch_rt_pack(rt, d->d_send, 0, 1u, (uint32_t)d->rank, (uint32_t)d->world);
+    int rc = launch_rt_pack(rt, d->d_send, 0, 1u, (uint32_t)d->tile_rank, (uint32_t)d->tile_world);
     if (rc == PSM_OK) {
         ncclResult_t r = ncclGather(d->d_send, d->d_recv, per, ncclFloat, 0, d->comm, d->stream);
         if (r != ncclSuccess) rc = nccl_err(c, r, "ncclGather");
     }
-    if (rc == PSM_OK && d->rank == 0)
+    if (rc == PSM_OK && d->rank == 0 && !emulated)
         for (int q = 1; q < d->world && rc == PSM_OK; q++)
             rc = launch_rt_pack(rt, d->d_recv + (size_t)q * per, 1, 1u, (uint32_t)q, (uint32_t)d->world);
     c->stream = keep;

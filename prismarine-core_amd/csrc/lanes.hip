@@ -15,6 +15,7 @@
 // another one's round; a lane that finishes a frame takes the next one as soon as its frame is folded.
 #include "psm_internal.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -213,22 +214,25 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
 // run dry in the same round -- and, where the global count says the frame goes on, calls again with
 // force_until[lane] = the round the lane has to reach regardless of its local count (it traces its few rays,
 // or none, and draws its rand() every round so the ranks stay in step).
-extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
-                                     const float proj_inv[16], uint32_t* rand_state, uint32_t* rounds,
-                                     const uint32_t* force_until, uint32_t depth, int start, int rebuild, const double* opt,
-                                     int32_t* counts_out) {
-    if (!rts || !bvhs || !rand_state || !rounds || !force_until || !counts_out || lanes == 0 || lanes > 64) return PSM_ERR_INVALID;
-    if (start && (!cam_inv || !proj_inv)) return PSM_ERR_INVALID;
-    for (uint32_t s = 0; s < lanes; s++) {
-        if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
-        int e = lane_resources(rts[s]);
-        if (e != PSM_OK) return e;
-    }
-    (void)hipSetDevice(rts[0]->ctx->device);
-    for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
-    std::vector<LaneState> st(lanes, IDLE);  // RUNNING = a round is in flight, FINISHED = parked
+namespace psm {
+
+// Free-running lanes of tile-sharded frames (see above): shared by psm_lanes_run_sharded and the pipelined batches of
+// psm_dist_render_frames (dist.hip). A lane is IDLE (nothing queued), RUNNING (a round's kernels and the read-back of
+// its ray count are in flight) or FINISHED (= parked: fewer than 32 local rays and no round forced, or depth reached).
+struct ShardedLanes {
+    psm_rt* const* rts;
+    psm_bvh* const* bvhs;
+    uint32_t lanes, depth;
+    uint32_t* rand_state;
+    uint32_t* rounds;
+    std::vector<uint32_t> force_until;
+    std::vector<LaneState> st;
     int rc = PSM_OK;
-    auto step = [&](uint32_t s) -> int {  // park, or queue one more round
+
+    ShardedLanes(psm_rt* const* r, psm_bvh* const* b, uint32_t n, uint32_t d, uint32_t* rs, uint32_t* rd)
+        : rts(r), bvhs(b), lanes(n), depth(d), rand_state(rs), rounds(rd), force_until(n, 0u), st(n, FINISHED) {}
+
+    int step(uint32_t s) {  // park, or queue one more round
         psm_rt* r = rts[s];
         if (rounds[s] >= depth || (r->ray_count < 32 && rounds[s] >= force_until[s])) { st[s] = FINISHED; return PSM_OK; }
         uint32_t t = lcg_next(rand_state[s]);  // drawn every round, ray or no ray
@@ -242,42 +246,168 @@ extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, u
         PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
         st[s] = RUNNING;
         return PSM_OK;
-    };
-    for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
-        if (start) {
-            rounds[s] = 0;
-            if (rebuild) rc = psm_bvh_build(bvhs[s], opt);
-            if (rc == PSM_OK) rc = psm_rt_camera(rts[s], cam_inv, proj_inv, lcg_next(rand_state[s]));
-        }
+    }
+    // begin a new frame on lane s: build (if rebuild) + camera, then rounds until it parks or a round is in flight
+    void start(uint32_t s, uint32_t seed, const float* cam_inv, const float* proj_inv, int rebuild, const double* opt) {
+        if (rc != PSM_OK) return;
+        rand_state[s] = seed;
+        rounds[s] = 0;
+        force_until[s] = 0;
+        if (rebuild) rc = psm_bvh_build(bvhs[s], opt);
+        if (rc == PSM_OK) rc = psm_rt_camera(rts[s], cam_inv, proj_inv, lcg_next(rand_state[s]));
+        st[s] = IDLE;
         while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
     }
-    uint32_t idle_spins = 0;
-    for (;;) {
-        if (rc != PSM_OK) break;
-        bool any = false, progressed = false;
-        for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
-            if (st[s] != RUNNING) continue;
-            any = true;
-            hipError_t q = hipEventQuery(rts[s]->ev_cnt);
-            if (q == hipErrorNotReady) continue;
-            if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
-            progressed = true;
-            rts[s]->ray_count = *rts[s]->h_cnt;
-            rts[s]->count_valid = true;
-            st[s] = IDLE;
-            while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
-        }
-        if (!any) break;
-        if (!progressed) {
-            if (++idle_spins > 256) std::this_thread::yield();
-        } else {
-            idle_spins = 0;
+    // continue a parked lane at least up to round `until`
+    void resume(uint32_t s, uint32_t until) {
+        if (rc != PSM_OK) return;
+        force_until[s] = until;
+        st[s] = IDLE;
+        while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+    }
+    // drive EVERY lane that has a round in flight until lanes [g0, g1) are all parked (lanes outside keep running)
+    int drive(uint32_t g0, uint32_t g1) {
+        uint32_t idle_spins = 0;
+        for (;;) {
+            if (rc != PSM_OK) return rc;
+            bool waiting = false, progressed = false;
+            for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
+                if (st[s] != RUNNING) continue;
+                if (s >= g0 && s < g1) waiting = true;
+                hipError_t q = hipEventQuery(rts[s]->ev_cnt);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
+                progressed = true;
+                rts[s]->ray_count = *rts[s]->h_cnt;
+                rts[s]->count_valid = true;
+                st[s] = IDLE;
+                while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+            }
+            if (!waiting) {
+                bool again = false;
+                for (uint32_t s = g0; s < g1; s++) again = again || st[s] == RUNNING;
+                if (!again) return rc;
+                continue;
+            }
+            if (!progressed) {
+                if (++idle_spins > 256) std::this_thread::yield();
+            } else {
+                idle_spins = 0;
+            }
         }
     }
+};
+
+}  // namespace psm
+
+extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                                     const float proj_inv[16], uint32_t* rand_state, uint32_t* rounds,
+                                     const uint32_t* force_until, uint32_t depth, int start, int rebuild, const double* opt,
+                                     int32_t* counts_out) {
+    if (!rts || !bvhs || !rand_state || !rounds || !force_until || !counts_out || lanes == 0 || lanes > 64) return PSM_ERR_INVALID;
+    if (start && (!cam_inv || !proj_inv)) return PSM_ERR_INVALID;
+    for (uint32_t s = 0; s < lanes; s++) {
+        if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
+        int e = lane_resources(rts[s]);
+        if (e != PSM_OK) return e;
+    }
+    (void)hipSetDevice(rts[0]->ctx->device);
+    for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
+    ShardedLanes L(rts, bvhs, lanes, depth, rand_state, rounds);
+    for (uint32_t s = 0; s < lanes; s++) {
+        if (start) L.start(s, rand_state[s], cam_inv, proj_inv, rebuild, opt);
+        else L.resume(s, force_until[s]);
+    }
+    int rc = L.drive(0, lanes);
     for (uint32_t s = 0; s < lanes; s++) {
         (void)hipStreamSynchronize(rts[s]->ctx->stream);
         counts_out[s] = (int32_t)rts[s]->ray_count;
         rts[s]->in_flight = 1;
     }
+    return rc;
+}
+
+// ---- pipelined batches of tile-sharded frames -----------------------------------------------------------------------
+//
+// psm_dist_render_batch (dist.hip) runs a batch of `lanes` frames start to finish: when the batch ends the chip drains
+// -- every lane waits for the slowest one, the exchange and the gathers -- before the next batch starts all lanes at
+// once. Here the lanes form TWO groups that alternate: while group g sits in its exchange / gather / fold, the other
+// group's frames keep the chip busy, and group g starts its next frames as soon as its tiles are on their way. Every
+// rank makes the same psm_dist_* calls in the same order (group 0's batch, group 1's, group 0's ...), so one
+// communicator serves both groups. Frames fold in frame order: batch b = frames [b*h, (b+1)*h), h = lanes / 2.
+extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
+                                      const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
+                                      int rebuild, const double* opt, psm_rt* fold_into, uint32_t* rounds_out /* [frames] or NULL */) {
+    if (!d || !rts || !bvhs || !cam_inv || !proj_inv || lanes == 0 || lanes > 64 || (frames && !frame_seeds)) return PSM_ERR_INVALID;
+    const int rank = psm_dist_rank(d), world = psm_dist_world(d);
+    if (rank == 0 && !fold_into) return PSM_ERR_INVALID;
+    for (uint32_t s = 0; s < lanes; s++) {
+        if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
+        int e = lane_resources(rts[s]);
+        if (e != PSM_OK) return e;
+    }
+    if (frames == 0) return PSM_OK;
+    (void)hipSetDevice(rts[0]->ctx->device);
+    for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
+    const uint32_t groups = lanes >= 2 ? 2u : 1u;
+    const uint32_t h0 = groups == 2 ? lanes / 2 : lanes;         // group 0: lanes [0, h0), group 1: [h0, lanes)
+    const uint32_t gbeg[2] = {0u, h0}, gend[2] = {h0, lanes};
+    std::vector<uint32_t> state(lanes, 0u), rounds(lanes, 0u);
+    ShardedLanes L(rts, bvhs, lanes, depth, state.data(), rounds.data());
+    // batches: consecutive runs of frames, alternating between the groups
+    struct Batch { uint32_t f0, n, g; };
+    std::vector<Batch> batches;
+    for (uint32_t f = 0, b = 0; f < frames; b++) {
+        const uint32_t g = b % groups, cap = gend[g] - gbeg[g];
+        const uint32_t n = std::min(cap, frames - f);
+        batches.push_back(Batch{f, n, g});
+        f += n;
+    }
+    auto start_batch = [&](const Batch& B) {
+        for (uint32_t k = 0; k < B.n; k++) L.start(gbeg[B.g] + k, frame_seeds[B.f0 + k], cam_inv, proj_inv, rebuild, opt);
+    };
+    for (size_t b = 0; b < batches.size() && b < groups; b++) start_batch(batches[b]);
+    int rc = L.rc;
+    std::vector<int32_t> mine, all, verdict;
+    std::vector<uint32_t> force;
+    for (size_t b = 0; b < batches.size() && rc == PSM_OK; b++) {
+        const Batch& B = batches[b];
+        const uint32_t g0 = gbeg[B.g], n = B.n;
+        mine.assign(2 * (size_t)n, 0); all.assign(2 * (size_t)n * (size_t)world, 0); verdict.assign(n, 0); force.assign(n, 0u);
+        std::vector<int32_t> over(n, 0);
+        rc = L.drive(g0, g0 + n);
+        while (rc == PSM_OK) {
+            for (uint32_t k = 0; k < n; k++) {
+                psm_rt* r = rts[g0 + k];
+                PSM_HIP(r->ctx, hipStreamSynchronize(r->ctx->stream));  // parked: its last count has been read; cheap
+                mine[k] = (int32_t)rounds[g0 + k];
+                mine[n + k] = (int32_t)r->ray_count;
+            }
+            rc = psm_dist_allgather_i32(d, mine.data(), all.data(), 2 * n);
+            if (rc != PSM_OK) break;
+            rc = psm_dist_decide((uint32_t)world, n, all.data(), depth, verdict.data(), force.data());
+            if (rc != PSM_OK) break;
+            bool done = true;
+            for (uint32_t k = 0; k < n; k++) { over[k] |= verdict[k]; done = done && over[k]; }
+            if (done) break;
+            for (uint32_t k = 0; k < n; k++)
+                if (!over[k]) L.resume(g0 + k, force[k]);
+            rc = L.drive(g0, g0 + n);
+        }
+        for (uint32_t k = 0; k < n && rc == PSM_OK; k++) {  // frame order
+            rc = psm_dist_gather_tiles(d, rts[g0 + k]);
+            if (rc == PSM_OK && rank == 0) rc = psm_rt_sample_from(fold_into, rts[g0 + k]);
+            if (rounds_out) rounds_out[B.f0 + k] = rounds[g0 + k];
+        }
+        if (rc == PSM_OK && b + groups < batches.size()) {  // this group's next frames (their camera() waits for the gather: stream order)
+            start_batch(batches[b + groups]);
+            rc = L.rc;
+        }
+    }
+    for (uint32_t s = 0; s < lanes; s++) {
+        (void)hipStreamSynchronize(rts[s]->ctx->stream);
+        rts[s]->in_flight = 1;
+    }
+    if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
     return rc;
 }

@@ -53,6 +53,10 @@ class NativeDist:
     def barrier(self):
         self.ctx.check(self._lib.psm_dist_barrier(self._h), "psm_dist_barrier")
 
+    def emulate_tile(self, tile_rank, tile_world):
+        """one-GPU rehearsal of a worker's per-frame cost (psm_dist_emulate_tile)"""
+        self.ctx.check(self._lib.psm_dist_emulate_tile(self._h, self._C.c_int(tile_rank), self._C.c_int(tile_world)), "psm_dist_emulate_tile")
+
     def close(self):
         if self._h:
             self._lib.psm_dist_destroy(self._h)

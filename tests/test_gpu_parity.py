@@ -1046,3 +1046,44 @@ def test_native_rccl_communicator_single_rank(psm, ctx, scenes):
     nd.close()
     rt.close()
     th.close()
+
+
+@pytest.mark.parametrize("lanes,frames", [(4, 7), (1, 3), (5, 5)])
+def test_native_sharded_frames_equal_unsharded(psm, ctx, scenes, lanes, frames):
+    """psm_dist_render_frames (two alternating lane groups, exchanges, one gather per frame, fold in frame order) on a
+    one-rank communicator gives the image psm_lanes_render gives for the same frames, and psm_dist_render_batch too."""
+    pdist = __import__("importlib").import_module("prismarine-core_amd.dist")
+    scene = scenes.cornell(open_top=True)
+    w, h = 64, 48
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+
+    def make():
+        b = psm.FrameBatch(lanes, w, h, seed=77)
+        b.allocate(scene["tris"].shape[0])
+        b.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+        b.applyMaterials(ms)
+        return b
+    ref = make()
+    ref.render(frames, scene["eye"], scene["view"])
+    want = ref.snapHdr()
+    ref.close()
+    cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
+    for pipelined in (True, False):
+        b = make()
+        b.each(lambda r: r.setTileInterleaved(0, 1))
+        nd = pdist.NativeDist(b.lanes[0].ctx, 0, 1, lambda raw: raw)
+        seeds = b.frame_seeds(frames)
+        if pipelined:
+            rounds = b.render_frames_sharded(nd, seeds, cam[0], cam[1])
+        else:
+            rounds = []
+            for f0 in range(0, frames, lanes):
+                rounds += b.render_batch_sharded(nd, seeds[f0:f0 + lanes], cam[0], cam[1])
+        assert len(rounds) == frames and min(rounds) >= 2
+        got = b.snapHdr()
+        np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(got[..., 3], want[..., 3])
+        nd.close()
+        b.close()
