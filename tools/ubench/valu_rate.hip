@@ -35,11 +35,6 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int
                 asm volatile("v_min3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
                              "v_min3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
-            } else if (KIND == 5) {  // VALU / SALU mix as the traversal loop has it: v_cmp -> sgpr, s_and, v_cndmask from sgpr
-                asm volatile("v_cmp_lt_f32 s[20:21], %0, %8\n v_cmp_gt_f32 s[22:23], %1, %8\n s_and_b64 s[20:21], s[20:21], s[22:23]\n v_cndmask_b32 %2, %2, %8, s[20:21]\n"
-                             "v_cmp_lt_f32 s[24:25], %4, %8\n v_cmp_gt_f32 s[26:27], %5, %8\n s_and_b64 s[24:25], s[24:25], s[26:27]\n v_cndmask_b32 %6, %6, %8, s[24:25]\n"
-                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
-                             : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
             } else {
                 asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
                              "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
@@ -87,6 +82,5 @@ int main() {
     run<2>("v_fma_mix_f32", 8);
     run<4>("v_min3/v_max3_f32", 8);
     run<3>("v_cmp(vcc)+v_cndmask", 8);
-    run<5>("2 v_cmp(sgpr)+s_and+v_cndmask", 6);
     return 0;
 }
