@@ -470,8 +470,8 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
 
 // ---- Pipeline -----------------------------------------------------------------------------------
 static void rt_free_grid(psm_rt* r) {
-    for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); }
-    dev_free(r->sA); dev_free(r->sB); dev_free(r->sC); dev_free(r->d_block);
+    for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); dev_free(r->q_bases[q]); }
+    dev_free(r->d_block);
     dev_free(r->hit0); dev_free(r->hitN); dev_free(r->pool);
     dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag);
 }
@@ -534,9 +534,12 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     size_t nb = (L + SHADE_BLOCK - 1) / SHADE_BLOCK;
     int rc = PSM_OK;
     auto A = [&](int x) { if (rc == PSM_OK) rc = x; };
-    for (int q = 0; q < 2; q++) { A(dev_alloc(c, &r->qA[q], L)); A(dev_alloc(c, &r->qB[q], L)); A(dev_alloc(c, &r->qC[q], L)); }
-    A(dev_alloc(c, &r->sA, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sB, nb * SHADE_BLOCK * 4)); A(dev_alloc(c, &r->sC, nb * SHADE_BLOCK * 4));
-    A(dev_alloc(c, &r->d_block, 2 * nb + 2));
+    for (int q = 0; q < 2; q++) {  // one segment of QUEUE_SEG slots per shading workgroup (256 rays in, at most 4 x 256 out)
+        A(dev_alloc(c, &r->qA[q], nb * QUEUE_SEG)); A(dev_alloc(c, &r->qB[q], nb * QUEUE_SEG)); A(dev_alloc(c, &r->qC[q], nb * QUEUE_SEG));
+        A(dev_alloc(c, &r->q_bases[q], nb + 2));
+        r->q_nb[q] = 1;
+    }
+    A(dev_alloc(c, &r->d_block, nb + 2));
     A(dev_alloc(c, &r->hit0, L)); A(dev_alloc(c, &r->hitN, L));
     r->pool_cap = (uint32_t)std::max<size_t>(L / 2, 1024);  // hits buffer = L/2 in the reference, Pipeline.inl:193
     A(dev_alloc(c, &r->pool, (size_t)r->pool_cap));
@@ -812,10 +815,18 @@ int psm_rt_download_rays(psm_rt* r, psm_ray* dst, uint32_t max_rays, uint32_t* c
     uint32_t m = std::min<uint32_t>((uint32_t)n, max_rays);
     std::vector<float4> A(m), B(m), C(m);
     if (m) {
-        PSM_HIP(c, hipMemcpyAsync(A.data(), r->qA[r->cur], m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-        PSM_HIP(c, hipMemcpyAsync(B.data(), r->qB[r->cur], m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-        PSM_HIP(c, hipMemcpyAsync(C.data(), r->qC[r->cur], m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-        PSM_HIP(c, hipStreamSynchronize(c->stream));
+        // the queue is segmented (one segment per shading workgroup): gather it into queue order on the device first
+        float4* d_dense = nullptr;
+        PSM_HIP(c, hipMalloc((void**)&d_dense, (size_t)3 * m * sizeof(float4)));
+        rc = launch_rt_gather_queue(r, d_dense, m);
+        if (rc == PSM_OK &&
+            (hipMemcpyAsync(A.data(), d_dense, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+             hipMemcpyAsync(B.data(), d_dense + m, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+             hipMemcpyAsync(C.data(), d_dense + 2 * (size_t)m, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+             hipStreamSynchronize(c->stream) != hipSuccess))
+            rc = set_err(c, PSM_ERR_HIP, "psm_rt_download_rays: copy");
+        (void)hipFree(d_dense);
+        if (rc != PSM_OK) return rc;
     }
     for (uint32_t i = 0; i < m; i++) {
         dst[i].origin[0] = A[i].x; dst[i].origin[1] = A[i].y; dst[i].origin[2] = A[i].z;
@@ -851,6 +862,9 @@ int psm_rt_upload_rays(psm_rt* r, const psm_ray* src, uint32_t count) {
     }
     uint32_t cnt[3] = {count, 0, 0};
     PSM_HIP(c, hipMemcpyAsync(r->d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    uint32_t bases[2] = {0, count};  // written densely: one segment
+    PSM_HIP(c, hipMemcpyAsync(r->q_bases[r->cur], bases, sizeof(bases), hipMemcpyHostToDevice, c->stream));
+    r->q_nb[r->cur] = 1;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     r->ray_count = count;
     r->count_valid = true;

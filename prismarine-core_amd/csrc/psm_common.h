@@ -52,4 +52,43 @@ PSM_D uint32_t block_scan_excl(uint32_t v, uint32_t* tmp, uint32_t* total) {
     return base + inc - v;
 }
 
+// ---- segmented ray queue -------------------------------------------------------------------------------------------
+// A ray queue is a sequence of segments of QUEUE_SEG slots: segment b holds rays bases[b] .. bases[b+1]-1 of the queue
+// (dense numbering = the canonical queue order) in its first slots; bases[nb] = total. The shading kernel writes each
+// workgroup's output rays into the workgroup's own segment (ordered inside it) and a scan of the counts gives `bases`:
+// the next round reads the rays THROUGH this map, so the compacting copy of reloadQueuedRays (Pipeline.inl:325-359:
+// three buffer copies per round there, one gather + scatter of every ray here in round 1) is gone. A queue written
+// densely (camera, upload) is one segment: nb = 1.
+constexpr uint32_t QUEUE_SEG = 1024;  // 256 input rays x at most 4 output rays
+
+struct RayQueue {
+    const float4 *A, *B, *C;   // origin|texel, direct|bitfield, color|pkey
+    const uint32_t* bases;     // nb + 1 entries
+    uint32_t nb;
+};
+
+// slot of ray i (i < total): interpolation guess, gallop, binary search for the b with bases[b] <= i < bases[b+1]
+PSM_D uint32_t queue_loc(const uint32_t* __restrict__ bases, uint32_t nb, uint32_t total, uint32_t i) {
+    if (nb <= 1u) return i;
+    uint32_t lo = 0, hi = nb;  // bases[lo] <= i < bases[hi]
+    uint32_t g = (uint32_t)(((uint64_t)i * nb) / total);
+    g = g < nb ? g : nb - 1u;
+    if (bases[g] <= i) {
+        lo = g;
+        uint32_t step = 1;
+        while (lo + step < hi && bases[lo + step] <= i) { lo += step; step <<= 1; }
+        if (lo + step < hi) hi = lo + step;
+    } else {
+        hi = g;
+        uint32_t step = 1;
+        while (hi > lo + step && bases[hi - step] > i) { hi -= step; step <<= 1; }
+        if (hi > lo + step) lo = hi - step;
+    }
+    while (hi - lo > 1u) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (bases[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo * QUEUE_SEG + (i - bases[lo]);
+}
+
 }  // namespace psm

@@ -128,13 +128,13 @@ struct psm_rt {
     int cur = 0;                  // current queue index
     uint32_t ray_count = 0;       // host mirror of the current queue length (valid after sync points)
     bool count_valid = true;
+    // two segmented ray queues (psm_common.h RayQueue): current and next. Capacity = one segment per shading workgroup.
     float4* qA[2] = {nullptr, nullptr};  // origin.xyz, texel
     float4* qB[2] = {nullptr, nullptr};  // direct.xyz, bitfield
     float4* qC[2] = {nullptr, nullptr};  // color.xyz, pkey
-    float4* sA = nullptr;         // staging (4 outputs per input ray, block-compacted)
-    float4* sB = nullptr;
-    float4* sC = nullptr;
-    uint32_t* d_block = nullptr;  // per-block output counts / bases
+    uint32_t* q_bases[2] = {nullptr, nullptr};  // segment bases, nb + 1 entries
+    uint32_t q_nb[2] = {1, 1};    // segments of each queue (1 = written densely by camera() / upload)
+    uint32_t* d_block = nullptr;  // per-workgroup output counts of the shading kernel
     uint32_t* d_cnt = nullptr;    // [0] current count, [1] next count, [2] chain pool cursor
     float4* hit0 = nullptr;       // head of chain per ray: u, v, t, tri
     uint32_t* hitN = nullptr;     // chain length | pool offset << 4
@@ -207,6 +207,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
 int launch_rt_sample(psm_rt* r, psm_rt* src);
 int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b);
+int launch_rt_gather_queue(psm_rt* r, float4* d_dense, uint32_t m);  // current queue in queue order: A | B | C, m rays each
 uint32_t tile_texel_count(const psm_rt* r);
 
 }  // namespace psm

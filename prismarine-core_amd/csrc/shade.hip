@@ -22,7 +22,7 @@ namespace psm {
 constexpr float TWO_PI_F = 6.2831853071795864769252867665590057683943f;
 constexpr float SQRT_OF_ONE_THIRD_F = 0.5773502691896257645091487805019574556476f;
 constexpr int SHADE_BLOCK = 256;
-constexpr int SHADE_SEG = SHADE_BLOCK * 4;
+static_assert(QUEUE_SEG == SHADE_BLOCK * 4, "one segment holds a shading workgroup's output rays");
 
 // ray bitfield, include/structs.glsl:73-78
 PSM_HD int bf_get(int bf, int off, int bits) { return (bf >> off) & ((1 << bits) - 1); }
@@ -95,9 +95,10 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
                                                  Tile tile, uint32_t nrays, float4* __restrict__ qA,
                                                  float4* __restrict__ qB, float4* __restrict__ qC,
                                                  float2* __restrict__ t_coord, float4* __restrict__ t_sum,
-                                                 int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt, int enable360) {
+                                                 int32_t* __restrict__ t_flag, uint32_t* __restrict__ cnt,
+                                                 uint32_t* __restrict__ qbases, int enable360) {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k == 0) { cnt[0] = nrays; cnt[1] = 0; cnt[2] = 0; }
+    if (k == 0) { cnt[0] = nrays; cnt[1] = 0; cnt[2] = 0; qbases[0] = 0; qbases[1] = nrays; }  // the primary queue is one dense segment
     if (k >= nrays) return;
     uint32_t x = k % w, y = tile_owned_row(tile, k / w);
     uint32_t idx = y * w + x;
@@ -412,7 +413,7 @@ PSM_D bool create_ray(WRay& r, int texel, uint32_t pkey, OutRay& o, float4* __re
 }
 
 struct ShadeArgs {
-    const float4 *qA, *qB, *qC;
+    RayQueue q;  // the rays to shade
     const float4* hit0;
     const uint32_t* hitN;
     const float4* pool;
@@ -440,7 +441,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     OutRay outs[4];
     uint32_t nout = 0;
     if (it < a.nrays) {
-        float4 A = a.qA[it], B = a.qB[it], C = a.qC[it];
+        const uint32_t loc = queue_loc(a.q.bases, a.q.nb, a.nrays, it);
+        float4 A = a.q.A[loc], B = a.q.B[loc], C = a.q.C[loc];
         int in_texel = __float_as_int(A.w);
         uint32_t in_pkey = __float_as_uint(C.w);
         Rng g{in_pkey, 0u, a.time << 5};
@@ -663,10 +665,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
             }
         }
     }
-    // ordered block compaction into this block's staging segment
+    // ordered compaction into this workgroup's segment of the next queue
     uint32_t total;
     uint32_t base = block_scan_excl<SHADE_BLOCK>(nout, scan_tmp, &total);
-    size_t seg = (size_t)blockIdx.x * SHADE_SEG;
+    size_t seg = (size_t)blockIdx.x * QUEUE_SEG;
     for (uint32_t k = 0; k < nout; k++) {
         a.sA[seg + base + k] = outs[k].A;
         a.sB[seg + base + k] = outs[k].B;
@@ -675,24 +677,26 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     if (threadIdx.x == 0) a.blockCounts[blockIdx.x] = total;
 }
 
-// reloadQueuedRays, Pipeline.inl:325-359: next count (clamped to currentRayLimit), pool cursor reset
-__global__ __launch_bounds__(1024) void rt_scan_blocks(uint32_t* __restrict__ g, uint32_t nb, uint32_t limit,
-                                                       uint32_t* __restrict__ cnt, DevCounters* __restrict__ ctr) {
+// reloadQueuedRays, Pipeline.inl:325-359: next count (clamped to currentRayLimit), pool cursor reset -- and the segment
+// bases of the next queue (exclusive scan of the workgroups' output counts; bases[nb] = total)
+__global__ __launch_bounds__(1024) void rt_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t limit,
+                                                       uint32_t* __restrict__ bases, uint32_t* __restrict__ cnt,
+                                                       DevCounters* __restrict__ ctr) {
     __shared__ uint32_t tmp[32];
     uint32_t tid = threadIdx.x;
     uint32_t chunk = (nb + 1023u) / 1024u;
     uint32_t s = min(tid * chunk, nb), e = min(s + chunk, nb);
     uint32_t sum = 0;
-    for (uint32_t i = s; i < e; i++) sum += g[i];
+    for (uint32_t i = s; i < e; i++) sum += counts[i];
     uint32_t total;
     uint32_t run = block_scan_excl<1024>(sum, tmp, &total);
     for (uint32_t i = s; i < e; i++) {
-        uint32_t v = g[i];
-        g[nb + i] = run;  // bases stored after the counts
-        run += v;
+        bases[i] = run;
+        run += counts[i];
     }
     if (tid == 0) {
-        uint32_t next = total < limit ? total : limit;
+        bases[nb] = total;
+        uint32_t next = total < limit ? total : limit;  // canonical overflow rule: rays past currentRayLimit are dropped
         if (total > limit) atomicAdd(&ctr->ray_limit_drops, (unsigned long long)(total - limit));
         cnt[1] = next;
         cnt[0] = next;
@@ -700,22 +704,14 @@ __global__ __launch_bounds__(1024) void rt_scan_blocks(uint32_t* __restrict__ g,
     }
 }
 
-__global__ __launch_bounds__(SHADE_BLOCK) void rt_compact(const float4* __restrict__ sA, const float4* __restrict__ sB,
-                                                          const float4* __restrict__ sC,
-                                                          const uint32_t* __restrict__ blocks, uint32_t nb,
-                                                          uint32_t limit, float4* __restrict__ qA,
-                                                          float4* __restrict__ qB, float4* __restrict__ qC) {
-    uint32_t b = blockIdx.x;
-    uint32_t count = blocks[b], base = blocks[nb + b];
-    size_t seg = (size_t)b * SHADE_SEG;
-    for (uint32_t j = threadIdx.x; j < count; j += SHADE_BLOCK) {
-        uint32_t dst = base + j;
-        if (dst < limit) {  // canonical overflow rule: drop past currentRayLimit
-            qA[dst] = sA[seg + j];
-            qB[dst] = sB[seg + j];
-            qC[dst] = sC[seg + j];
-        }
-    }
+// the current queue in queue order (debug / parity download): A | B | C, m rays each
+__global__ __launch_bounds__(256) void rt_gather_queue(RayQueue q, uint32_t total, uint32_t m, float4* __restrict__ dense) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t loc = queue_loc(q.bases, q.nb, total, i);
+    dense[i] = q.A[loc];
+    dense[(size_t)m + i] = q.B[loc];
+    dense[2 * (size_t)m + i] = q.C[loc];
 }
 
 // ---- sampler.comp:37-97 + deinterlace/filter copies ----------------------------------------------
@@ -813,15 +809,28 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
     uint32_t nrays = tile_texel_count(r);
     if (nrays)
         rt_camera<<<(nrays + 255) / 256, 256, 0, c->stream>>>(ci, pi, time, r->w, r->h, make_tile(r), nrays, r->qA[r->cur], r->qB[r->cur],
-                                                          r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt, r->enable360);
+                                                          r->qC[r->cur], r->t_coord, r->t_sum, r->t_flag, r->d_cnt, r->q_bases[r->cur], r->enable360);
     else
-        PSM_HIP(c, hipMemsetAsync(r->d_cnt, 0, 3 * sizeof(uint32_t), c->stream));
+        { PSM_HIP(c, hipMemsetAsync(r->d_cnt, 0, 3 * sizeof(uint32_t), c->stream)); PSM_HIP(c, hipMemsetAsync(r->q_bases[r->cur], 0, 2 * sizeof(uint32_t), c->stream)); }
     if (r->tile_root && nrays < n)
         rt_camera_rest<<<(n + 255) / 256, 256, 0, c->stream>>>(time, r->w, r->h, make_tile(r), r->t_coord, r->t_sum, r->t_flag);
     PSM_HIP(c, hipGetLastError());
     r->ray_count = nrays;
     r->count_valid = true;
     r->trav_n = 0;
+    r->q_nb[r->cur] = 1;
+    return PSM_OK;
+}
+
+static RayQueue current_queue(const psm_rt* r) {
+    return RayQueue{r->qA[r->cur], r->qB[r->cur], r->qC[r->cur], r->q_bases[r->cur], r->q_nb[r->cur]};
+}
+
+int launch_rt_gather_queue(psm_rt* r, float4* d_dense, uint32_t m) {
+    psm_ctx* c = r->ctx;
+    if (m == 0) return PSM_OK;
+    rt_gather_queue<<<(m + 255) / 256, 256, 0, c->stream>>>(current_queue(r), r->ray_count, m, d_dense);
+    PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }
 
@@ -831,11 +840,12 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     if (n == 0) return PSM_OK;
     uint32_t nb = (n + SHADE_BLOCK - 1) / SHADE_BLOCK;
     ShadeArgs a;
-    a.qA = r->qA[r->cur]; a.qB = r->qB[r->cur]; a.qC = r->qC[r->cur];
+    a.q = current_queue(r);
     a.hit0 = r->hit0; a.hitN = r->hitN; a.pool = r->pool;
     a.src.tri48 = b->d_tri48; a.src.nrm = b->d_nrm; a.src.tri_mats = b->d_mats; a.src.uv = b->d_tex;
     a.src.mats = r->d_mats; a.src.tex = r->d_tex_table; a.lights = r->d_lights;
-    a.sA = r->sA; a.sB = r->sB; a.sC = r->sC;
+    const int nxt_q = r->cur ^ 1;
+    a.sA = r->qA[nxt_q]; a.sB = r->qB[nxt_q]; a.sC = r->qC[nxt_q];  // every workgroup writes its own segment of the next queue
     a.blockCounts = r->d_block;
     a.t_sum = r->t_sum; a.t_flag = r->t_flag;
     a.nrays = n; a.time = time;
@@ -861,10 +871,9 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
         else if (any_tex) rt_shade<true, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         else if (multi) rt_shade<false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         else rt_shade<false, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->d_cnt, c->d_counters);
-        rt_compact<<<nb, SHADE_BLOCK, 0, c->stream>>>(r->sA, r->sB, r->sC, r->d_block, nb, r->limit, r->qA[nxt], r->qB[nxt],
-                                                      r->qC[nxt]);
+        rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->q_bases[nxt], r->d_cnt, c->d_counters);
     }
+    r->q_nb[nxt] = nb;
     PSM_HIP(c, hipGetLastError());
     r->cur = nxt;
     r->count_valid = false;

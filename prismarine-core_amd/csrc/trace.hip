@@ -97,6 +97,7 @@ struct Baked {
 // tests in the same order -- so hits, chains and counters are bit-exact; only the idle lanes go.
 template <bool COUNT, bool CHAIN, bool PHASED>
 __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __restrict__ qA, const float4* __restrict__ qB,
+                                                          const uint32_t* __restrict__ qbases, uint32_t qnb,
                                                           uint32_t nrays, const uint4* __restrict__ node32,
                                                           const float4* __restrict__ tri48,
                                                           const uint32_t* __restrict__ sm, float4* __restrict__ hit0,
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     uint32_t i = slot;
     if (resume) i = alive ? ph.in.idx()[slot] : 0u;
 
-    float4 A = alive ? qA[i] : make_float4(0, 0, 0, 0);
-    float4 B = alive ? qB[i] : make_float4(1, 0, 0, 0);
+    const uint32_t loc = alive ? queue_loc(qbases, qnb, nrays, i) : 0u;  // the queue is segmented (psm_common.h)
+    float4 A = alive ? qA[loc] : make_float4(0, 0, 0, 0);
+    float4 B = alive ? qB[loc] : make_float4(1, 0, 0, 0);
     v3 origin = mk3(A.x, A.y, A.z);
     v3 direct = normalize3(mk3(B.x, B.y, B.z));  // :350
 
@@ -472,7 +474,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     const int mode = plan_traverse(r, n, chain, plan);
     {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
-#define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
+#define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], r->q_bases[r->cur], r->q_nb[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
                       r->pool_cap, r->d_cnt, c->d_counters, tag
         if (mode == PSM_TRAVERSE_WHOLE) {
             TimedScope ts(c, CAT_TRAVERSE);
