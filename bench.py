@@ -319,8 +319,11 @@ def roofline(st, Rr, V, T, copy_gbs, scene, width, height, lanes_mode):
     out = {"bound": "unknown: no committed PMC pass for this workload", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "launches": int(st.traverse_launches),
            "avg_launch_ms": avg_ms,
-           "measured": ("kernel pass: the timed region's frames one after another, HIP events per launch on the launching "
-                        "stream (with frames in flight launches of different streams overlap)") if lanes_mode
+           "measured": ("kernel pass: the timed region's frames one after another on one stream, HIP events per launch: the "
+                        "single-launch traversal kernel running alone. The timed region itself keeps several frames in "
+                        "flight, whose intersections run the same per-ray loop as the ballot-triggered hand-over schedule "
+                        "(rt_traverse<false,false,true>, <= 3 launches per round, overlapping other frames' kernels), which "
+                        "has no per-launch time of its own to price") if lanes_mode
                        else "timed region, HIP events per launch",
            "algorithmic_bytes_per_launch": alg, "own_record_bytes_per_launch": own,
            "own_record_gbs": own / sec / 1e9 if sec > 0 else 0.0,

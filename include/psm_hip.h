@@ -233,7 +233,10 @@ int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
  *   ADAPTIVE    the same hand-over, triggered per wave by __ballot / popcount: a wave hands over as soon as fewer
  *               than min_live of its lanes have work left; resume launches are persistent waves striding over the
  *               continuation queue (psm_rt_set_traverse_adaptive)
- *   AUTO        the library's choice (default). Further hierarchies of a multi-BVH queue always run WHOLE. */
+ *   AUTO        (default) ADAPTIVE while the Pipeline is one of several frames in flight (psm_lanes_*: the other frames'
+ *               kernels fill the tails the extra launches add; +11 % on C3), WHOLE for a frame on its own (it is bound
+ *               by its longest ray, which extra launches serialise) and for intersections under min_rays rays.
+ *               Further hierarchies of a multi-BVH queue always run WHOLE. */
 enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3 };
 int psm_rt_set_traverse_mode(psm_rt* rt, int mode);
 /* PHASED: count caps (1..7) -> count + 1 launches, for intersections over at least min_rays rays; count = 0 selects
@@ -241,7 +244,8 @@ int psm_rt_set_traverse_mode(psm_rt* rt, int mode);
 int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count, uint32_t min_rays);
 /* ADAPTIVE parameters (does not change the mode): hand over below min_live live lanes (2..64) but not before
  * min_steps wave-steps; a resume launch that finds at most final_rays rays waiting finishes them; at most
- * max_launches launches (2..15) per intersection; intersections under min_rays rays run WHOLE. */
+ * max_launches launches (2..15) per intersection; intersections under min_rays rays run WHOLE.
+ * Defaults: 12, 8, 65536, 3, 2^18. */
 int psm_rt_set_traverse_adaptive(psm_rt* rt, uint32_t min_live, uint32_t min_steps, uint32_t final_rays,
                                  uint32_t max_launches, uint32_t min_rays);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */

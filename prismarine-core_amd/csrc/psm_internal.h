@@ -166,9 +166,9 @@ struct psm_rt {
     uint32_t phase_caps[7] = {96};  // PSM_TRAVERSE_PHASED: wave-step caps of the launches before the last one
     int phase_caps_n = 1;
     int trav_mode = 0;              // PSM_TRAVERSE_* (psm_rt_set_traverse_mode); 0 = automatic
-    uint32_t adapt_min_live = 16, adapt_min_steps = 8, adapt_final_rays = 4096, adapt_max_launches = 8;
+    uint32_t adapt_min_live = 12, adapt_min_steps = 8, adapt_final_rays = 65536, adapt_max_launches = 3;  // tuned on C3, 4 frames in flight
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
-    uint32_t phase_min_rays = 1u << 20;
+    uint32_t phase_min_rays = 1u << 18;  // smaller intersections run as one launch
     // frames in flight (lanes.hip): pinned slot + events, created on first use
     uint32_t* h_cnt = nullptr;
     hipEvent_t ev_cnt = nullptr, ev_fold = nullptr;

@@ -95,15 +95,45 @@ struct Baked {
 // launch resumes them packed 64 to a wave. Resume launches are persistent: a fixed grid of waves strides over
 // the continuation queue, 64 rays at a time. Per ray nothing changes -- the same node steps and triangle
 // tests in the same order -- so hits, chains and counters are bit-exact; only the idle lanes go.
+// All arguments of the kernel in one struct. The hot loop needs a few of them (queue, node and triangle arrays);
+// the rest -- result arrays, counters, the hand-over state -- are read where they are used, through the kernarg
+// segment, behind an opaque move (cold_args): held in scalar registers from the kernel's entry they would cost the
+// loop ~30 SGPRs, whose spills take two VGPRs from a kernel that is allowed 64 (8 waves per SIMD).
+struct TravArgs {
+    const float4 *qA, *qB;        // hot
+    const uint32_t* qbases;
+    uint32_t qnb, nrays;
+    const uint4* node32;
+    const float4* tri48;
+    const uint32_t* sm;
+    uint32_t cap, min_live, min_steps, final_rays;  // Phase, hot part
+    const uint32_t* in_count;
+    float4* hit0;                 // cold from here on
+    uint32_t* hitN;
+    float4* pool;
+    uint32_t* cnt;
+    DevCounters* ctr;
+    uint32_t pool_cap, obj_tag;
+    TravState in, out;
+    uint32_t* out_count;
+};
+
+PSM_D const TravArgs* cold_args() {
+    unsigned long long zero;  // an opaque 0: whatever is loaded through the sum cannot be hoisted above this point
+    asm volatile("s_mov_b64 %0, 0" : "=s"(zero));
+    return (const TravArgs*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + zero);
+}
+
 template <bool COUNT, bool CHAIN, bool PHASED>
-__global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __restrict__ qA, const float4* __restrict__ qB,
-                                                          const uint32_t* __restrict__ qbases, uint32_t qnb,
-                                                          uint32_t nrays, const uint4* __restrict__ node32,
-                                                          const float4* __restrict__ tri48,
-                                                          const uint32_t* __restrict__ sm, float4* __restrict__ hit0,
-                                                          uint32_t* __restrict__ hitN, float4* __restrict__ pool,
-                                                          uint32_t pool_cap, uint32_t* __restrict__ cnt,
-                                                          DevCounters* __restrict__ ctr, uint32_t obj_tag, Phase ph) {
+__global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
+    const float4* __restrict__ qA = ka.qA;
+    const float4* __restrict__ qB = ka.qB;
+    const uint32_t* __restrict__ qbases = ka.qbases;
+    const uint32_t qnb = ka.qnb, nrays = ka.nrays;
+    const uint4* __restrict__ node32 = ka.node32;
+    const float4* __restrict__ tri48 = ka.tri48;
+    const uint32_t* __restrict__ sm = ka.sm;
+    struct { uint32_t cap, min_live, min_steps, final_rays; const uint32_t* in_count; } ph = {ka.cap, ka.min_live, ka.min_steps, ka.final_rays, ka.in_count};
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
     const int tid = threadIdx.x;
     const bool resume = PHASED && ph.in_count != nullptr;
@@ -120,7 +150,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     const uint32_t slot = batch + (uint32_t)(tid & 63);
     bool alive = slot < total;
     uint32_t i = slot;
-    if (resume) i = alive ? ph.in.idx()[slot] : 0u;
+    if (resume) i = alive ? cold_args()->in.idx()[slot] : 0u;
 
     const uint32_t loc = alive ? queue_loc(qbases, qnb, nrays, i) : 0u;  // the queue is segmented (psm_common.h)
     float4 A = alive ? qA[loc] : make_float4(0, 0, 0, 0);
@@ -167,7 +197,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     // hit state (TResult + bakedStack, :27-45)
     float predist = INF;
     if (CHAIN) {
-        if (alive && (hitN[i] & 15u) != 0u) predist = hit0[i].z;
+        const TravArgs* K = cold_args();
+        if (alive && (K->hitN[i] & 15u) != 0u) predist = K->hit0[i].z;
     }
     int lastTri = -1;
     int bakedCount = 0;
@@ -178,16 +209,17 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     int sp = 0;
     int it = 0;
     if (resume && alive) {  // pick the ray up where the previous launch left it
-        uint32_t m = ph.in.misc()[slot];
-        cur = ph.in.cur()[slot];
+        const TravState in = cold_args()->in;
+        uint32_t m = in.misc()[slot];
+        cur = in.cur()[slot];
         sp = (int)(m & 255u);
         it = (int)((m >> 8) & 0xFFFFu);
         bakedCount = (int)(m >> 24);
-        predist = ph.in.predist()[slot];
-        lastTri = ph.in.lastTri()[slot];
-        float4 hd = ph.in.head()[slot];
+        predist = in.predist()[slot];
+        lastTri = in.lastTri()[slot];
+        float4 hd = in.head()[slot];
         head.u = hd.x; head.v = hd.y; head.t = hd.z; head.tri = __float_as_int(hd.w);
-        for (int k = 0; k < sp; k++) stack[k][tid] = ph.in.stack()[(size_t)k * ph.in.capacity + slot];
+        for (int k = 0; k < sp; k++) stack[k][tid] = in.stack()[(size_t)k * in.capacity + slot];
         validBox = true;
     }
     uint32_t wsteps = 0;
@@ -288,19 +320,21 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
             const bool susp = validBox && bakedCount <= 1;
             const unsigned long long sb = __ballot(susp);
             if (sb != 0ull) {
+                const TravArgs* K = cold_args();
+                const TravState out = K->out;
                 uint32_t base = 0;
                 const int leader = __ffsll((long long)sb) - 1;
-                if (lane_id() == leader) base = atomicAdd(ph.out_count, (uint32_t)__popcll(sb));
+                if (lane_id() == leader) base = atomicAdd(K->out_count, (uint32_t)__popcll(sb));
                 base = __shfl(base, leader);
                 if (susp) {
                     const uint32_t o = base + (uint32_t)__popcll(sb & ((1ull << lane_id()) - 1ull));
-                    ph.out.idx()[o] = i;
-                    ph.out.cur()[o] = cur;
-                    ph.out.misc()[o] = (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24);
-                    ph.out.predist()[o] = predist;
-                    ph.out.lastTri()[o] = lastTri;
-                    ph.out.head()[o] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
-                    for (int k = 0; k < sp; k++) ph.out.stack()[(size_t)k * ph.out.capacity + o] = stack[k][tid];
+                    out.idx()[o] = i;
+                    out.cur()[o] = cur;
+                    out.misc()[o] = (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24);
+                    out.predist()[o] = predist;
+                    out.lastTri()[o] = lastTri;
+                    out.head()[o] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
+                    for (int k = 0; k < sp; k++) out.stack()[(size_t)k * out.capacity + o] = stack[k][tid];
                     validBox = false;
                     suspended = true;
                 }
@@ -309,6 +343,13 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
         }
     }
     if (PHASED && suspended) alive = false;  // its result is written by the launch that finishes it
+    const TravArgs* K = cold_args();
+    float4* __restrict__ hit0 = K->hit0;
+    uint32_t* __restrict__ hitN = K->hitN;
+    float4* __restrict__ pool = K->pool;
+    uint32_t* __restrict__ cnt = K->cnt;
+    DevCounters* __restrict__ ctr = K->ctr;
+    const uint32_t pool_cap = K->pool_cap, obj_tag = K->obj_tag;
 
     if (CHAIN) {
         if (alive && bakedCount > 0) {
@@ -395,6 +436,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(const float4* __res
     if (!resume) break;
     }  // batches
     if (COUNT) {
+        DevCounters* ctr = cold_args()->ctr;
         uint32_t v = wave_sum(nV), t = wave_sum(nT), d = wave_sum(nDrop), c = wave_sum(nCap), b = wave_sum(nBakedDrop);
         if (lane_id() == 0) {
             atomicAdd(&ctr->wave_clock_ticks, (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
@@ -440,10 +482,11 @@ static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<Ph
     plan.clear();
     int mode = r->trav_mode;
     if (chain) return PSM_TRAVERSE_WHOLE;  // later hierarchies of a multi-BVH queue: rt_traverse<*, CHAIN>
-    // AUTO: one launch. Measured on MI355X: the hand-over schedules cut the VALU instructions of a
-    // frame by a quarter and lift lane utilisation from 36 % to 52 %, but every schedule ends at the same ~115 G
-    // node visits / s (the divergent 32-byte gathers), and their extra launches serialise the long rays' tails.
-    if (mode == PSM_TRAVERSE_AUTO) mode = PSM_TRAVERSE_WHOLE;
+    // AUTO, measured on MI355X: with several frames in flight the ballot-triggered hand-over wins
+    // (2.78-2.82 against 3.11-3.17 ms per C3 frame: 31 % fewer VALU instructions, and the other frames' kernels fill
+    // the tails its extra launches add); a frame on its own is bound by its longest ray, which the extra launches
+    // serialise (5.0 against 3.6 ms of traversal), so it runs one launch.
+    if (mode == PSM_TRAVERSE_AUTO) mode = r->in_flight > 1 ? PSM_TRAVERSE_ADAPTIVE : PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_PHASED) {
         for (int k = 0; k < r->phase_caps_n; k++) plan.push_back(PhasePlan{r->phase_caps[k], 0u});
@@ -474,18 +517,20 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     const int mode = plan_traverse(r, n, chain, plan);
     {
         uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
-#define PSM_TRAV_ARGS r->qA[r->cur], r->qB[r->cur], r->q_bases[r->cur], r->q_nb[r->cur], n, b->d_node32, b->d_tri48, b->d_small, r->hit0, r->hitN, r->pool, \
-                      r->pool_cap, r->d_cnt, c->d_counters, tag
+        TravArgs ta = {};
+        ta.qA = r->qA[r->cur]; ta.qB = r->qB[r->cur]; ta.qbases = r->q_bases[r->cur]; ta.qnb = r->q_nb[r->cur]; ta.nrays = n;
+        ta.node32 = b->d_node32; ta.tri48 = b->d_tri48; ta.sm = b->d_small;
+        ta.hit0 = r->hit0; ta.hitN = r->hitN; ta.pool = r->pool; ta.cnt = r->d_cnt; ta.ctr = c->d_counters;
+        ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
+        ta.cap = 0xFFFFFFFFu;
         if (mode == PSM_TRAVERSE_WHOLE) {
             TimedScope ts(c, CAT_TRAVERSE);
-            Phase none = {};
-            none.cap = 0xFFFFFFFFu;
             if (chain) {
-                if (c->counting) rt_traverse<true, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
-                else rt_traverse<false, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
+                if (c->counting) rt_traverse<true, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
+                else rt_traverse<false, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
             } else {
-                if (c->counting) rt_traverse<true, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
-                else rt_traverse<false, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, none);
+                if (c->counting) rt_traverse<true, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
+                else rt_traverse<false, false, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
             }
         } else {
             // launch p hands unfinished rays to launch p+1 through a dense continuation queue; the last launch runs
@@ -497,7 +542,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
             PSM_HIP(c, hipMemsetAsync(r->d_phase_cnt, 0, sizeof(uint32_t) * MAX_PHASES, c->stream));
             uint64_t bound = n;
             for (size_t p = 0; p < np; p++) {
-                Phase ph;
+                TravArgs ph = ta;
                 ph.cap = p < plan.size() ? plan[p].cap : 0xFFFFFFFFu;
                 ph.min_live = p < plan.size() ? plan[p].min_live : 0u;
                 ph.min_steps = r->adapt_min_steps;
@@ -513,12 +558,11 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
                     if (g == 0) g = 1;
                 }
                 TimedScope ts(c, CAT_TRAVERSE);
-                if (c->counting) rt_traverse<true, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
-                else rt_traverse<false, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(PSM_TRAV_ARGS, ph);
+                if (c->counting) rt_traverse<true, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
+                else rt_traverse<false, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
                 if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);
             }
         }
-#undef PSM_TRAV_ARGS
     }
     PSM_HIP(c, hipGetLastError());
     c->rays_traced += n;
