@@ -289,7 +289,7 @@ VALU_QUAD_CYCLES = 4.0       # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MI
 SIMDS = 1024
 
 
-def pmc_entry(scene, width, height, kernel):
+def pmc_entry(scene, width, height, kernel, which=None):
     """Per-launch PMC figures of `kernel` for this workload from the committed rocprofv3 passes (profiles/collect.sh ->
     profiles/make_traffic.py): bench.py cannot run the profiler on itself."""
     for name in ("traffic_r02.json",):
@@ -298,7 +298,8 @@ def pmc_entry(scene, width, height, kernel):
         except (OSError, ValueError):
             continue
         for e in d.get("entries", []):
-            if (e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel):
+            if ((e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel)
+                    and e.get("pass") == which):
                 return e, "profiles/" + name
     return None, None
 
@@ -349,6 +350,10 @@ def roofline(st, Rr, V, T, copy_gbs, scene, width, height, lanes_mode):
         out["valu_issue_utilisation"] = sq["SQ_ACTIVE_INST_VALU"] * VALU_QUAD_CYCLES / SIMDS / (e["kernel_trace_avg_us"] * 1e-6 * 2.4e9)
         out["valu_lane_utilisation"] = e.get("valu_lane_utilisation")
         out["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU")
+    t, _ = pmc_entry(scene, width, height, "rt_traverse<false, false, true>", "as timed (frames in flight)")
+    if t is not None and lanes_mode:
+        # the hand-over kernels the timed region runs: lane utilisation over all their launches (SQ pass of the bench as timed)
+        out["timed_schedule_valu_lane_utilisation"] = t.get("valu_lane_utilisation")
     if hbm_frac is not None and traffic >= 0.5 * own:
         out["bound"] = "hbm" if hbm_frac >= 0.4 else "hbm latency (HBM-resident records, divergent 32-byte gathers)"
     else:

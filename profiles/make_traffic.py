@@ -78,6 +78,17 @@ def main():
             e["source"] = ("rocprofv3 --pmc passes of profiles/collect.sh %s (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own "
                            "pass, --lanes 1), bench.py --scene %s --width %d --height %d" % (tag, scene, w, h))
             entries.append(e)
+        # the schedule of the timed region (frames in flight): the SQ pass of the bench as timed, per traversal kernel
+        sq4 = per_kernel(tag, "sq4", "rt_traverse")
+        for k in sorted(sq4):
+            c = sq4[k]
+            if "SQ_ACTIVE_INST_VALU" not in c:
+                continue
+            act, thr, ins = c["SQ_ACTIVE_INST_VALU"], c.get("SQ_THREAD_CYCLES_VALU", [0, 0.0]), c.get("SQ_INSTS_VALU", [0, 0.0])
+            entries.append({"scene": scene, "width": w, "height": h, "kernel": k, "pass": "as timed (frames in flight)",
+                            "launches_sampled": act[0], "valu_insts_total": ins[1], "valu_lane_utilisation": thr[1] / (act[1] * 64.0),
+                            "source": "rocprofv3 --pmc SQ_* pass of profiles/collect.sh %s with the bench's default frames in flight "
+                                      "(5 frames of the timed schedule, then the bench's counting and serial kernel passes)" % tag})
     json.dump({"entries": entries}, open(out_path, "w"), indent=1)
     print("wrote %d entries to %s" % (len(entries), out_path))
 

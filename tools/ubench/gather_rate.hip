@@ -1,0 +1,89 @@
+// gather_rate.hip -- how many dependent 32-byte record fetches per second does gfx950 sustain when every lane of a
+// wave64 chases its own pointer, the way the BVH traversal loop does (two global_load_dwordx4 per record, the next
+// index depends on the loaded data)?  Varies: table size (L2 / Infinity Cache / HBM resident), live lanes per wave,
+// index distribution (uniform, or "tree": a level drawn uniformly, an index uniform within the level, so the upper
+// levels are hot like a BVH's), and VALU padding per step (dependent v_min/v_max pairs, the half-rate kind).
+// Build: hipcc --offload-arch=gfx950 -O3 -o gather_rate gather_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <int LOADS, bool TREE>
+__global__ __launch_bounds__(128, 8) void chase(const uint4* __restrict__ tab, int log2n, int steps, int live, int pad,
+                                                uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    if (lane >= live) return;
+    uint32_t gid = blockIdx.x * 128 + threadIdx.x;
+    uint32_t r = hash32(gid * 2654435761u + 12345u);
+    const uint32_t mask = (1u << log2n) - 1u;
+    uint32_t idx = r & mask;
+    float acc = (float)lane;
+    for (int s = 0; s < steps; s++) {
+        uint4 a = tab[(size_t)idx * 2];
+        uint4 b = LOADS == 2 ? tab[(size_t)idx * 2 + 1] : a;
+        r = hash32(r ^ a.x ^ b.y);
+        for (int p = 0; p < pad; p++) {   // dependent half-rate VALU work, like the slab test's min/max chain
+            acc = fminf(acc, __uint_as_float((a.z & 0x3fffffffu) + p));
+            acc = fmaxf(acc, __uint_as_float((b.w & 0x3fffffffu) + p));
+        }
+        if (TREE) {
+            uint32_t lvl = (r >> 24) % (uint32_t)(log2n + 1);   // level 0..log2n, each equally likely
+            uint32_t base = (lvl == 0) ? 0u : ((1u << lvl) - 1u);
+            idx = (base + ((r >> 2) & ((1u << lvl) - 1u))) & mask;
+        } else {
+            idx = r & mask;
+        }
+    }
+    out[gid] = r ^ __float_as_uint(acc);
+}
+
+template <int LOADS, bool TREE>
+static double run(const uint4* tab, int log2n, int live, int pad, uint32_t* out) {
+    const int grid = 256 * 16, steps = 256;   // 16 workgroups of 128 per CU = 8 waves per SIMD, one generation
+    chase<LOADS, TREE><<<grid, 128>>>(tab, log2n, 8, live, pad, out);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    chase<LOADS, TREE><<<grid, 128>>>(tab, log2n, steps, live, pad, out);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    double recs = (double)grid * 2 * live * steps;
+    return recs / (ms * 1e-3) * 1e-9;   // G records per second
+}
+
+int main() {
+    const int maxlog = 24;   // 16 Mi records x 32 B = 512 MiB
+    std::vector<uint32_t> h((size_t)8 << maxlog);
+    uint32_t s = 1;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = s; }
+    uint4* tab; uint32_t* out;
+    hipMalloc(&tab, h.size() * 4);
+    hipMalloc(&out, 256 * 16 * 128 * 4);
+    hipMemcpy(tab, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    printf("G records/s (32-byte record = 2 x dwordx4 unless noted); 8 waves per SIMD, dependent chain of 256 fetches per lane\n");
+    for (int log2n : {15, 18, 20, 24}) {   // 1 MiB, 8 MiB, 32 MiB, 512 MiB tables
+        for (int tree = 0; tree < 2; tree++) {
+            for (int pad : {0, 24, 48}) {
+                printf("table %4d MiB %-7s pad %2d v_min/max pairs:", (32 << log2n) >> 20, tree ? "tree" : "uniform", pad);
+                for (int live : {8, 16, 32, 48, 64}) {
+                    double g = tree ? run<2, true>(tab, log2n, live, pad, out) : run<2, false>(tab, log2n, live, pad, out);
+                    printf("  live %2d: %6.1f", live, g);
+                }
+                if (pad == 0) {
+                    double g1 = tree ? run<1, true>(tab, log2n, 64, 0, out) : run<1, false>(tab, log2n, 64, 0, out);
+                    printf("  | one dwordx4 per record, live 64: %6.1f", g1);
+                }
+                printf("\n");
+            }
+        }
+    }
+    return 0;
+}
