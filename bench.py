@@ -421,7 +421,14 @@ def main():
     scene = {"sponza_like": scenes.sponza_like, "cornell": scenes.cornell, "stress": scenes.stress}[args.scene]()
     if args.textured:
         scene = scenes.textured(scene)
-    R = Renderer(psm, scenes, scene, args, dist)
+    try:
+        R = Renderer(psm, scenes, scene, args, dist)
+    except pdist.NativeUnavailable as e:
+        # every rank gets this together (Comm.attach_native agrees on it): all fall back to torch.distributed collectives
+        if dist.rank == 0:
+            print("bench: the C ABI's RCCL communicator is unavailable (%s); using torch.distributed collectives" % e, file=sys.stderr)
+        os.environ["PSM_DIST_NATIVE"] = "0"
+        R = Renderer(psm, scenes, scene, args, dist)
     ctx = R.ctx
     lanes_mode = True
 
@@ -523,7 +530,9 @@ def main():
                                        args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth,
                                        R.lanes),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes},
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes,
+                       "collectives": ("none" if not dist.active else
+                                       "psm_dist_* (RCCL from libpsm_hip.so)" if R.native is not None else "torch.distributed " + dist.backend)},
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
             "stage_ms_per_frame_measured": ("kernel pass: the same frames one after another on one stream (serial path; with "

@@ -20,6 +20,11 @@ def tile_rows(rank, world, height):
     return y0, min(y0 + per, height), per
 
 
+class NativeUnavailable(RuntimeError):
+    """The C ABI's RCCL communicator could not be created on some rank; raised on EVERY rank (Comm.attach_native
+    agrees on it), so the caller can fall back to torch.distributed collectives as one."""
+
+
 class NativeDist:
     """The C ABI's own communicator (psm_dist_*, RCCL directly from libpsm_hip.so): the path's one data-path
     collective per frame (gather of the tiles' per-texel radiance to rank 0) and the small all-gather of
@@ -30,11 +35,15 @@ class NativeDist:
         import ctypes as C
         from . import lib
         self._C, self._lib, self.ctx, self.rank, self.world = C, lib(), ctx, rank, world
+        self._h = None
         ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            ctx.check(self._lib.psm_dist_unique_id(ident), "psm_dist_unique_id")
-        raw = bcast_id(bytes(ident) if rank == 0 else None)
-        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        rc = self._lib.psm_dist_unique_id(ident) if rank == 0 else 0
+        # the id always travels (byte 128 = rank 0's return code), so a failure on rank 0 is every rank's failure
+        # instead of a hang in the side channel
+        raw = bcast_id(bytes(ident) + bytes([1 if rc else 0]) if rank == 0 else None)
+        if raw[128]:
+            raise NativeUnavailable("psm_dist_unique_id failed on rank 0 (rc %d)" % rc)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw[:128])
         self._h = C.c_void_p()
         ctx.check(self._lib.psm_dist_init(ctx._h, C.c_int(rank), C.c_int(world), ident, C.byref(self._h)), "psm_dist_init")
 
@@ -102,14 +111,32 @@ class Comm:
             return None
 
         def bcast(raw):
-            t = self.torch.zeros(128, dtype=self.torch.uint8, device=self.dev)
+            t = self.torch.zeros(129, dtype=self.torch.uint8, device=self.dev)
             if raw is not None:
                 t.copy_(self.torch.frombuffer(bytearray(raw), dtype=self.torch.uint8))
             if self.world > 1:
                 self.dist.broadcast(t, src=0)
             return bytes(t.cpu().numpy().tobytes())
-        self.native = NativeDist(ctx, self.rank, self.world, bcast)
+        err = None
+        try:
+            self.native = NativeDist(ctx, self.rank, self.world, bcast)
+        except NativeUnavailable:
+            raise                      # rank 0's failure, already known to every rank
+        except Exception as e:         # this rank's communicator failed: tell the others
+            err = e
+        if self.min_int(0 if err is not None else 1) == 0:
+            if self.native is not None:
+                self.native.close()
+                self.native = None
+            raise NativeUnavailable("psm_dist_init failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
         return self.native
+
+    def min_int(self, v):
+        if not self.active or self.world <= 1:
+            return int(v)
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
 
     def barrier(self):
         if self.active:
