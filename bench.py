@@ -48,6 +48,7 @@ def parse():
                     help="not the headline workload: add texcoords + the procedural texture table (SURVEY f2)")
     ap.add_argument("--depth", type=int, default=16)  # Application.hpp:237
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-build-graph", action="store_true", help="rebuild with plain launches instead of the captured hipGraph (A/B)")
     ap.add_argument("--cpu-sample-rays", type=int, default=3_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--emulate-tile", default=None, help="R/W: render only the tile of rank R of W on one GPU, no communication (Amdahl study)")
@@ -97,6 +98,9 @@ class Renderer:
         self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams)
         self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
         self.batch.allocate(scene["tris"].shape[0])
+        if args.no_build_graph:
+            for ln in self.batch.lanes:
+                ln.th.setBuildGraph(False)
         self.batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
         self.ms = psm.MaterialSet()
         for m in scene["materials"]:

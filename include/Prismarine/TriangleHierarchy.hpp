@@ -40,6 +40,7 @@ namespace NSM {
         void resolve();
         void build(const glm::dmat4 &optimization = glm::dmat4(1.0));
         void configureIntersection(bool clearDepth);
+        void setBuildGraph(bool enable);  // not in the reference: replay rebuilds as one captured hipGraph (default on)
         psm_bvh * handle() { return bvh; }
     };
 }

@@ -31,6 +31,7 @@ namespace NSM {
         triangleCount = 0;
     }
 
+    inline void TriangleHierarchy::setBuildGraph(bool enable) { if (bvh) check(psm_bvh_set_build_graph(bvh, enable ? 1 : 0), "TriangleHierarchy::setBuildGraph"); }
     inline void TriangleHierarchy::configureIntersection(bool clearDepth) { (void)clearDepth; }  // ignored by the reference's shaders too
 
     inline void TriangleHierarchy::loadTriangles(const float * positions, const float * normals, const int32_t * materials, size_t count, const float * texcoords) {

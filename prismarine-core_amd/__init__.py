@@ -23,7 +23,7 @@ EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_copy_bandwidth", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev", "psm_sort_set_algorithm",
-    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build",
+    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
@@ -320,6 +320,10 @@ class TriangleHierarchy:
         opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
         self.ctx.check(lib().psm_bvh_build(self._h, _p(opt) if opt is not None else None), "psm_bvh_build")
         self.resolve()
+
+    def setBuildGraph(self, enable=True):
+        """Replay rebuilds as one captured hipGraph from the second build of a triangle count on (default), or keep plain launches."""
+        self.ctx.check(lib().psm_bvh_set_build_graph(self._h, C.c_int(1 if enable else 0)), "psm_bvh_set_build_graph")
 
     def stage(self, name, optimization=None):
         if name == "bounds":

@@ -257,6 +257,7 @@ int psm_bvh_destroy(psm_bvh* b) {
     dev_free(b->d_keys); dev_free(b->d_idx); dev_free(b->d_leafbox); dev_free(b->d_leaftri);
     dev_free(b->d_block); dev_free(b->d_small); dev_free(b->d_opt); dev_free(b->d_seg);
     dev_free(b->d_sorted_tri); dev_free(b->d_pairbox); dev_free(b->d_link); dev_free(b->d_range); dev_free(b->d_node32);
+    if (b->build_graph) (void)hipGraphExecDestroy(b->build_graph);
     delete b;
     return PSM_OK;
 }
@@ -413,14 +414,86 @@ int psm_bvh_stage_emit(psm_bvh* b) {
     if (rc == PSM_OK) b->built = true;
     return rc;
 }
-int psm_bvh_build(psm_bvh* b, const double* opt) {
-    if (!b) return PSM_ERR_INVALID;
+static int bvh_build_plain(psm_bvh* b, const double* opt) {
     TimedScope ts(b->ctx, CAT_BUILD);
     int rc = psm_bvh_stage_bounds(b, opt);
     if (rc == PSM_OK) rc = psm_bvh_stage_morton(b);
     if (rc == PSM_OK) rc = psm_bvh_stage_sort(b);
     if (rc == PSM_OK) rc = psm_bvh_stage_emit(b);
     return rc;
+}
+
+static void bvh_drop_graph(psm_bvh* b) {
+    if (b->build_graph) (void)hipGraphExecDestroy(b->build_graph);
+    b->build_graph = nullptr;
+}
+
+// Capture the build's launches (bounds, Morton + leaves, the sort's passes, segment tree, emit: 36 at C3) on the
+// context's stream into one executable graph. Every argument is a device pointer of this hierarchy / context or a
+// function of the triangle count, so the graph stays valid until one of them changes (checked by the caller).
+static int bvh_capture_graph(psm_bvh* b) {
+    psm_ctx* c = b->ctx;
+    bvh_drop_graph(b);
+    int rc = sort_reserve(c, b->tri_count);  // nothing may be allocated while the stream is capturing
+    if (rc != PSM_OK) return rc;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return PSM_ERR_HIP; }
+    rc = launch_bvh_bounds(b);
+    if (rc == PSM_OK) rc = launch_bvh_morton(b);
+    if (rc == PSM_OK) rc = launch_sort(c, b->d_keys, b->d_idx, b->tri_count, b->d_small + SM_COUNT);
+    if (rc == PSM_OK) rc = launch_bvh_emit(b);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (rc == PSM_OK && e == hipSuccess && g) e = hipGraphInstantiate(&b->build_graph, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (rc != PSM_OK || e != hipSuccess || !b->build_graph) {
+        (void)hipGetLastError();
+        b->build_graph = nullptr;
+        return rc != PSM_OK ? rc : PSM_ERR_HIP;
+    }
+    b->graph_error_word = c->sort_error_word;  // what launch_sort left for sort_check (one-sweep: its timeout word)
+    return PSM_OK;
+}
+
+int psm_bvh_build(psm_bvh* b, const double* opt) {
+    if (!b) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    // The graph belongs to (triangle count, sort algorithm, generation of the context's sort buffers).
+    if (b->graph_tris != b->tri_count || b->graph_algo != c->sort_algorithm || b->graph_sort_gen != c->sort_gen) {
+        bvh_drop_graph(b);
+        b->plain_builds = 0;
+    }
+    // Plain launches: the first build of a configuration (a scene that is built once gains nothing from a capture, and
+    // it allocates the sort's buffers), per-stage timing (events between the stages), or graphs switched off.
+    if (!b->use_graph || c->timing || b->tri_count == 0 || b->plain_builds == 0) {
+        int rc = bvh_build_plain(b, opt);
+        b->plain_builds = (rc == PSM_OK) ? b->plain_builds + 1 : 0;
+        b->graph_tris = b->tri_count, b->graph_algo = c->sort_algorithm, b->graph_sort_gen = c->sort_gen;
+        return rc;
+    }
+    (void)hipSetDevice(c->device);
+    static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    PSM_HIP(c, hipMemcpyAsync(b->d_opt, opt ? opt : ident, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (opt) PSM_HIP(c, hipStreamSynchronize(c->stream));  // the caller's matrix may be a temporary
+    if (!b->build_graph && bvh_capture_graph(b) != PSM_OK) {  // no graph on this runtime / stream: plain launches from now on
+        b->use_graph = false;
+        return bvh_build_plain(b, opt);
+    }
+    if (hipGraphLaunch(b->build_graph, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        bvh_drop_graph(b);
+        b->use_graph = false;
+        return bvh_build_plain(b, opt);
+    }
+    c->sort_error_word = b->graph_error_word;
+    b->bounds_done = b->morton_done = b->sort_done = b->built = true;
+    return PSM_OK;
+}
+
+int psm_bvh_set_build_graph(psm_bvh* b, int enable) {
+    if (!b) return PSM_ERR_INVALID;
+    b->use_graph = enable != 0;
+    if (!b->use_graph) bvh_drop_graph(b);
+    return PSM_OK;
 }
 
 int psm_bvh_get_info(psm_bvh* b, psm_bvh_info* info) {

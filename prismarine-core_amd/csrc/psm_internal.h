@@ -87,6 +87,7 @@ struct psm_ctx {
     uint32_t* sort_vals_tmp = nullptr;
     uint32_t* sort_hist = nullptr;
     size_t sort_cap = 0, sort_hist_cap = 0;
+    uint32_t sort_gen = 0;              // bumped whenever a sort buffer is reallocated (captured build graphs hold the pointers)
     int sort_algorithm = 0;             // 0: histogram / scan / scatter kernels per pass (default: measured faster); 1: one-sweep
     uint32_t* sort_error_word = nullptr; // device word the look-back raises on a spin timeout
 };
@@ -117,6 +118,12 @@ struct psm_bvh {
     int2* d_link = nullptr;
     int2* d_range = nullptr;
     uint4* d_node32 = nullptr;    // traversal record per internal node: 12 fp16 box coords + 2 links (32 B)
+    // the build as one hipGraph (36 launches at C3): captured on the second build of a triangle count, replayed afterwards
+    bool use_graph = true;
+    hipGraphExec_t build_graph = nullptr;
+    uint32_t graph_tris = 0, graph_sort_gen = 0, plain_builds = 0;
+    int graph_algo = -1;
+    uint32_t* graph_error_word = nullptr;
 };
 
 struct psm_rt {
@@ -197,6 +204,7 @@ struct TimedScope {
 // kernels (launch wrappers) ------------------------------------------------------------------------
 int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n);
 int sort_check(psm_ctx* c);
+int sort_reserve(psm_ctx* c, size_t n_max);
 int launch_bvh_bounds(psm_bvh* b);
 int launch_bvh_morton(psm_bvh* b);
 int launch_bvh_emit(psm_bvh* b);

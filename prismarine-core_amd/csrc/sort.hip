@@ -328,15 +328,14 @@ __global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict_
     }
 }
 
-template <int ITEMS>
-static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n) {
-    constexpr uint32_t TILE = 256 * ITEMS;
-    uint32_t numTiles = (uint32_t)((n_max + TILE - 1) / TILE);
-    size_t E = (size_t)256 * numTiles + 256;  // per-tile counts + 256 digit totals
+// ping-pong buffers and histogram / status words of the sort, grown on demand. Every growth bumps sort_gen: a captured
+// build graph (psm_bvh_build) holds these pointers and is re-captured when the generation has moved on.
+static int sort_buffers(psm_ctx* c, size_t n_max, size_t E) {
     if (c->sort_cap < n_max) {
         if (c->sort_keys_tmp) (void)hipFree(c->sort_keys_tmp);
         if (c->sort_vals_tmp) (void)hipFree(c->sort_vals_tmp);
         c->sort_keys_tmp = nullptr; c->sort_vals_tmp = nullptr; c->sort_cap = 0;
+        c->sort_gen++;
         PSM_HIP(c, hipMalloc(&c->sort_keys_tmp, n_max * sizeof(uint64_t)));
         PSM_HIP(c, hipMalloc(&c->sort_vals_tmp, n_max * sizeof(uint32_t)));
         c->sort_cap = n_max;
@@ -344,9 +343,34 @@ static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
     if (c->sort_hist_cap < E) {
         if (c->sort_hist) (void)hipFree(c->sort_hist);
         c->sort_hist = nullptr; c->sort_hist_cap = 0;
+        c->sort_gen++;
         PSM_HIP(c, hipMalloc(&c->sort_hist, E * sizeof(uint32_t)));
         c->sort_hist_cap = E;
     }
+    return PSM_OK;
+}
+
+static bool sort_uses_passes(const psm_ctx* c, size_t n_max) { return c->sort_algorithm == 0 || n_max >= (1u << 30); }
+static size_t sort_words(const psm_ctx* c, size_t n_max) {
+    uint32_t tile = 256u * (n_max <= (1u << 21) ? 4u : 16u);
+    size_t numTiles = (n_max + tile - 1) / tile;
+    return sort_uses_passes(c, n_max) ? (size_t)256 * numTiles + 256 : (size_t)CB_WORDS + (size_t)8 * numTiles * 256;
+}
+
+// allocate what launch_sort(c, ., ., n_max, .) will need, without launching anything (no allocation may happen while a
+// stream is being captured)
+int sort_reserve(psm_ctx* c, size_t n_max) {
+    if (n_max == 0) return PSM_OK;
+    if (n_max > 0xFFFFFFF0ull) return set_err(c, PSM_ERR_CAPACITY, "sort: n exceeds 32-bit indexing");
+    return sort_buffers(c, n_max, sort_words(c, n_max));
+}
+
+template <int ITEMS>
+static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n) {
+    constexpr uint32_t TILE = 256 * ITEMS;
+    uint32_t numTiles = (uint32_t)((n_max + TILE - 1) / TILE);
+    size_t E = (size_t)256 * numTiles + 256;  // per-tile counts + 256 digit totals
+    { int rc = sort_buffers(c, n_max, E); if (rc != PSM_OK) return rc; }
     uint64_t* kin = d_keys; uint32_t* vin = d_vals;
     uint64_t* kout = c->sort_keys_tmp; uint32_t* vout = c->sort_vals_tmp;
     for (int pass = 0; pass < 8; pass++) {  // Radix.hpp:57: 64-bit keys, 8 passes
@@ -368,20 +392,7 @@ static int sort_onesweep(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t 
     constexpr uint32_t TILE = 256 * ITEMS;
     uint32_t numTiles = (uint32_t)((n_max + TILE - 1) / TILE);
     size_t E = (size_t)CB_WORDS + (size_t)8 * numTiles * 256;  // control block + status words of the 8 passes
-    if (c->sort_cap < n_max) {
-        if (c->sort_keys_tmp) (void)hipFree(c->sort_keys_tmp);
-        if (c->sort_vals_tmp) (void)hipFree(c->sort_vals_tmp);
-        c->sort_keys_tmp = nullptr; c->sort_vals_tmp = nullptr; c->sort_cap = 0;
-        PSM_HIP(c, hipMalloc(&c->sort_keys_tmp, n_max * sizeof(uint64_t)));
-        PSM_HIP(c, hipMalloc(&c->sort_vals_tmp, n_max * sizeof(uint32_t)));
-        c->sort_cap = n_max;
-    }
-    if (c->sort_hist_cap < E) {
-        if (c->sort_hist) (void)hipFree(c->sort_hist);
-        c->sort_hist = nullptr; c->sort_hist_cap = 0;
-        PSM_HIP(c, hipMalloc(&c->sort_hist, E * sizeof(uint32_t)));
-        c->sort_hist_cap = E;
-    }
+    { int rc = sort_buffers(c, n_max, E); if (rc != PSM_OK) return rc; }
     uint32_t* cb = c->sort_hist;
     PSM_HIP(c, hipMemsetAsync(cb, 0, E * sizeof(uint32_t), c->stream));
     // histogram blocks: enough to fill the chip, at least 4096 keys each
@@ -407,7 +418,7 @@ int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, co
     if (n_max == 0) return PSM_OK;
     if (n_max > 0xFFFFFFF0ull) return set_err(c, PSM_ERR_CAPACITY, "sort: n exceeds 32-bit indexing");
     TimedScope ts(c, CAT_SORT);
-    if (c->sort_algorithm == 0 || n_max >= (1u << 30)) {  // (the one-sweep status words hold 30-bit counts)
+    if (sort_uses_passes(c, n_max)) {  // (the one-sweep status words hold 30-bit counts)
         c->sort_error_word = nullptr;  // no look-back, nothing to time out (and the buffer it pointed into is reused)
         if (n_max <= (1u << 21)) return sort_passes<4>(c, d_keys, d_vals, n_max, d_n);
         return sort_passes<16>(c, d_keys, d_vals, n_max, d_n);

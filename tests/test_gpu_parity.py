@@ -131,6 +131,75 @@ def test_build_with_ties_degenerates_and_opt(psm, ctx, oracle, scenes):
     _check_build(psm, ctx, oracle, sc, opt)
 
 
+def _built_equals_oracle(psm, oracle, th, ob):
+    """the state a finished build leaves behind: transform, sorted keys + order, topology, ranges, triangle ids, boxes"""
+    info = th.info()
+    n = ob["count"]
+    assert info.leaf_count == n
+    assert np.array_equal(bits(np.array(info.transform)), bits(ob["M"]))
+    assert np.array_equal(th.download(psm.BVH_KEYS, np.uint64, n), ob["keys"])
+    assert np.array_equal(th.download(psm.BVH_INDICES, np.uint32, n), ob["idx"].astype(np.uint32))
+    link = th.download(psm.BVH_LINK, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+    pb = th.download(psm.BVH_PAIR_BOX, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
+    rg = th.download(psm.BVH_RANGE, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
+    assert info.root == oracle.find_split(ob["keys"], 0, n - 1)
+    nodes = canonical_nodes(info.root, link, pb, rg, oracle.NODE_DT)
+    assert np.array_equal(nodes["pdata"], ob["nodes"]["pdata"])
+    assert np.array_equal(nodes["box"], ob["nodes"]["box"])
+
+
+def test_rebuild_replayed_as_captured_graph_is_bit_exact(psm, ctx, oracle, scenes):
+    """psm_bvh_build replays a rebuild as one captured hipGraph from the second build of a triangle count on. Every
+    build -- plain, the capturing one, replays, with another optimisation matrix, after the triangle set changed, after
+    another sorter grew the context's sort buffers under the graph, with the other sort algorithm, with graphs off --
+    must leave exactly the oracle's tree."""
+    sc = _scene(scenes, "sponza_small")
+    ob = oracle.build_scene(sc["tris"])
+    th = _load(psm, ctx, sc)
+    for _ in range(4):           # plain, capture + replay, replay, replay
+        th.markDirty()
+        th.build()
+        _built_equals_oracle(psm, oracle, th, ob)
+    a = 0.3
+    opt = np.array([[np.cos(a), 0, np.sin(a), 0.5], [0, 1.3, 0, -1.0], [-np.sin(a), 0, np.cos(a), 2.0], [0, 0, 0, 1]], np.float64).reshape(16)
+    ob_opt = oracle.build_scene(sc["tris"], opt)
+    th.markDirty()
+    th.build(opt)                # replay of the same graph: the matrix travels through device memory
+    _built_equals_oracle(psm, oracle, th, ob_opt)
+    # another sorter on the same context grows the shared sort buffers: the graph's pointers are stale and it is re-captured
+    rs = psm.RadixSort(ctx)
+    k = np.random.RandomState(3).randint(0, 2**63, size=sc["tris"].shape[0] * 3, dtype=np.int64).astype(np.uint64)
+    gk, _ = rs.sort_arrays(k, np.arange(k.size, dtype=np.uint32))
+    assert np.array_equal(gk, np.sort(k))
+    for _ in range(3):
+        th.markDirty()
+        th.build()
+        _built_equals_oracle(psm, oracle, th, ob)
+    rs.setAlgorithm(1)           # the one-sweep sort: another graph
+    for _ in range(3):
+        th.markDirty()
+        th.build()
+        _built_equals_oracle(psm, oracle, th, ob)
+    rs.setAlgorithm(0)
+    th.setBuildGraph(False)
+    th.markDirty()
+    th.build()
+    _built_equals_oracle(psm, oracle, th, ob)
+    th.setBuildGraph(True)
+    # a different triangle set in the same hierarchy
+    half = sc["tris"].shape[0] // 2
+    sc2 = {"tris": np.ascontiguousarray(sc["tris"][:half]), "normals": np.ascontiguousarray(sc["normals"][:half]),
+           "mats": np.ascontiguousarray(sc["mats"][:half])}
+    ob2 = oracle.build_scene(sc2["tris"])
+    th.clearTribuffer()
+    th.loadTriangles(sc2["tris"], sc2["normals"], sc2["mats"])
+    for _ in range(3):
+        th.markDirty()
+        th.build()
+        _built_equals_oracle(psm, oracle, th, ob2)
+    th.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3])
 def test_build_tiny(psm, ctx, oracle, scenes, n):
     tris = scenes.cornell()["tris"][:n]
@@ -235,6 +304,95 @@ def test_traverse_random_rays_with_chains(psm, ctx, oracle, scenes):
     _hits_equal(gh, gc, oh, oc)
     rt.close()
     th.close()
+
+
+def _trace_both(psm, ctx, oracle, tris, origin, direct):
+    sc = {"tris": tris, "normals": np.zeros_like(tris), "mats": np.zeros(tris.shape[0], np.int32)}
+    sc["normals"][:, :, 1] = 1.0
+    th = _load(psm, ctx, sc)
+    th.build()
+    ob = oracle.build_scene(tris)
+    n = origin.shape[0]
+    rays = np.zeros(n, psm.RAY_DT)
+    rays["origin"], rays["direct"], rays["color"] = origin, direct, 1.0
+    rays["bitfield"] = 1 | (3 << 8)
+    rays["texel"] = np.arange(n) % 100
+    rays["pkey"] = np.arange(n)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(128, 128)
+    rt.upload_rays(rays)
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    assert rt.intersection(th) == 1
+    st = ctx.stats()
+    ctx.stats_enable(False, False)
+    gh, gc = rt.download_hits(n)
+    oh, oc, octr = oracle.traverse(ob["nodes"], tris, ob["M"], origin, direct, 8)
+    rt.close()
+    th.close()
+    return gh, gc, st, oh, oc, octr
+
+
+def test_traverse_axis_aligned_inside_and_far_rays_bit_exact(psm, ctx, oracle, scenes):
+    """The slab test divides by the direction (directTraverse.comp:372-373): rays with zero components (1/0 = inf,
+    0 * inf = NaN inside min/max), rays that start inside the geometry's boxes, rays from very far away, very long and
+    very short direction vectors, and rays that point away from everything. Hits, chains, V and T as the oracle's."""
+    rng = np.random.RandomState(11)
+    tris = np.ascontiguousarray(scenes.sponza_like(n_tris=12007)["tris"])
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    n = 16384
+    origin = (lo + rng.rand(n, 3) * (hi - lo)).astype(np.float32)           # inside the scene's bounds
+    direct = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    k = n // 8
+    direct[0 * k:1 * k, 0] = 0.0                                              # one zero component
+    direct[1 * k:2 * k, 1:] = 0.0                                             # two: axis-parallel rays
+    direct[1 * k:2 * k, 0] = np.where(rng.rand(k) < 0.5, -1.0, 1.0)
+    direct[2 * k:3 * k] *= np.float32(1e-18)                                  # tiny directions (normalised by the kernel)
+    direct[3 * k:4 * k] *= np.float32(1e15)                                   # huge ones
+    origin[4 * k:5 * k] = (origin[4 * k:5 * k] - direct[4 * k:5 * k] / np.linalg.norm(direct[4 * k:5 * k], axis=1, keepdims=True)
+                           * np.float32(5000.0)).astype(np.float32)          # starts 5000 units away, aims at the scene
+    origin[5 * k:6 * k] += np.float32(20000.0)                                # beyond INFINITY, pointing anywhere
+    v = tris[rng.randint(0, tris.shape[0], k)]                                # starts exactly on a vertex of a triangle
+    origin[6 * k:7 * k] = v[:, 0]
+    direct[7 * k:8 * k, 2] = -0.0                                             # negative zero component
+    gh, gc, st, oh, oc, octr = _trace_both(psm, ctx, oracle, tris, origin, direct)
+    _hits_equal(gh, gc, oh, oc)
+    assert (st.node_visits, st.tri_tests, st.stack_drops, st.iter_caps) == (octr.node_visits, octr.tri_tests, octr.stack_drops, octr.iter_caps)
+    # tiny / huge directions, far origins and on-vertex origins do hit things; what a zero component does (1/0 = inf in the
+    # slab test, 0 * inf = NaN, minNum / maxNum semantics) is whatever the restated arithmetic says -- identically on both sides
+    assert (oc[2 * k:4 * k] > 0).sum() > 1000 and (oc[4 * k:5 * k] > 0).sum() > 1000 and (oc[6 * k:7 * k] > 0).all()
+
+
+def test_traverse_stack_overflow_iteration_cap_and_long_chains_bit_exact(psm, ctx, oracle):
+    """Faithful-by-default limits: the 16-entry stack whose overflowing pushes are dropped
+    (directTraverse.comp:451-462), the 8192-iteration cap (:383) and the equal-distance chain of at most 8 entries
+    (:294). 2^19 slivers in one plane, sorted along x, make a tree 19 levels deep; rays grazing the plane run through
+    every padded box and hit nothing, so the stack overflows and the loop runs into its cap. 12 coplanar copies of one
+    triangle make chains of 12."""
+    rng = np.random.RandomState(5)
+    N = 1 << 19
+    x0 = np.arange(N, dtype=np.float64) / N
+    tris = np.zeros((N, 3, 3), np.float32)
+    tris[:, 0] = np.stack([x0, np.zeros(N), np.full(N, -0.5)], 1)
+    tris[:, 1] = np.stack([x0 + 0.8 / N, np.zeros(N), np.full(N, -0.5)], 1)
+    tris[:, 2] = np.stack([x0, np.zeros(N), np.full(N, 0.5)], 1)
+    lid = np.array([[[0.2, 0.6, -0.3], [0.8, 0.6, -0.3], [0.5, 0.6, 0.3]]], np.float32)
+    tris = np.ascontiguousarray(np.concatenate([tris, np.repeat(lid, 12, 0)], 0))
+    n = 2048
+    h = n // 2
+    origin = np.zeros((n, 3), np.float32)
+    direct = np.zeros((n, 3), np.float32)
+    origin[:h] = np.stack([np.full(h, -0.25), rng.rand(h) * 2e-4 + 1e-5, rng.rand(h) * 0.6 - 0.3], 1)   # grazing rays
+    direct[:h] = np.stack([np.ones(h), rng.normal(0, 1e-6, h), rng.normal(0, 1e-3, h)], 1)
+    t = np.stack([0.35 + rng.rand(h) * 0.3, np.full(h, 0.6), rng.rand(h) * 0.2 - 0.15], 1)              # rays onto the lid
+    origin[h:] = t + np.stack([rng.normal(0, 0.2, h), np.full(h, 0.5), rng.normal(0, 0.2, h)], 1)
+    direct[h:] = t - origin[h:]
+    origin, direct = origin.astype(np.float32), direct.astype(np.float32)
+    gh, gc, st, oh, oc, octr = _trace_both(psm, ctx, oracle, tris, origin, direct)
+    assert octr.stack_drops > 1000 and octr.iter_caps >= h   # the case is what it says
+    assert int(oc.max()) == 8 and (oc == 8).sum() > h // 2   # chains of 12 are cut at BAKED_CAP
+    _hits_equal(gh, gc, oh, oc)
+    assert (st.node_visits, st.tri_tests, st.stack_drops, st.iter_caps) == (octr.node_visits, octr.tri_tests, octr.stack_drops, octr.iter_caps)
 
 
 @pytest.mark.parametrize("scale", [0.004, 35.0])
