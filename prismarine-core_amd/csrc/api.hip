@@ -428,7 +428,7 @@ static void bvh_drop_graph(psm_bvh* b) {
     b->build_graph = nullptr;
 }
 
-// Capture the build's launches (bounds, Morton + leaves, the sort's passes, segment tree, emit: 36 at C3) on the
+// Capture the build's launches (bounds, Morton + leaves, the sort's passes, segment tree, emit: 34 at C3) on the
 // context's stream into one executable graph. Every argument is a device pointer of this hierarchy / context or a
 // function of the triangle count, so the graph stays valid until one of them changes (checked by the caller).
 static int bvh_capture_graph(psm_bvh* b) {

@@ -118,7 +118,7 @@ struct psm_bvh {
     int2* d_link = nullptr;
     int2* d_range = nullptr;
     uint4* d_node32 = nullptr;    // traversal record per internal node: 12 fp16 box coords + 2 links (32 B)
-    // the build as one hipGraph (36 launches at C3): captured on the second build of a triangle count, replayed afterwards
+    // the build as one hipGraph (34 launches at C3): captured on the second build of a triangle count, replayed afterwards
     bool use_graph = true;
     hipGraphExec_t build_graph = nullptr;
     uint32_t graph_tris = 0, graph_sort_gen = 0, plain_builds = 0;

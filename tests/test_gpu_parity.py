@@ -524,7 +524,8 @@ def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes
 
 # ---------------------------------------------------------------------------- shade + full frames
 @pytest.mark.parametrize("name,w,h", [("cornell_open", 96, 96), ("sponza_small", 160, 90),
-                                      ("cornell_open+tex", 96, 96), ("sponza_small+tex", 160, 90)])
+                                      ("cornell_open+tex", 96, 96), ("sponza_small+tex", 160, 90),
+                                      ("cornell_open", 97, 61), ("cornell", 33, 17)])   # ragged: no multiple of a wave, a workgroup or a band
 def test_shade_rounds_bit_exact_queues(psm, ctx, oracle, scenes, name, w, h):
     """+tex: SURVEY f2 -- texcoords, the sampler table and every texture part of surface.comp:100-161."""
     scene = _scene(scenes, name)
@@ -559,8 +560,51 @@ def test_shade_rounds_bit_exact_queues(psm, ctx, oracle, scenes, name, w, h):
     th.close()
 
 
+def test_queue_overflow_drops_past_the_ray_limit_in_queue_order(psm, ctx, oracle, scenes):
+    """currentRayLimit = min(4 w h, 4096^2) (Pipeline.inl:187-189). A full queue of rays that all hit bright diffuse walls
+    emits more rays than the limit holds; canonical rule: the queue keeps the first `limit` rays in queue
+    order, the rest are dropped (and counted). Queue after the round slot for slot as the oracle's."""
+    scene = scenes.cornell()     # closed box: every ray hits something
+    w, h = 32, 32
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    ob = oracle.build_scene(scene["tris"])
+    mats = scenes.materials_array(scene["materials"])
+    cfg = oracle.make_cfg(w, h, material_count=len(mats))
+    limit = 4 * w * h
+    assert cfg.ray_limit == limit
+    lights = oracle.default_lights(1)
+    parts = [oracle.camera(cfg, cam[0], cam[1], 500 + q) for q in range(4)]
+    orays = np.concatenate([p_[0] for p_ in parts])      # 4096 rays = the limit, four jittered copies of the camera rays
+    assert orays.shape[0] == limit
+    orays["pkey"] = np.arange(limit)
+    ocoord, osum, oflag = parts[0][1], parts[0][2], parts[0][3]
+    rt.camera_matrices(cam[0], cam[1], time=500)      # texel coords / sums / flags as the oracle's first camera pass
+    rt.applyMaterials(ms)
+    rt.upload_rays(orays)
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    dropped = 0
+    for rnd in range(3):
+        rt.intersection(th)
+        oh, oc, _ = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], orays["origin"], orays["direct"], 8)
+        gh, gc = rt.download_hits(orays.shape[0])
+        _hits_equal(gh, gc, oh, oc)
+        rt.shade(time=900 + rnd)
+        orays = oracle.shade(cfg, lights, mats, scene["mats"], scene["tris"], scene["normals"], 900 + rnd, orays, oh, oc, osum, oflag)
+        assert rt.raycountCache == orays.shape[0]
+        _rays_equal(rt.download_rays(), orays)
+        if orays.shape[0] == limit:
+            dropped += 1
+    st = ctx.stats()
+    ctx.stats_enable(False, False)
+    assert dropped >= 1 and st.ray_limit_drops > 0     # the queue did overflow
+    rt.close()
+    th.close()
+
+
 @pytest.mark.parametrize("name,w,h,frames", [("cornell_open", 64, 64, 3), ("sponza_small", 128, 72, 2),
-                                             ("cornell_open+tex", 64, 64, 3), ("sponza_small+tex", 128, 72, 2)])
+                                             ("cornell_open+tex", 64, 64, 3), ("sponza_small+tex", 128, 72, 2),
+                                             ("cornell_open", 37, 29, 2)])
 def test_accumulated_radiance(psm, ctx, oracle, scenes, name, w, h, frames):
     """Viewer.cpp:296-312 call order, several frames; accumulated radiance within 1e-4 relative."""
     scene = _scene(scenes, name)
