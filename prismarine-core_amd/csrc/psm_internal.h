@@ -37,16 +37,6 @@ struct TravState {      // structure of arrays in ONE allocation, `capacity` ent
     __host__ __device__ int32_t* lastTri() const { return (int32_t*)(base + (size_t)32 * capacity); }
     __host__ __device__ int32_t* stack() const { return (int32_t*)(base + (size_t)36 * capacity); }
 };
-struct Phase {
-    uint32_t cap;              // wave-steps this launch may take (0xFFFFFFFF: no cap)
-    uint32_t min_live;         // a wave hands its rays over once fewer than this many lanes have work left (0: never)
-    uint32_t min_steps;        // ... but not before this many wave-steps
-    uint32_t final_rays;       // resume: with no more than this many rays waiting the launch runs them to completion
-    const uint32_t* in_count;  // resume: number of suspended rays (device), nullptr = fresh rays
-    TravState in, out;
-    uint32_t* out_count;
-};
-
 enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_BOUNDS, CAT_MORTON, CAT_EMIT, CAT_COUNT };
 
 // device-resident counters (one block per context)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# Record of round 2 GPU session e: s_setprio experiments (by launch / by wave age) on an EXPERIMENT build of trace.hip. The
+# PSM_EXP_* switches it sets were removed with that build (results in DESIGN.md 5.2; diffs in the history); kept as a record.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 cd $REPO

@@ -14,7 +14,7 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     return x;
 }
 
-template <int LOADS, bool TREE>
+template <int LOADS, bool TREE, bool PAIR = false>
 __global__ __launch_bounds__(128, 8) void chase(const uint4* __restrict__ tab, int log2n, int steps, int live, int pad,
                                                 uint32_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -32,7 +32,9 @@ __global__ __launch_bounds__(128, 8) void chase(const uint4* __restrict__ tab, i
             acc = fminf(acc, __uint_as_float((a.z & 0x3fffffffu) + p));
             acc = fmaxf(acc, __uint_as_float((b.w & 0x3fffffffu) + p));
         }
-        if (TREE) {
+        if (PAIR && (s & 1) == 0) {
+            idx ^= 1u + (r & 2u);   // every other fetch stays in the 128-byte line of the one before (a record next to it)
+        } else if (TREE) {
             uint32_t lvl = (r >> 24) % (uint32_t)(log2n + 1);   // level 0..log2n, each equally likely
             uint32_t base = (lvl == 0) ? 0u : ((1u << lvl) - 1u);
             idx = (base + ((r >> 2) & ((1u << lvl) - 1u))) & mask;
@@ -43,14 +45,14 @@ __global__ __launch_bounds__(128, 8) void chase(const uint4* __restrict__ tab, i
     out[gid] = r ^ __float_as_uint(acc);
 }
 
-template <int LOADS, bool TREE>
+template <int LOADS, bool TREE, bool PAIR = false>
 static double run(const uint4* tab, int log2n, int live, int pad, uint32_t* out) {
     const int grid = 256 * 16, steps = 256;   // 16 workgroups of 128 per CU = 8 waves per SIMD, one generation
-    chase<LOADS, TREE><<<grid, 128>>>(tab, log2n, 8, live, pad, out);
+    chase<LOADS, TREE, PAIR><<<grid, 128>>>(tab, log2n, 8, live, pad, out);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    chase<LOADS, TREE><<<grid, 128>>>(tab, log2n, steps, live, pad, out);
+    chase<LOADS, TREE, PAIR><<<grid, 128>>>(tab, log2n, steps, live, pad, out);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -83,6 +85,14 @@ int main() {
                 }
                 printf("\n");
             }
+        }
+        // what a layout buys in which every other step finds its record in the line the step before has fetched
+        for (int pad : {0, 24, 36}) {
+            printf("table %4d MiB tree, every other fetch in the previous line, pad %2d:", (32 << log2n) >> 20, pad);
+            for (int live : {16, 32, 48, 64}) printf("  live %2d: %6.1f", live, run<2, true, true>(tab, log2n, live, pad, out));
+            printf("   (independent lines, pad %2d:", pad);
+            for (int live : {32, 48}) printf(" live %2d: %6.1f", live, run<2, true, false>(tab, log2n, live, pad, out));
+            printf(")\n");
         }
     }
     return 0;
