@@ -35,6 +35,27 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int
                 asm volatile("v_min3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
                              "v_min3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 7) {   // 8 half-rate VALU + 8 SALU mask operations (independent of the VALU ones) per group
+                asm volatile("v_min_f32 %0, %0, %8\n s_and_b64 s[20:21], s[22:23], s[24:25]\n v_max_f32 %1, %1, %8\n s_or_b64 s[26:27], s[20:21], s[24:25]\n"
+                             "v_min_f32 %2, %2, %8\n s_andn2_b64 s[22:23], s[26:27], s[24:25]\n v_max_f32 %3, %3, %8\n s_xor_b64 s[20:21], s[22:23], s[26:27]\n"
+                             "v_min_f32 %4, %4, %8\n s_and_b64 s[26:27], s[20:21], s[24:25]\n v_max_f32 %5, %5, %8\n s_or_b64 s[22:23], s[26:27], s[24:25]\n"
+                             "v_min_f32 %6, %6, %8\n s_andn2_b64 s[20:21], s[22:23], s[24:25]\n v_max_f32 %7, %7, %8\n s_xor_b64 s[26:27], s[20:21], s[22:23]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
+                             : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
+            } else if (KIND == 8) {   // 8 half-rate VALU + 16 SALU
+                asm volatile("v_min_f32 %0, %0, %8\n s_and_b64 s[20:21], s[22:23], s[24:25]\n s_bcnt1_i32_b64 s28, s[20:21]\n v_max_f32 %1, %1, %8\n s_or_b64 s[26:27], s[20:21], s[24:25]\n s_cmp_gt_u32 s28, 7\n"
+                             "v_min_f32 %2, %2, %8\n s_andn2_b64 s[22:23], s[26:27], s[24:25]\n s_cselect_b64 s[30:31], -1, 0\n v_max_f32 %3, %3, %8\n s_xor_b64 s[20:21], s[22:23], s[26:27]\n s_mov_b64 s[32:33], s[30:31]\n"
+                             "v_min_f32 %4, %4, %8\n s_and_b64 s[26:27], s[20:21], s[24:25]\n s_bcnt1_i32_b64 s28, s[26:27]\n v_max_f32 %5, %5, %8\n s_or_b64 s[22:23], s[26:27], s[24:25]\n s_cmp_gt_u32 s28, 9\n"
+                             "v_min_f32 %6, %6, %8\n s_andn2_b64 s[20:21], s[22:23], s[24:25]\n s_cselect_b64 s[30:31], -1, 0\n v_max_f32 %7, %7, %8\n s_xor_b64 s[26:27], s[20:21], s[22:23]\n s_mov_b64 s[32:33], s[30:31]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
+                             : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s30", "s31", "s32", "s33", "scc");
+            } else if (KIND == 9) {   // 8 half-rate VALU, each consuming a mask a SALU instruction has just produced (v_cndmask on an SGPR pair)
+                asm volatile("s_and_b64 s[20:21], s[22:23], s[24:25]\n v_cndmask_b32 %0, %0, %8, s[20:21]\n s_or_b64 s[26:27], s[20:21], s[24:25]\n v_cndmask_b32 %1, %1, %8, s[26:27]\n"
+                             "s_andn2_b64 s[22:23], s[26:27], s[24:25]\n v_cndmask_b32 %2, %2, %8, s[22:23]\n s_xor_b64 s[20:21], s[22:23], s[26:27]\n v_cndmask_b32 %3, %3, %8, s[20:21]\n"
+                             "s_and_b64 s[26:27], s[20:21], s[24:25]\n v_cndmask_b32 %4, %4, %8, s[26:27]\n s_or_b64 s[22:23], s[26:27], s[24:25]\n v_cndmask_b32 %5, %5, %8, s[22:23]\n"
+                             "s_andn2_b64 s[20:21], s[22:23], s[24:25]\n v_cndmask_b32 %6, %6, %8, s[20:21]\n s_xor_b64 s[26:27], s[20:21], s[22:23]\n v_cndmask_b32 %7, %7, %8, s[26:27]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
+                             : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
             } else {
                 asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
                              "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
@@ -82,5 +103,9 @@ int main() {
     run<2>("v_fma_mix_f32", 8);
     run<4>("v_min3/v_max3_f32", 8);
     run<3>("v_cmp(vcc)+v_cndmask", 8);
+    // does scalar work cost VALU issue? (per VALU instruction, as above)
+    run<7>("v_min/max + 1 SALU each", 8);
+    run<8>("v_min/max + 2 SALU each", 8);
+    run<9>("s_op -> v_cndmask(sgpr)", 8);
     return 0;
 }
