@@ -99,6 +99,10 @@ struct Baked {
 // the rest -- result arrays, counters, the hand-over state -- are read where they are used, through the kernarg
 // segment, behind an opaque move (cold_args): held in scalar registers from the kernel's entry they would cost the
 // loop ~30 SGPRs, whose spills take two VGPRs from a kernel that is allowed 64 (8 waves per SIMD).
+// The wave's lane mask of a flag. A flag already is a lane mask in an SGPR pair: the builtin is one s_and with exec,
+// where __ballot(int) first turns the flag into 0/1 in a VGPR and compares it again (2 VALU per ballot, per wave-step).
+PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 struct TravArgs {
     const float4 *qA, *qB;        // hot
     const uint32_t* qbases;
@@ -233,13 +237,11 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     bool pLeftNear = false;
     bool parkedNow = false;  // pl >= 0 || pr >= 0 (both are -1 or a triangle id); false again once the tests have run
     for (;;) {
-        if (validBox & !parkedNow) {
-            if (it >= MAX_ITERS) {
-                validBox = false;
-                if (COUNT) nCap++;
-            } else {
+        if (validBox && !parkedNow) {
+            {
                 it++;
-                const uint4* np = node32 + 2 * (size_t)cur;
+                // 32-bit byte offset (the node array is < 4 GiB: 2^27 nodes): one shift, the load adds it to the scalar base
+                const uint4* np = (const uint4*)((const char*)node32 + ((uint32_t)cur << 5));
                 uint4 n0 = np[0], n1 = np[1];
                 int2 lk = make_int2((int)n1.z, (int)n1.w);
                 if (COUNT) nV++;
@@ -249,28 +251,37 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 const bool leftNear = lessEqualF(L.near, R.near);  // :414 (only read when both children are accepted)
                 const bool ogL = child_ok(L, dirlenInv, toffset, predist), ogR = child_ok(R, dirlenInv, toffset, predist);
                 const bool lfL = lk.x < 0, lfR = lk.y < 0;
-                pl = (ogL & lfL) ? ~lk.x : -1;   // accepted leaves, :441-448: tested below
-                pr = (ogR & lfR) ? ~lk.y : -1;
+                // the flags are lane masks: && / || on values already computed are mask ANDs / ORs (bitwise & | would
+                // promote them to integers and materialise them in VGPRs)
+                const bool leafL = ogL && lfL, leafR = ogR && lfR;
+                pl = leafL ? ~lk.x : -1;   // accepted leaves, :441-448: tested below
+                pr = leafR ? ~lk.y : -1;
                 pLeftNear = leftNear;
-                parkedNow = (ogL & lfL) | (ogR & lfR);
-                const bool intL = ogL & !lfL, intR = ogR & !lfR;
-                const bool leftFirst = intL & (leftNear | !intR);  // :451-462: both ? leftNear : intL
+                parkedNow = leafL || leafR;
+                const bool intL = ogL != leafL, intR = ogR != leafR;  // accepted and not a leaf (one mask XOR, no second compare)
+                const bool leftFirst = intL && (leftNear || !intR);  // :451-462: both ? leftNear : intL
                 const int first = leftFirst ? lk.x : lk.y, second = leftFirst ? lk.y : lk.x;
-                if (intL & intR & (lk.x != lk.y)) {
+                if (intL && intR && (lk.x != lk.y)) {
                     if (sp < STACK_CAP) stack[sp++][tid] = second;
                     else if (COUNT) nDrop++;
                 }
-                if (intL | intR) {
+                if (intL || intR) {
                     cur = first;
                 } else {  // :467-476
                     sp--;
                     if (sp >= 0) cur = stack[sp][tid];
                     else validBox = false;
                 }
+                // :383: the loop runs MAX_ITERS iterations at most; a ray that still has work after its last one stops here
+                // (flagged with the step itself instead of in a branch of its own before the next one: its parked leaves,
+                // if any, are still tested below, exactly as when the flag was raised one wave-step later)
+                const bool capped = validBox && it >= MAX_ITERS;
+                validBox = validBox && !capped;
+                if (COUNT) nCap += capped ? 1u : 0u;
             }
         }
-        const unsigned long long pend = __ballot(parkedNow);
-        const unsigned long long canStep = __ballot(validBox && !parkedNow);
+        const unsigned long long pend = lane_mask(parkedNow);
+        const unsigned long long canStep = lane_mask(validBox && !parkedNow);
         if (COUNT) dg_steps++;
         // wave-uniform: the cap, or too few lanes with work left (parked or able to step) to be worth a wave
         const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && (uint32_t)__popcll(pend | canStep) < min_live));
@@ -281,20 +292,16 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             continue;  // keep stepping the others
         }
         if (parkedNow) {  // testIntersectionPacked, :261-309
-            bool leafL = pl >= 0, leafR = pr >= 0;
-            bool leftOrder = (leafL && leafR) ? pLeftNear : leafL;
-            int tx = leftOrder ? pl : pr, ty = leftOrder ? pr : pl;
-            bool vx = leftOrder ? leafL : leafR, vy = leftOrder ? leafR : leafL;
-            bool validx = (tx >= 0) && (tx != lastTri) && vx;
-            bool validy = (ty >= 0) && (ty != lastTri) && vy && (tx != ty);
-            if (!validx) {
-                int t = tx; tx = ty; ty = t;
-                bool q = validx; validx = validy; validy = q;
-            }
+            // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are -1 when not)
+            const bool lo = (pl >= 0) && (pLeftNear || pr < 0);
+            const int tx = lo ? pl : pr, ty = lo ? pr : pl;
+            const bool validx = (tx >= 0) && (tx != lastTri);
+            const bool validy = (ty >= 0) && (ty != lastTri) && (tx != ty);
+            int tri = validx ? tx : ty;       // first test: x, or y straight away when x is skipped
+            bool valid = validx || validy;
+            bool again = validx && validy;    // second test: y after x
 #pragma unroll 1
             for (int pass = 0; pass < 2; pass++) {
-                int tri = pass == 0 ? tx : ty;
-                bool valid = pass == 0 ? validx : validy;
                 if (valid) {
                     float u = 0.f, v = 0.f;
                     float d = tri_test(tri48, tri, origin, direct, u, v);
@@ -310,6 +317,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                         else if (COUNT) nBakedDrop++;
                     }
                 }
+                tri = ty;
+                valid = again;
+                again = false;
             }
             pl = -1; pr = -1;
             parkedNow = false;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             // every parked test has just run. Rays with work left and a chain of at most one hit hand their state
             // to the next launch (a longer chain lives in registers / scratch: such a ray, < 0.1 %, finishes here)
             const bool susp = validBox && bakedCount <= 1;
-            const unsigned long long sb = __ballot(susp);
+            const unsigned long long sb = lane_mask(susp);
             if (sb != 0ull) {
                 const TravArgs* K = cold_args();
                 const TravState out = K->out;
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                     suspended = true;
                 }
             }
-            if (__ballot(validBox) == 0ull) break;
+            if (lane_mask(validBox) == 0ull) break;
         }
     }
     if (PHASED && suspended) alive = false;  // its result is written by the launch that finishes it
