@@ -81,7 +81,8 @@ int psm_sort_set_algorithm(psm_ctx* ctx, int algorithm);
 /* ---------------------------------------------------------------------------------------------
  * psm::TriangleHierarchy, Include/Prismarine/TriangleHierarchy.{hpp,inl}
  * ------------------------------------------------------------------------------------------- */
-/* allocate(count), TriangleHierarchy.inl:77-112 (capacity = 2*count there; here exactly max_tris) */
+/* allocate(count), TriangleHierarchy.inl:77-112 (capacity = 2*count there; here exactly max_tris).
+ * max_tris <= 2^27 (PSM_ERR_CAPACITY beyond; the reference stops at ~4.19 M, TriangleHierarchy.inl:80). */
 int psm_bvh_create(psm_ctx* ctx, size_t max_tris, psm_bvh** out);
 int psm_bvh_destroy(psm_bvh* bvh);
 /* clearTribuffer(), TriangleHierarchy.inl:161-166 */

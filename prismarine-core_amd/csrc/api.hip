@@ -264,7 +264,9 @@ int psm_bvh_destroy(psm_bvh* b) {
 
 int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
     if (!c || !out || max_tris == 0) return PSM_ERR_INVALID;
-    if (max_tris > 0x7FFFFF00ull / 9) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_create: max_tris exceeds 32-bit indexing");
+    // 2^27 triangles (the reference: ~4.19 M, TriangleHierarchy.inl:80): the traversal kernel addresses its 32-byte node
+    // records with a 32-bit byte offset, and 9 floats per triangle stay below 2^31 elements
+    if (max_tris > (1ull << 27)) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_create: max_tris exceeds 2^27 (32-bit node offsets)");
     (void)hipSetDevice(c->device);
     psm_bvh* b = new (std::nothrow) psm_bvh();
     if (!b) return PSM_ERR_INVALID;

@@ -233,12 +233,13 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     // then all of them run the triangle block together. Per ray the sequence of node steps and triangle
     // tests is exactly the reference's (:441-476) -- a parked lane does nothing in between -- but the wave
     // issues the ~150-instruction triangle block for ~half its live lanes instead of for 3-4 of them.
-    int pl = -1, pr = -1;
+    int pl = 0, pr = 0;  // parked leaf links as stored in the node record (~triangle id: negative), 0 = none
     bool pLeftNear = false;
-    bool parkedNow = false;  // pl >= 0 || pr >= 0 (both are -1 or a triangle id); false again once the tests have run
+    bool parkedNow = false;  // pl < 0 || pr < 0; false again once the tests have run
     for (;;) {
         if (validBox && !parkedNow) {
             {
+                const bool lastIter = it >= MAX_ITERS - 1;  // :383, see below
                 it++;
                 // 32-bit byte offset (the node array is < 4 GiB: 2^27 nodes): one shift, the load adds it to the scalar base
                 const uint4* np = (const uint4*)((const char*)node32 + ((uint32_t)cur << 5));
@@ -254,8 +255,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 // the flags are lane masks: && / || on values already computed are mask ANDs / ORs (bitwise & | would
                 // promote them to integers and materialise them in VGPRs)
                 const bool leafL = ogL && lfL, leafR = ogR && lfR;
-                pl = leafL ? ~lk.x : -1;   // accepted leaves, :441-448: tested below
-                pr = leafR ? ~lk.y : -1;
+                pl = leafL ? lk.x : 0;   // accepted leaves, :441-448: tested below (kept undecoded: one select each)
+                pr = leafR ? lk.y : 0;
                 pLeftNear = leftNear;
                 parkedNow = leafL || leafR;
                 const bool intL = ogL != leafL, intR = ogR != leafR;  // accepted and not a leaf (one mask XOR, no second compare)
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 // :383: the loop runs MAX_ITERS iterations at most; a ray that still has work after its last one stops here
                 // (flagged with the step itself instead of in a branch of its own before the next one: its parked leaves,
                 // if any, are still tested below, exactly as when the flag was raised one wave-step later)
-                const bool capped = validBox && it >= MAX_ITERS;
+                const bool capped = validBox && lastIter;
                 validBox = validBox && !capped;
                 if (COUNT) nCap += capped ? 1u : 0u;
             }
@@ -292,9 +293,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             continue;  // keep stepping the others
         }
         if (parkedNow) {  // testIntersectionPacked, :261-309
-            // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are -1 when not)
-            const bool lo = (pl >= 0) && (pLeftNear || pr < 0);
-            const int tx = lo ? pl : pr, ty = lo ? pr : pl;
+            // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
+            const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
+            const int tx = ~(lo ? pl : pr), ty = ~(lo ? pr : pl);  // triangle ids, -1 = none (~0)
             const bool validx = (tx >= 0) && (tx != lastTri);
             const bool validy = (ty >= 0) && (ty != lastTri) && (tx != ty);
             int tri = validx ? tx : ty;       // first test: x, or y straight away when x is skipped
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 valid = again;
                 again = false;
             }
-            pl = -1; pr = -1;
+            pl = 0; pr = 0;
             parkedNow = false;
         }
         if (capHit) {

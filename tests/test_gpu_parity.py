@@ -1172,6 +1172,9 @@ def test_errors_are_reported(psm, ctx):
         ctx.check(psm.lib().psm_rt_traverse(rt._h, th._h), "traverse before build")
     rt.close()
     th.close()
+    big = psm.TriangleHierarchy(ctx)
+    with pytest.raises(psm.PsmError):
+        big.allocate((1 << 27) + 1)   # beyond the 32-bit node offsets of the traversal kernel: refused, nothing allocated
 
 
 def test_cpp_header_layer_viewer_call_order(psm, ctx, oracle, scenes, tmp_path):
