@@ -83,6 +83,9 @@ struct Baked {
     int tri;
 };
 
+// The wave's lane mask of a flag (the flag stays a flag: __ballot(int) would first widen it to an integer).
+PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // CHAIN: a further intersection() over the same rays with another hierarchy (multi-BVH). The
 // search starts from the distance of the chain the ray already carries (traverse(), :335-346) and the hits
 // it bakes overwrite the front of that chain, the rest of the old chain staying linked behind them
@@ -99,10 +102,6 @@ struct Baked {
 // the rest -- result arrays, counters, the hand-over state -- are read where they are used, through the kernarg
 // segment, behind an opaque move (cold_args): held in scalar registers from the kernel's entry they would cost the
 // loop ~30 SGPRs, whose spills take two VGPRs from a kernel that is allowed 64 (8 waves per SIMD).
-// The wave's lane mask of a flag. A flag already is a lane mask in an SGPR pair: the builtin is one s_and with exec,
-// where __ballot(int) first turns the flag into 0/1 in a VGPR and compares it again (2 VALU per ballot, per wave-step).
-PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
 struct TravArgs {
     const float4 *qA, *qB;        // hot
     const uint32_t* qbases;
@@ -149,8 +148,17 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
     const int root = (int)sm[SM_ROOT];
-    // fresh rays: one ray per thread of the grid. Resume: every wave strides over the continuation queue.
-    for (uint32_t batch = blockIdx.x * TRAV_BLOCK + (uint32_t)(tid & ~63); batch < total; batch += gridDim.x * TRAV_BLOCK) {
+    // fresh rays: one ray per thread of the grid. Workgroups b and b + 8 of a grid share an XCD (round-robin dispatch,
+    // observed, a speed matter only) and each XCD has its own 4 MB L2: the grid is dealt so that an XCD walks runs of
+    // 32 consecutive workgroups' rays (4096 rays: two rows of texels, neighbouring parts of the tree), the runs
+    // themselves round-robin. One contiguous eighth of the queue per XCD was 6 % slower (C5: 28 %): the expensive
+    // part of the image lands on one XCD. Runs of 32 or 128: 1-2 % faster than plain round-robin serial, equal in
+    // flight (tools/run_r02_y.sh). Resume: every wave strides over the continuation queue.
+    constexpr uint32_t XCD_GROUP = 32;
+    const uint32_t bq = blockIdx.x >> 3;   // position within the XCD's sequence
+    const uint32_t vb_ = ((bq / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + (bq % XCD_GROUP);
+    const uint32_t vblock = resume ? blockIdx.x : vb_;
+    for (uint32_t batch = vblock * TRAV_BLOCK + (uint32_t)(tid & ~63); batch < total; batch += gridDim.x * TRAV_BLOCK) {
     const uint32_t slot = batch + (uint32_t)(tid & 63);
     bool alive = slot < total;
     uint32_t i = slot;
@@ -527,7 +535,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     std::vector<PhasePlan> plan;
     const int mode = plan_traverse(r, n, chain, plan);
     {
-        uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+        uint32_t grid = ((n + TRAV_BLOCK - 1) / TRAV_BLOCK + 255u) & ~255u;  // a multiple of 8 XCDs x 32 (rt_traverse: vblock)
         TravArgs ta = {};
         ta.qA = r->qA[r->cur]; ta.qB = r->qB[r->cur]; ta.qbases = r->q_bases[r->cur]; ta.qnb = r->q_nb[r->cur]; ta.nrays = n;
         ta.node32 = b->d_node32; ta.tri48 = b->d_tri48; ta.sm = b->d_small;

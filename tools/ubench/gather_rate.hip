@@ -2,7 +2,8 @@
 // wave64 chases its own pointer, the way the BVH traversal loop does (two global_load_dwordx4 per record, the next
 // index depends on the loaded data)?  Varies: table size (L2 / Infinity Cache / HBM resident), live lanes per wave,
 // index distribution (uniform, or "tree": a level drawn uniformly, an index uniform within the level, so the upper
-// levels are hot like a BVH's), and VALU padding per step (dependent v_min/v_max pairs, the half-rate kind).
+// levels are hot like a BVH's), and VALU padding per step (`pad` x 8 v_min/v_max in four independent chains, on top of
+// the ~20 VALU instructions of the chase itself).
 // Build: hipcc --offload-arch=gfx950 -O3 -o gather_rate gather_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -23,26 +24,29 @@ __global__ __launch_bounds__(128, 8) void chase(const uint4* __restrict__ tab, i
     uint32_t r = hash32(gid * 2654435761u + 12345u);
     const uint32_t mask = (1u << log2n) - 1u;
     uint32_t idx = r & mask;
-    float acc = (float)lane;
+    float acc = (float)lane, acc1 = acc + 1.f, acc2 = acc + 2.f, acc3 = acc + 3.f;
     for (int s = 0; s < steps; s++) {
         uint4 a = tab[(size_t)idx * 2];
         uint4 b = LOADS == 2 ? tab[(size_t)idx * 2 + 1] : a;
-        r = hash32(r ^ a.x ^ b.y);
-        for (int p = 0; p < pad; p++) {   // dependent half-rate VALU work, like the slab test's min/max chain
-            acc = fminf(acc, __uint_as_float((a.z & 0x3fffffffu) + p));
-            acc = fmaxf(acc, __uint_as_float((b.w & 0x3fffffffu) + p));
-        }
+        r = hash32(r ^ a.x ^ a.y ^ a.w ^ b.x ^ b.y ^ b.z);   // every component is used: the loads stay two dwordx4
+        // half-rate VALU work (v_min / v_max, like the slab test): `pad` x 8 instructions in four independent chains, as
+        // inline assembly so that the count is what it says (fminf / fmaxf would add a canonicalising v_max each)
+        const float x0 = __uint_as_float(a.z & 0x3fffffffu), x1 = __uint_as_float(b.w & 0x3fffffffu);
+        for (int p = 0; p < pad; p++)
+            asm volatile("v_min_f32 %0, %0, %4\n v_max_f32 %1, %1, %5\n v_min_f32 %2, %2, %5\n v_max_f32 %3, %3, %4\n"
+                         "v_min_f32 %0, %0, %5\n v_max_f32 %1, %1, %4\n v_min_f32 %2, %2, %4\n v_max_f32 %3, %3, %5\n"
+                         : "+v"(acc), "+v"(acc1), "+v"(acc2), "+v"(acc3) : "v"(x0), "v"(x1));
         if (PAIR && (s & 1) == 0) {
             idx ^= 1u + (r & 2u);   // every other fetch stays in the 128-byte line of the one before (a record next to it)
         } else if (TREE) {
-            uint32_t lvl = (r >> 24) % (uint32_t)(log2n + 1);   // level 0..log2n, each equally likely
+            uint32_t lvl = ((r >> 24) * (uint32_t)(log2n + 1)) >> 8;   // level 0..log2n, each (almost) equally likely; no division
             uint32_t base = (lvl == 0) ? 0u : ((1u << lvl) - 1u);
             idx = (base + ((r >> 2) & ((1u << lvl) - 1u))) & mask;
         } else {
             idx = r & mask;
         }
     }
-    out[gid] = r ^ __float_as_uint(acc);
+    out[gid] = r ^ __float_as_uint(acc) ^ __float_as_uint(acc1) ^ __float_as_uint(acc2) ^ __float_as_uint(acc3);
 }
 
 template <int LOADS, bool TREE, bool PAIR = false>
@@ -73,8 +77,8 @@ int main() {
     printf("G records/s (32-byte record = 2 x dwordx4 unless noted); 8 waves per SIMD, dependent chain of 256 fetches per lane\n");
     for (int log2n : {15, 18, 20, 24}) {   // 1 MiB, 8 MiB, 32 MiB, 512 MiB tables
         for (int tree = 0; tree < 2; tree++) {
-            for (int pad : {0, 24, 48}) {
-                printf("table %4d MiB %-7s pad %2d v_min/max pairs:", (32 << log2n) >> 20, tree ? "tree" : "uniform", pad);
+            for (int pad : {0, 6, 12, 18}) {
+                printf("table %4d MiB %-7s +%3d VALU:", (32 << log2n) >> 20, tree ? "tree" : "uniform", 8 * pad);
                 for (int live : {8, 16, 32, 48, 64}) {
                     double g = tree ? run<2, true>(tab, log2n, live, pad, out) : run<2, false>(tab, log2n, live, pad, out);
                     printf("  live %2d: %6.1f", live, g);
@@ -87,10 +91,10 @@ int main() {
             }
         }
         // what a layout buys in which every other step finds its record in the line the step before has fetched
-        for (int pad : {0, 24, 36}) {
-            printf("table %4d MiB tree, every other fetch in the previous line, pad %2d:", (32 << log2n) >> 20, pad);
+        for (int pad : {0, 12}) {
+            printf("table %4d MiB tree, every other fetch in the previous line, +%3d VALU:", (32 << log2n) >> 20, 8 * pad);
             for (int live : {16, 32, 48, 64}) printf("  live %2d: %6.1f", live, run<2, true, true>(tab, log2n, live, pad, out));
-            printf("   (independent lines, pad %2d:", pad);
+            printf("   (independent lines:");
             for (int live : {32, 48}) printf(" live %2d: %6.1f", live, run<2, true, false>(tab, log2n, live, pad, out));
             printf(")\n");
         }
