@@ -289,17 +289,16 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 if (COUNT) nCap += capped ? 1u : 0u;
             }
         }
-        const unsigned long long pend = lane_mask(parkedNow);
-        const unsigned long long canStep = lane_mask(validBox && !parkedNow);
+        // wave-uniform bookkeeping, in scalar registers: np lanes wait for a leaf test, nl lanes have work of any kind
+        const uint32_t np = (uint32_t)__popcll(lane_mask(parkedNow));
+        const uint32_t nl = np + (uint32_t)__popcll(lane_mask(validBox && !parkedNow));
         if (COUNT) dg_steps++;
-        // wave-uniform: the cap, or too few lanes with work left (parked or able to step) to be worth a wave
-        const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && (uint32_t)__popcll(pend | canStep) < min_live));
-        if (pend == 0ull) {
-            if (canStep == 0ull) break;
-            if (!capHit) continue;
-        } else if (!capHit && canStep != 0ull && 2 * __popcll(pend) < __popcll(pend | canStep)) {
-            continue;  // keep stepping the others
-        }
+        if (nl == 0u) break;
+        // the cap, or too few lanes with work left to be worth a wave
+        const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && nl < min_live));
+        // keep stepping the others while fewer than half of the lanes with work wait for a leaf test (with nobody able
+        // to step, np == nl: the tests run)
+        if (!capHit && 2u * np < nl) continue;
         if (parkedNow) {  // testIntersectionPacked, :261-309
             // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
             const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
