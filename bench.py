@@ -336,6 +336,10 @@ def roofline(st, Rr, V, T, copy_gbs, scene, width, height, lanes_mode):
            "own_record_frac_of_infinity_cache_gather": own / sec / 1e9 / MALL_GATHER_GBS if sec > 0 else None,
            "node_visits_per_s": V / (st.traverse_ms * 1e-3) if st.traverse_ms > 0 else None,
            "measured_copy_gbs": copy_gbs, "R": int(Rr), "V": int(V), "T": int(T), "rank": 0}
+    if out["frac"] > 1.0:
+        out["frac_note"] = ("above 1: SURVEY 8(d)'s algorithmic figure prices a node visit at 64 B where the kernel fetches one 32-B "
+                            "record, most of them from L2 / Infinity Cache -- it is not an HBM utilisation (that is hbm_frac); "
+                            "own_record_* is what the kernel moves")
     if e is None:
         return out
     traffic = e.get("traffic_bytes_per_launch")
