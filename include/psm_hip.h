@@ -240,7 +240,7 @@ int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
  *               than min_live of its lanes have work left; resume launches are persistent waves striding over the
  *               continuation queue (psm_rt_set_traverse_adaptive)
  *   AUTO        (default) ADAPTIVE while the Pipeline is one of several frames in flight (psm_lanes_*: the other frames'
- *               kernels fill the tails the extra launches add; +11 % on C3), WHOLE for a frame on its own (it is bound
+ *               kernels fill the tails the extra launches add; +5 % on C3, +9 % on C5's scene), WHOLE for a frame on its own (it is bound
  *               by its longest ray, which extra launches serialise) and for intersections under min_rays rays.
  *               Further hierarchies of a multi-BVH queue always run WHOLE. */
 enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3 };

@@ -500,10 +500,10 @@ static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<Ph
     plan.clear();
     int mode = r->trav_mode;
     if (chain) return PSM_TRAVERSE_WHOLE;  // later hierarchies of a multi-BVH queue: rt_traverse<*, CHAIN>
-    // AUTO, measured on MI355X (DESIGN.md 5.2): with several frames in flight the ballot-triggered hand-over wins
-    // (2.78-2.82 against 3.11-3.17 ms per C3 frame: 31 % fewer VALU instructions, and the other frames' kernels fill
-    // the tails its extra launches add); a frame on its own is bound by its longest ray, which the extra launches
-    // serialise (5.0 against 3.6 ms of traversal), so it runs one launch.
+    // AUTO, measured on MI355X (DESIGN.md 4.2, 5.2): with several frames in flight the ballot-triggered hand-over wins
+    // (2.65 against 2.79 ms per C3 frame, 14.0 against 15.3 on C5's scene: fewer VALU instructions, and the other frames'
+    // kernels fill the tails its extra launches add); a frame on its own is bound by its longest ray, which the extra
+    // launches serialise, so it runs one launch; so do rounds under phase_min_rays rays (tiles).
     if (mode == PSM_TRAVERSE_AUTO) mode = r->in_flight > 1 ? PSM_TRAVERSE_ADAPTIVE : PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_PHASED) {
