@@ -274,9 +274,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                     if (sp < STACK_CAP) stack[sp++][tid] = second;
                     else if (COUNT) nDrop++;
                 }
-                if (intL || intR) {
-                    cur = first;
-                } else {  // :467-476
+                cur = first;              // the nearer accepted internal child (a dead value when there is none)
+                if (!(intL || intR)) {    // :467-476
                     sp--;
                     if (sp >= 0) cur = stack[sp][tid];
                     else validBox = false;
@@ -293,12 +292,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         const uint32_t np = (uint32_t)__popcll(lane_mask(parkedNow));
         const uint32_t nl = np + (uint32_t)__popcll(lane_mask(validBox && !parkedNow));
         if (COUNT) dg_steps++;
-        if (nl == 0u) break;
         // the cap, or too few lanes with work left to be worth a wave
         const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && nl < min_live));
         // keep stepping the others while fewer than half of the lanes with work wait for a leaf test (with nobody able
-        // to step, np == nl: the tests run)
+        // to step, np == nl: the tests run; with nobody left at all, nl == 0, the wave is done)
         if (!capHit && 2u * np < nl) continue;
+        if (nl == 0u) break;
         if (parkedNow) {  // testIntersectionPacked, :261-309
             // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
             const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
