@@ -11,7 +11,10 @@
  * by line (file:line cited at every function) under the canonical determinism
  * rules written down in DESIGN.md; it is cross-checked by independent
  * properties in tests/ (naive bit-loop Morton, brute-force closest hit,
- * std-sort stability, BVH invariants).
+ * std-sort stability, BVH invariants), by second readings of the GLSL that
+ * do not come from this file (tests/independent_{build,traverse,
+ * camera_sampler,shade}.py), and its two host formulas are pinned by the
+ * reference's own vendored glm (oracle/ref_glm).
  *
  * Conventions
  *   - matrices are row-major float[16]: (M v)[i] = sum_j M[4*i+j] v[j]
