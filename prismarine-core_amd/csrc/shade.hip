@@ -438,8 +438,10 @@ template <bool TEX, bool MULTI>
 __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     __shared__ uint32_t scan_tmp[8];
     uint32_t it = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+    // the (at most) four rays a ray puts on the next queue, each in its own slot -- current, diffuse, reflection, shadow:
+    // the canonical order -- with a flag; every index below is a constant, so the slots live in registers, not in scratch
     OutRay outs[4];
-    uint32_t nout = 0;
+    bool have[4] = {false, false, false, false};
     if (it < a.nrays) {
         const uint32_t loc = queue_loc(a.q.bases, a.q.nb, a.nrays, it);
         float4 A = a.q.A[loc], B = a.q.B[loc], C = a.q.C[loc];
@@ -617,7 +619,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
             S_BOUNCE(ray.bf, bounce >= 0 ? bounce : 0);
             if (mlength3(ray.fin) >= 0.0001f && R_ACTIVE(ray.bf) == 0) deposit(ray.fin, in_texel, a.t_sum, a.t_flag);
             if (R_ACTIVE(ray.bf) == 1) {
-                OutRay& o = outs[nout++];
+                OutRay& o = outs[0];
+                have[0] = true;
                 o.A = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, __int_as_float(in_texel));
                 o.B = make_float4(ray.direct.x, ray.direct.y, ray.direct.z, __int_as_float(ray.bf));
                 o.C = make_float4(ray.color.x, ray.color.y, ray.color.z, __uint_as_float(in_pkey));
@@ -649,8 +652,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
                 r.fin = r.fin * 0.f;
                 r.origin = fma3(r.direct, GAP, r.origin);
             }
-            if (create_ray(diffuseRay, in_texel, child_key(in_pkey, 1u), outs[nout], a.t_sum, a.t_flag)) nout++;
-            if (create_ray(reflectionRay, in_texel, child_key(in_pkey, 2u), outs[nout], a.t_sum, a.t_flag)) nout++;
+            have[1] = create_ray(diffuseRay, in_texel, child_key(in_pkey, 1u), outs[1], a.t_sum, a.t_flag);
+            have[2] = create_ray(reflectionRay, in_texel, child_key(in_pkey, 2u), outs[2], a.t_sum, a.t_flag);
             {
                 float ce = pclamp(emis, 0.0f, 1.0f);
                 emissiveRay.color = emissiveRay.color * ce;
@@ -661,18 +664,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
             {  // applyLight, shadinglib.glsl:181-189
                 bool off = (R_TYPE(diffuseRay.bf) == 2) || (dot3(c_normal, shadowRay.direct) < 0.f);
                 S_ACTIVE(shadowRay.bf, off ? 0 : R_ACTIVE(shadowRay.bf));
-                if (create_ray(shadowRay, in_texel, child_key(in_pkey, 3u), outs[nout], a.t_sum, a.t_flag)) nout++;
+                have[3] = create_ray(shadowRay, in_texel, child_key(in_pkey, 3u), outs[3], a.t_sum, a.t_flag);
             }
         }
     }
     // ordered compaction into this workgroup's segment of the next queue
     uint32_t total;
+    const uint32_t nout = (uint32_t)have[0] + (uint32_t)have[1] + (uint32_t)have[2] + (uint32_t)have[3];
     uint32_t base = block_scan_excl<SHADE_BLOCK>(nout, scan_tmp, &total);
-    size_t seg = (size_t)blockIdx.x * QUEUE_SEG;
-    for (uint32_t k = 0; k < nout; k++) {
-        a.sA[seg + base + k] = outs[k].A;
-        a.sB[seg + base + k] = outs[k].B;
-        a.sC[seg + base + k] = outs[k].C;
+    size_t at = (size_t)blockIdx.x * QUEUE_SEG + base;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (have[k]) {
+            a.sA[at] = outs[k].A;
+            a.sB[at] = outs[k].B;
+            a.sC[at] = outs[k].C;
+            at++;
+        }
     }
     if (threadIdx.x == 0) a.blockCounts[blockIdx.x] = total;
 }
