@@ -1292,3 +1292,61 @@ def test_native_sharded_frames_equal_unsharded(psm, ctx, scenes, lanes, frames):
         assert np.array_equal(got[..., 3], want[..., 3])
         nd.close()
         b.close()
+
+
+def test_lifecycle_resizes_tiny_images_and_empty_inputs(psm, oracle, scenes):
+    """What a host does to the classes over an application's life (Viewer.cpp:56-63,231-242: resizeBuffers on every
+    window resize, clearTribuffer + loadMesh per scene): contexts created and destroyed, the ray grid resized between
+    frames (down to 1x1 and up again), a frame whose queue runs empty, an intersection over zero rays, a hierarchy
+    cleared and refilled with another triangle count while its build graph exists -- no error, no stale state: the
+    frame after all of it equals the oracle's."""
+    scene = scenes.cornell(open_top=True)
+    for _ in range(3):                                   # contexts come and go
+        c = psm.Context(0)
+        th = _load(psm, c, scene)
+        th.build()
+        th.close()
+        c.close()
+    ctx = psm.Context(0)
+    th = _load(psm, ctx, scene)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    rt = psm.Pipeline(ctx, seed=11)
+    for w, h in [(40, 30), (1, 1), (7, 3), (64, 48), (40, 30)]:
+        rt.resizeBuffers(w, h)
+        rt.resize(w, h)
+        for _ in range(2):
+            rounds = psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+            assert 0 <= rounds <= 16
+        img = rt.snapHdr()
+        assert img.shape[:2] == (h, w) and np.isfinite(img).all()
+    # a queue of zero rays: intersection and shade are no-ops, the count stays zero
+    rt.upload_rays(np.zeros(0, psm.RAY_DT))
+    assert rt.getRayCount() == 0
+    rt.intersection(th)
+    rt.applyMaterials(ms)
+    rt.shade(time=1)
+    assert rt.raycountCache == 0
+    # the hierarchy refilled with other triangle counts (its captured build graph belongs to the old count)
+    for n in (5, scene["tris"].shape[0], 12):
+        th.clearTribuffer()
+        th.loadTriangles(scene["tris"][:n], scene["normals"][:n], scene["mats"][:n])
+        for _ in range(3):
+            th.markDirty()
+            th.build()
+        ob = oracle.build_scene(scene["tris"][:n])
+        assert th.info().leaf_count == ob["count"]
+        assert np.array_equal(th.download(psm.BVH_KEYS, np.uint64, ob["count"]), ob["keys"])
+    # and after all of it a frame that equals the oracle's
+    th.clearTribuffer()
+    th.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+    w, h = 40, 30
+    rt2 = psm.Pipeline(ctx, seed=31337)
+    rt2.resizeBuffers(w, h)
+    rt2.resize(w, h)
+    for _ in range(2):
+        psm.render_frame(rt2, th, ms, scene["eye"], scene["view"])
+    ref, _ = oracle.render_frames(scene, w, h, frames=2, seed=31337, nthreads=8)
+    np.testing.assert_allclose(rt2.snapHdr()[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    rt.close(); rt2.close(); th.close(); ctx.close()
