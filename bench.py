@@ -208,8 +208,7 @@ class Renderer:
                         self.all_dev.copy_(got)
                         torch.cuda.synchronize()
                 if dist.rank == 0:
-                    for r in range(1, dist.world):
-                        ln.rays.unpack_texels_dev(True, r, dist.world, self.all_dev.data_ptr() + r * self.per * 4)
+                    ln.rays.unpack_tiles_dev(dist.world, 0, self.all_dev.data_ptr(), self.per)  # the other ranks' tiles, one launch
                     if dist.backend == "nccl":  # all_dev is reused by the next lane's gather
                         torch.cuda.current_stream().wait_stream(self.lane_streams[s])
                     batch.fold_one(ln)
@@ -252,8 +251,7 @@ class Renderer:
                 self.all_dev.copy_(got)
                 torch.cuda.synchronize()
         if dist.rank == 0:
-            for r in range(1, dist.world):
-                self.rt.unpack_texels_dev(True, r, dist.world, self.all_dev.data_ptr() + r * self.per * 4)
+            self.rt.unpack_tiles_dev(dist.world, 0, self.all_dev.data_ptr(), self.per)  # the other ranks' tiles, one launch
 
 
 def cpu_baseline(scene, ray_sets, args):

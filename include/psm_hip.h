@@ -280,6 +280,10 @@ int psm_rt_set_texels_dev(psm_rt* rt, uint32_t y0, uint32_t y1, const float* d_s
 int psm_rt_tile_texels(psm_rt* rt, uint32_t* count);
 int psm_rt_pack_texels_dev(psm_rt* rt, float* d_dst);
 int psm_rt_unpack_texels_dev(psm_rt* rt, int interleaved, uint32_t a, uint32_t b, const float* d_src);
+/* the gathering rank's side of the gather in one launch: d_all holds the dense tiles of ranks 0..world-1 of an interleaved
+ * sharding back to back, stride_floats apart (a multiple of 4, at least the largest tile: what a gather of equal-sized
+ * buffers delivers); every texel skip_rank does not own takes its radiance from its owner's tile */
+int psm_rt_unpack_tiles_dev(psm_rt* rt, uint32_t world, uint32_t skip_rank, const float* d_all, size_t stride_floats);
 /* ray count hand-off without a host read-back: copy the current count to a device int32 (on the
  * context's stream); tell the library the count the host learned elsewhere (e.g. from an all-gather) */
 int psm_rt_ray_count_dev(psm_rt* rt, int32_t* d_dst);

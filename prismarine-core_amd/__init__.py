@@ -30,7 +30,7 @@ EXPORTS = [
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
     "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
-    "psm_rt_unpack_texels_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
+    "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
     "psm_dist_unique_id", "psm_dist_init", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
@@ -467,6 +467,11 @@ class Pipeline:
 
     def pack_texels_dev(self, dev_ptr):
         self.ctx.check(lib().psm_rt_pack_texels_dev(self._h, C.c_void_p(dev_ptr)), "psm_rt_pack_texels_dev")
+
+    def unpack_tiles_dev(self, world, skip_rank, dev_ptr, stride_floats):
+        """all the other ranks' gathered tiles (dense, stride_floats apart) into this image in one launch"""
+        self.ctx.check(lib().psm_rt_unpack_tiles_dev(self._h, C.c_uint32(world), C.c_uint32(skip_rank), C.c_void_p(dev_ptr),
+                                                     C.c_size_t(stride_floats)), "psm_rt_unpack_tiles_dev")
 
     def unpack_texels_dev(self, interleaved, a, b, dev_ptr):
         self.ctx.check(lib().psm_rt_unpack_texels_dev(self._h, C.c_int(int(interleaved)), C.c_uint32(a), C.c_uint32(b),

@@ -680,6 +680,12 @@ int psm_rt_unpack_texels_dev(psm_rt* r, int interleaved, uint32_t a, uint32_t b,
     (void)hipSetDevice(r->ctx->device);
     return launch_rt_pack(r, const_cast<float*>(d_src), 1, interleaved ? 1u : 0u, a, b);
 }
+int psm_rt_unpack_tiles_dev(psm_rt* r, uint32_t world, uint32_t skip_rank, const float* d_all, size_t stride_floats) {
+    if (!r || !d_all || !r->t_sum || world == 0 || (stride_floats & 3u)) return PSM_ERR_INVALID;
+    if (stride_floats < (size_t)interleaved_texels(0, world, r->w, r->h) * 4) return set_err(r->ctx, PSM_ERR_CAPACITY, "psm_rt_unpack_tiles_dev: stride smaller than the largest tile");
+    (void)hipSetDevice(r->ctx->device);
+    return launch_rt_unpack_all(r, d_all, world, skip_rank, stride_floats);
+}
 int psm_rt_ray_count_dev(psm_rt* r, int32_t* d_dst) {
     if (!r || !d_dst) return PSM_ERR_INVALID;
     psm_ctx* c = r->ctx;

@@ -44,11 +44,6 @@ static int nccl_err(psm_ctx* c, ncclResult_t r, const char* what) {
         if (r__ != ncclSuccess) return psm::nccl_err((ctx), r__, #call); \
     } while (0)
 
-static uint32_t interleaved_texels(uint32_t rank, uint32_t world, uint32_t w, uint32_t h) {
-    uint32_t rows = 0;
-    for (uint32_t g = rank; g * 8 < h; g += world) rows += (h - g * 8) < 8u ? (h - g * 8) : 8u;
-    return rows * w;
-}
 }  // namespace psm
 
 using namespace psm;
@@ -147,9 +142,8 @@ int psm_dist_gather_tiles(psm_dist* d, psm_rt* rt) {
         ncclResult_t r = ncclGather(d->d_send, d->d_recv, per, ncclFloat, 0, d->comm, d->stream);
         if (r != ncclSuccess) rc = nccl_err(c, r, "ncclGather");
     }
-    if (rc == PSM_OK && d->rank == 0 && !emulated)
-        for (int q = 1; q < d->world && rc == PSM_OK; q++)
-            rc = launch_rt_pack(rt, d->d_recv + (size_t)q * per, 1, 1u, (uint32_t)q, (uint32_t)d->world);
+    if (rc == PSM_OK && d->rank == 0 && !emulated && d->world > 1)   // every other rank's tile into the image, one launch
+        rc = launch_rt_unpack_all(rt, d->d_recv, (uint32_t)d->world, 0u, per);
     c->stream = keep;
     if (rc != PSM_OK) return rc;
     // ... and hands back: whatever the Pipeline's stream does next (sample(), the next camera()) sees the gathered image

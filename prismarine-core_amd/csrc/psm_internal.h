@@ -205,7 +205,14 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
 int launch_rt_sample(psm_rt* r, psm_rt* src);
 int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b);
+int launch_rt_unpack_all(psm_rt* r, const float* d_all, uint32_t world, uint32_t skip, size_t stride_floats);
 int launch_rt_gather_queue(psm_rt* r, float4* d_dense, uint32_t m);  // current queue in queue order: A | B | C, m rays each
 uint32_t tile_texel_count(const psm_rt* r);
+// texels rank `rank` of `world` owns when 8-row bands are dealt round-robin (rank 0 owns the most)
+inline uint32_t interleaved_texels(uint32_t rank, uint32_t world, uint32_t w, uint32_t h) {
+    uint32_t rows = 0;
+    for (uint32_t g = rank; g * 8 < h; g += world) rows += (h - g * 8) < 8u ? (h - g * 8) : 8u;
+    return rows * w;
+}
 
 }  // namespace psm

@@ -781,6 +781,21 @@ __global__ __launch_bounds__(256) void rt_pack(float4* __restrict__ t_sum, float
     else buf[d] = t_sum[idx];
 }
 
+// the gathering rank's side of the tile gather in ONE launch: `all` holds the dense tiles of ranks 0..world-1 of an
+// interleaved sharding back to back (stride floats4 each, what ncclGather delivers); every texel that `skip` does not
+// own takes its radiance from its owner's tile. (One rt_pack launch per peer walked the whole image seven times.)
+__global__ __launch_bounds__(256) void rt_unpack_all(float4* __restrict__ t_sum, const float4* __restrict__ all, uint32_t w,
+                                                     uint32_t h, uint32_t world, uint32_t skip, size_t stride) {
+    uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= w * h) return;
+    uint32_t x = idx % w, y = idx / w;
+    uint32_t g = y >> 3;
+    uint32_t q = g % world;
+    if (q == skip) return;
+    size_t d = (size_t)((g / world) * 8 + (y - g * 8)) * w + x;   // tile_row(): owned rows before the band + row in the band
+    t_sum[idx] = all[(size_t)q * stride + d];
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 static Tile make_tile(const psm_rt* r) {
     Tile t;
@@ -804,6 +819,14 @@ int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t 
     t.mode = mode; t.a = a; t.b = b; t.h = r->h;
     uint32_t n = r->w * r->h;
     rt_pack<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (float4*)d_buf, r->w, r->h, t, unpack);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+int launch_rt_unpack_all(psm_rt* r, const float* d_all, uint32_t world, uint32_t skip, size_t stride_floats) {
+    psm_ctx* c = r->ctx;
+    uint32_t n = r->w * r->h;
+    rt_unpack_all<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (const float4*)d_all, r->w, r->h, world, skip, stride_floats / 4);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }

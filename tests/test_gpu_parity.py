@@ -718,6 +718,20 @@ def test_interleaved_tiles_camera_and_gather(psm, ctx, oracle, scenes):
     assert want[:, :3].max() > 0.1
     np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=1e-5, atol=1e-6)
     assert np.array_equal(got[:, 3], want[:, 3])
+    # the same gather the way psm_dist_gather_tiles does it on the gathering rank: every rank's dense tile back to back
+    # (what ncclGather delivers, stride = the largest tile), then ONE launch that fills every texel rank 1 does not own
+    # -- here into rank 1's pipeline, so that the skipped rank is not always 0
+    hall = ctx.buf_alloc(per * world)
+    pall, _ = ctx.buf_ptr(hall)
+    for r in range(world):
+        pipes[r].pack_texels_dev(pall + r * per)
+    pipes[1].unpack_tiles_dev(world, 1, pall, per // 4)
+    got1, _, _ = pipes[1].download_texels()
+    np.testing.assert_allclose(got1[:, :3], want[:, :3], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(got1[:, 3], want[:, 3])
+    with pytest.raises(psm.PsmError):
+        pipes[1].unpack_tiles_dev(world, 1, pall, per // 4 - 4)   # a stride smaller than the largest tile is refused
+    ctx.buf_free(hall)
     ctx.buf_free(hb)
     for rt in pipes + [full, rt0]:
         rt.close()
