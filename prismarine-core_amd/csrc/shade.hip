@@ -768,17 +768,16 @@ __global__ __launch_bounds__(256) void rt_sample(uint32_t w, uint32_t h, uint32_
     filtered[it] = xs;
 }
 
-// dense <-> full-image copy of a tile's per-texel radiance (tile gather)
-__global__ __launch_bounds__(256) void rt_pack(float4* __restrict__ t_sum, float4* __restrict__ buf, uint32_t w, uint32_t h,
+// dense <-> full-image copy of a tile's per-texel radiance (tile gather): one thread per texel OF THE TILE
+// (dense index k = owned row * w + x), not per texel of the image
+__global__ __launch_bounds__(256) void rt_pack(float4* __restrict__ t_sum, float4* __restrict__ buf, uint32_t w, uint32_t ntile,
                                                Tile tile, int unpack) {
-    uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= w * h) return;
-    uint32_t x = idx % w, y = idx / w;
-    TileRow tr = tile_row(tile, y);
-    if (!tr.owned) return;
-    size_t d = (size_t)(tr.local_base + (y - tr.by)) * w + x;
-    if (unpack) t_sum[idx] = buf[d];
-    else buf[d] = t_sum[idx];
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ntile) return;
+    uint32_t lr = k / w, x = k - lr * w;
+    uint32_t idx = tile_owned_row(tile, lr) * w + x;
+    if (unpack) t_sum[idx] = buf[k];
+    else buf[k] = t_sum[idx];
 }
 
 // the gathering rank's side of the tile gather in ONE launch: `all` holds the dense tiles of ranks 0..world-1 of an
@@ -817,8 +816,9 @@ int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t 
     psm_ctx* c = r->ctx;
     Tile t;
     t.mode = mode; t.a = a; t.b = b; t.h = r->h;
-    uint32_t n = r->w * r->h;
-    rt_pack<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (float4*)d_buf, r->w, r->h, t, unpack);
+    uint32_t n = (mode ? interleaved_texels(a, b, r->w, r->h) : (b - a) * r->w);  // texels of the tile
+    if (n == 0) return PSM_OK;
+    rt_pack<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (float4*)d_buf, r->w, n, t, unpack);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }
