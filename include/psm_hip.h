@@ -149,7 +149,9 @@ int psm_bvh_stage_morton(psm_bvh* bvh);                     /* aabbmaker.comp */
 int psm_bvh_stage_sort(psm_bvh* bvh);                       /* Radix.hpp:47-74 */
 int psm_bvh_stage_emit(psm_bvh* bvh);                       /* build-new + child-link + refit */
 
-/* Debug / parity downloads (synchronise). `what`: */
+/* Debug / parity downloads (synchronise). `what` (PAIR_BOX, LINK and RANGE -- the nodes in the reference's terms -- are not
+ * written by a build, whose traversal reads its own 32-byte record: the first download after a build produces them from the
+ * build's still-resident inputs; PSM_ERR_STATE once the next build has begun): */
 enum {
     PSM_BVH_KEYS = 0,      /* uint64[leaf_count]   sorted Morton codes (unsorted before stage_sort) */
     PSM_BVH_INDICES = 1,   /* uint32[leaf_count]   MortonIndices */

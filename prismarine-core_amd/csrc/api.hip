@@ -388,6 +388,7 @@ int psm_bvh_stage_bounds(psm_bvh* b, const double* opt) {
     static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     PSM_HIP(c, hipMemcpyAsync(b->d_opt, opt ? opt : ident, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (opt) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    b->built = false;  // a new build has begun: the node records of the last one can no longer be produced (psm_bvh_download)
     int rc = launch_bvh_bounds(b);
     if (rc == PSM_OK) b->bounds_done = true;
     return rc;
@@ -488,6 +489,7 @@ int psm_bvh_build(psm_bvh* b, const double* opt) {
     }
     c->sort_error_word = b->graph_error_word;
     b->bounds_done = b->morton_done = b->sort_done = b->built = true;
+    b->records_valid = false;
     return PSM_OK;
 }
 
@@ -538,6 +540,12 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
         default: return set_err(c, PSM_ERR_INVALID, "psm_bvh_download: unknown item");
     }
     if (bytes > b->cap * elem) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_download: too many bytes");
+    if (what == PSM_BVH_PAIR_BOX || what == PSM_BVH_LINK || what == PSM_BVH_RANGE) {
+        // the reference-shaped node records are not written by a build (traversal reads its own 32-byte record)
+        if (!b->built) return set_err(c, PSM_ERR_STATE, "psm_bvh_download: node records before a build");
+        int rc = launch_bvh_emit_records(b);
+        if (rc != PSM_OK) return rc;
+    }
     PSM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     return sort_check(c);

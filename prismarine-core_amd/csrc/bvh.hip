@@ -435,6 +435,10 @@ PSM_D int find_split(const uint64_t* __restrict__ keys, int first, int last) {
 //    first delta = nlz(key[s]^key[s+1]) bits with key[s];
 //  * keys equal across the gap: the gap lies inside a run of equal keys [a,b]; the run is a node
 //    of the reference tree and below it findSplit halves ranges at (first+last)>>1.
+// RECORDS: also write the per-node records in the reference's terms (child boxes as 2 x uvec4, links, ranges) that
+// psm_bvh_download hands out for parity checks. Traversal reads node32 only, so a build writes 32 of the 80 bytes per
+// node; the records are produced on demand by running the kernel again on the build's (still resident) inputs.
+template <bool RECORDS>
 __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ keys, const int32_t* __restrict__ sorted_tri,
                                                 SegTree st, uint32_t* __restrict__ sm, uint4* __restrict__ pairbox,
                                                 int2* __restrict__ link, int2* __restrict__ range,
@@ -504,10 +508,12 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     lk.y = (s + 1 == l) ? ~sorted_tri[l] : find_split(keys, s + 1, l);
     uint4 lb = key_to_box(seg_query(st, (uint32_t)f, (uint32_t)s));          // refit.comp:91-98
     uint4 rb = key_to_box(seg_query(st, (uint32_t)(s + 1), (uint32_t)l));
-    pairbox[2 * (size_t)s + 0] = lb;
-    pairbox[2 * (size_t)s + 1] = rb;
-    link[s] = lk;
-    range[s] = make_int2(f, l);
+    if (RECORDS) {
+        pairbox[2 * (size_t)s + 0] = lb;
+        pairbox[2 * (size_t)s + 1] = rb;
+        link[s] = lk;
+        range[s] = make_int2(f, l);
+    }
     // traversal record (trace.hip): xyz of both child boxes (the w halves are never read by the
     // slab test) + both links = 32 bytes, one aligned pair of 16-byte loads per visit
     node32[2 * (size_t)s + 0] = make_uint4(lb.x, (lb.y & 0xffffu) | (lb.z << 16), (lb.z >> 16) | (lb.w << 16), rb.x);
@@ -571,9 +577,26 @@ int launch_bvh_emit(psm_bvh* b) {
     st.seg = b->d_seg;
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
     uint32_t grid = (n + 255u) / 256u;
-    bvh_emit<<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
-                                          b->d_range, b->d_node32);
+    bvh_emit<false><<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
+                                                 b->d_range, b->d_node32);
+    b->records_valid = false;
     PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+// the per-node records of the last build (psm_bvh_download: PAIR_BOX, LINK, RANGE), produced when first asked for
+int launch_bvh_emit_records(psm_bvh* b) {
+    psm_ctx* c = b->ctx;
+    uint32_t n = b->tri_count;
+    if (n == 0 || b->records_valid) return PSM_OK;
+    int nlev = (int)b->seg_off.size() - 1;
+    SegTree st;
+    st.seg = b->d_seg;
+    for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
+    bvh_emit<true><<<(n + 255u) / 256u, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
+                                                             b->d_range, b->d_node32);
+    PSM_HIP(c, hipGetLastError());
+    b->records_valid = true;
     return PSM_OK;
 }
 

@@ -108,6 +108,7 @@ struct psm_bvh {
     int2* d_link = nullptr;
     int2* d_range = nullptr;
     uint4* d_node32 = nullptr;    // traversal record per internal node: 12 fp16 box coords + 2 links (32 B)
+    bool records_valid = false;   // d_pairbox / d_link / d_range hold the last build's records (written on demand)
     // the build as one hipGraph (34 launches at C3): captured on the second build of a triangle count, replayed afterwards
     bool use_graph = true;
     hipGraphExec_t build_graph = nullptr;
@@ -198,6 +199,7 @@ int sort_reserve(psm_ctx* c, size_t n_max);
 int launch_bvh_bounds(psm_bvh* b);
 int launch_bvh_morton(psm_bvh* b);
 int launch_bvh_emit(psm_bvh* b);
+int launch_bvh_emit_records(psm_bvh* b);
 int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
 int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views);
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
