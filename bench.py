@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32, help="timed frames (with 4 in flight a run of 8 is half ramp-up and drain)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="sponza_like", choices=["sponza_like", "cornell", "stress"])
