@@ -92,7 +92,7 @@ namespace NSM {
         }
 
         // The same frames tile-sharded over the GPUs of a node (one process per GPU; psm_dist_init has built `dist` and
-        // every lane carries psm_rt_set_tile_interleaved(rank, world)): psm_dist_render_batch per `lanes` frames -- the
+        // every lane carries psm_rt_set_tile_interleaved(rank, world)): psm_dist_render_frames over all the frames -- the
         // path's one collective per frame is the tile gather to rank 0, whose accumulator() holds the image. Every rank
         // calls this with the same arguments. Set GPU_MAX_HW_QUEUES=8 in the environment before the first HIP call: the
         // runtime's default of 4 hardware queues makes lanes share queues.
@@ -102,17 +102,16 @@ namespace NSM {
             glm::mat4 ci = glm::inverse(glm::lookAt(eye, view, glm::vec3(0.0f, 1.0f, 0.0f))), pi = glm::inverse(persp);
             float camInv[16], projInv[16];
             for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { camInv[4 * r + c] = ci[c][r]; projInv[4 * r + c] = pi[c][r]; }
-            for (uint32_t f0 = 0; f0 < frames; f0 += (uint32_t)ctxs.size()) {
-                size_t n = std::min<size_t>(ctxs.size(), frames - f0);
-                std::vector<uint32_t> seeds(n);
-                for (auto & sd : seeds) sd = master->nextRand();
-                std::vector<psm_rt *> rts;
-                std::vector<psm_bvh *> bvhs;
-                for (size_t s = 0; s < n; s++) { rays[s]->syncUniforms(); rts.push_back(rays[s]->handle()); bvhs.push_back(objs[s]->handle()); }
-                check(psm_dist_render_batch(dist, rts.data(), bvhs.data(), (uint32_t)n, camInv, projInv, seeds.data(), depth, rebuild ? 1 : 0,
-                                            nullptr, master->handle(), nullptr), "FrameBatch::renderSharded");
-                for (size_t s = 0; s < n; s++) rays[s]->noteTraced(objs[s]);
-            }
+            // all frames in one call: the lanes form two groups that alternate batches, so no batch drains before the next
+            // one starts (psm_dist_render_frames); one rand() draw of the accumulating Pipeline seeds each frame
+            std::vector<uint32_t> seeds(frames);
+            for (auto & sd : seeds) sd = master->nextRand();
+            std::vector<psm_rt *> rts;
+            std::vector<psm_bvh *> bvhs;
+            for (size_t s = 0; s < ctxs.size(); s++) { rays[s]->syncUniforms(); rts.push_back(rays[s]->handle()); bvhs.push_back(objs[s]->handle()); }
+            check(psm_dist_render_frames(dist, rts.data(), bvhs.data(), (uint32_t)rts.size(), camInv, projInv, seeds.data(), frames, depth,
+                                         rebuild ? 1 : 0, nullptr, master->handle(), nullptr), "FrameBatch::renderSharded");
+            for (size_t s = 0; s < ctxs.size(); s++) rays[s]->noteTraced(objs[s]);
         }
     };
 }

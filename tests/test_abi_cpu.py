@@ -76,3 +76,14 @@ def test_dropin_headers_compile_and_link(tmp_path):
                            "-L", os.path.join(ROOT, "prismarine-core_amd"), "-lpsm_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "prismarine-core_amd")])
     assert os.path.exists(exe)
+
+
+def test_sharded_frame_batch_compiles_and_links(tmp_path):
+    """psm::FrameBatch::renderSharded (the C++ mirror of the tile-sharded path, psm_dist_render_frames underneath) compiles
+    warning-free against the C ABI's declarations and links against libpsm_hip.so (no GPU needed to build it)."""
+    exe = str(tmp_path / "frame_batch_sharded")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-DPSM_NO_SYSTEM_GLM",
+                           os.path.join(ROOT, "tests", "cpp", "frame_batch_sharded.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "prismarine-core_amd"), "-lpsm_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "prismarine-core_amd")])
+    assert os.path.exists(exe)
