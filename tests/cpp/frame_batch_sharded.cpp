@@ -1,4 +1,5 @@
 #include "Prismarine/Prismarine.hpp"
+#include "Prismarine/Implementations.hpp"   // as the reference: one translation unit of the application includes the bodies
 #include "Prismarine/FrameBatch.hpp"
 // compile-only: the sharded entry point of the header layer against the C ABI's declarations
 void use(psm_dist * d, psm::FrameBatch & b) { b.renderSharded(d, 16, glm::vec3(0, 6, 6), glm::vec3(0, 2, 0), 16, true); }
