@@ -32,7 +32,9 @@ typedef enum {
     PSM_ERR_HIP = -2,         /* a HIP runtime call failed; see psm_last_error */
     PSM_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
     PSM_ERR_CAPACITY = -4,    /* exceeds an allocated capacity */
-    PSM_ERR_STATE = -5        /* call order violated (e.g. traverse before build) */
+    PSM_ERR_STATE = -5,       /* call order violated (e.g. traverse before build) */
+    PSM_ERR_PEER = -6         /* tile-sharded frames: another rank reported a failure or did not arrive; every rank
+                                 of the communicator returns from the same psm_dist_* call with an error */
 } psm_status;
 
 typedef struct psm_ctx psm_ctx;
@@ -199,6 +201,12 @@ int psm_rt_set_tile(psm_rt* rt, uint32_t y0, uint32_t y1);
  * camera() then touches only the owned texels -- except on rank 0, the rank the tiles are gathered to, which
  * also prepares the jitter positions / flags of all other texels because its sample() reads the whole image. */
 int psm_rt_set_tile_interleaved(psm_rt* rt, uint32_t rank, uint32_t world);
+/* the same with a weighted dealing: the bands go round in periods of P = weights[0] + ... + weights[world-1] <= 64, rank r
+ * owning weights[r] bands of every period, laid out by a smooth weighted round-robin (each step every rank's credit grows
+ * by its weight, the largest credit -- lowest rank on ties -- takes the band and pays P) so that a rank's bands are
+ * spread evenly over the image. weights NULL = 1 each = psm_rt_set_tile_interleaved. The gathering rank also unpacks,
+ * fills and samples the whole image, so it is given fewer bands than the workers (8 GPUs: 2 of every 23 against 3). */
+int psm_rt_set_tile_weighted(psm_rt* rt, uint32_t rank, uint32_t world, const uint32_t* weights);
 /* lightColor/lightVector/lightOffset/lightAmbient + setLightCount, Pipeline.hpp:103-121 */
 int psm_rt_set_lights(psm_rt* rt, const psm_light* lights, uint32_t count);
 /* environment: constant colour ... */
@@ -355,6 +363,34 @@ int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lan
 typedef struct psm_dist psm_dist;
 int psm_dist_unique_id(uint8_t id[128]);                        /* ncclGetUniqueId */
 int psm_dist_init(psm_ctx* ctx, int rank, int world, const uint8_t id[128], psm_dist** out); /* ncclCommInitRank on ctx's device; collective */
+/* The same in two steps, for launchers that want to agree between them: psm_dist_prepare creates this rank's LOCAL
+ * resources only (stream, events; cannot block on a peer), psm_dist_connect is the collective ncclCommInitRank. A rank
+ * whose prepare failed can tell the others over the side channel before anybody is inside the collective. */
+int psm_dist_prepare(psm_ctx* ctx, int rank, int world, psm_dist** out);
+int psm_dist_connect(psm_dist* dist, const uint8_t id[128]);
+/* The transport seam: the two exchanges of the path as a table of functions. psm_dist_init / psm_dist_connect install
+ * RCCL (ncclGather / ncclAllGather on the communicator's stream, stream-ordered); psm_dist_connect_transport installs
+ * the caller's table instead, and psm_dist_connect_hoststaged a transport built into the library that stages through a
+ * POSIX shared-memory segment (hipMemcpy to the host, sequence counters, bounded waits), so that several processes
+ * SHARING ONE GPU -- which RCCL refuses -- can drive the whole sharded scheduler against real peers (tests; never
+ * chosen silently). A transport function returns 0 or non-zero; it may complete on `hip_stream` (a hipStream_t) or
+ * synchronously on the host. All pointers are device pointers. */
+typedef struct {
+    void* user;
+    /* `count` floats of every rank at d_send -> root's d_recv[world * count] in rank order (d_recv is NULL elsewhere) */
+    int (*gather_f32)(void* user, const float* d_send, float* d_recv, size_t count, int root, void* hip_stream);
+    /* n ints of every rank at d_send -> every rank's d_recv[world * n] in rank order */
+    int (*allgather_i32)(void* user, const int32_t* d_send, int32_t* d_recv, size_t n, void* hip_stream);
+    void (*destroy)(void* user);            /* may be NULL */
+    const char* (*last_error)(void* user);  /* may be NULL */
+    const char* name;                       /* e.g. "rccl", "host-staged" */
+} psm_dist_transport;
+int psm_dist_connect_transport(psm_dist* dist, const psm_dist_transport* transport);
+/* shm_name: a POSIX shared-memory name every rank of the group passes ("/psm-<unique>"); rank 0 creates it and unlinks
+ * it once all ranks are attached. slot_bytes >= the largest tile of a gather (16 B x the texels rank 0 owns);
+ * timeout_ms bounds every wait for a peer (PSM_ERR_PEER afterwards, on every rank that waits). */
+int psm_dist_connect_hoststaged(psm_dist* dist, const char* shm_name, size_t slot_bytes, uint32_t timeout_ms);
+const char* psm_dist_transport_name(const psm_dist* dist);     /* NULL while not connected */
 int psm_dist_destroy(psm_dist* dist);
 int psm_dist_rank(const psm_dist* dist);
 int psm_dist_world(const psm_dist* dist);
@@ -364,15 +400,25 @@ int psm_dist_gather_tiles(psm_dist* dist, psm_rt* rt);
 /* n ints from every rank to every rank (host arrays: recv holds world * n); synchronises */
 int psm_dist_allgather_i32(psm_dist* dist, const int32_t* send, int32_t* recv, uint32_t n);
 int psm_dist_barrier(psm_dist* dist);
+/* every rank's own status (PSM_OK or its error code) -> one verdict for all: PSM_OK when every rank is fine, this rank's
+ * own code when it failed, PSM_ERR_PEER when only others did. One one-int all-gather; every rank must call it. */
+int psm_dist_agree(psm_dist* dist, int local_rc);
 /* the global `fewer than 32 rays -> stop` rule (Pipeline.inl:459-461) from every rank's answers: all = [world][2][lanes]
  * (rounds done, local rays waiting) as gathered after psm_lanes_run_sharded -> per lane: over (the frame has ended) and
- * force_until (the round every rank must reach next). Pure host arithmetic; needs no device. */
+ * force_until (the round every rank must reach next). Pure host arithmetic; needs no device.
+ * A rank that failed locally reports rounds = -1 for its lanes (it keeps taking part in the collectives so that nobody
+ * waits for it): any negative round makes psm_dist_decide return PSM_ERR_PEER on every rank at the same exchange. */
 int psm_dist_decide(uint32_t world, uint32_t lanes, const int32_t* all, uint32_t depth, int32_t* over, uint32_t* force_until);
 /* `lanes` tile-sharded frames in flight, start to finish, on this rank (every rank makes the same call): build (if
  * rebuild) + camera + rounds on lanes that run free and park on their local counts (psm_lanes_run_sharded), the
  * all-gathers + psm_dist_decide until every frame has ended, then per frame, in frame order, psm_dist_gather_tiles and on
  * rank 0 psm_rt_sample_from(fold_into, lane). rts[s] must carry psm_rt_set_tile_interleaved(rank, world); fold_into is
- * rank 0's accumulating Pipeline (ignored elsewhere); rounds_out[lanes] may be NULL. */
+ * rank 0's accumulating Pipeline (ignored elsewhere); rounds_out[lanes] may be NULL.
+ * Failure: a rank whose own work fails (build, kernels, capacity) keeps the collective sequence -- it reports rounds = -1
+ * at the next exchange and sends an empty tile to gathers already due -- so every rank leaves at the same exchange
+ * with an error (its own, or PSM_ERR_PEER) instead of waiting inside a collective; a last one-int exchange makes the
+ * return code agree when the failure came after the last decision. Only a failing transport call itself cannot be
+ * covered. */
 int psm_dist_render_batch(psm_dist* dist, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
                           const float proj_inv[16], const uint32_t* frame_seeds, uint32_t depth, int rebuild, const double* opt,
                           psm_rt* fold_into, uint32_t* rounds_out);
@@ -386,6 +432,9 @@ int psm_dist_render_frames(psm_dist* dist, psm_rt* const* rts, psm_bvh* const* b
 /* one-GPU rehearsal of a worker rank's per-frame cost: gathers pack tile (tile_rank, tile_world) instead of the
  * communicator's own (rank, world) and unpack nothing (the image is then not a complete frame) */
 int psm_dist_emulate_tile(psm_dist* dist, int tile_rank, int tile_world);
+/* the dealing of the bands this communicator's gathers pack and unpack (psm_rt_set_tile_weighted's weights; NULL =
+ * round-robin, the default). Every rank passes the same weights. */
+int psm_dist_set_band_weights(psm_dist* dist, const uint32_t* weights);
 
 /* ---------------------------------------------------------------------------------------------
  * statistics (PROFILE_RT replacement, Utils.hpp:27): algorithmic counters + HIP-event timing

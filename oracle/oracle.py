@@ -82,6 +82,8 @@ def lib():
         _lib.psmo_brute_force.restype = C.c_int
         _lib.psmo_camera.restype = C.c_int
         _lib.psmo_camera_interleaved.restype = C.c_int
+        _lib.psmo_camera_weighted.restype = C.c_int
+        _lib.psmo_band_pattern.restype = C.c_int
         _lib.psmo_shade.restype = C.c_int
         _lib.psmo_rand_next.restype = C.c_uint32
     return _lib
@@ -350,15 +352,23 @@ def camera(cfg, cam_inv, proj_inv, time, y0=0, y1=None):
     return rays[:n], coord, tsum, flag
 
 
-def camera_interleaved(cfg, cam_inv, proj_inv, time, rank, world):
+def band_pattern(world, weights=None):
+    pat = (C.c_uint8 * 64)()
+    wv = None if weights is None else (C.c_uint32 * world)(*[int(v) for v in weights])
+    n = lib().psmo_band_pattern(C.c_int(world), wv, pat)
+    return list(pat[:n])
+
+
+def camera_interleaved(cfg, cam_inv, proj_inv, time, rank, world, weights=None):
     wh = cfg.width * cfg.height
     rays = np.zeros(wh, RAY_DT)
     coord = np.zeros((wh, 2), np.float32)
     tsum = np.zeros((wh, 4), np.float32)
     flag = np.zeros(wh, np.int32)
-    n = lib().psmo_camera_interleaved(C.byref(cfg), _p(np.ascontiguousarray(cam_inv, np.float32)),
-                                      _p(np.ascontiguousarray(proj_inv, np.float32)), C.c_uint32(time),
-                                      C.c_int(rank), C.c_int(world), _p(rays), _p(coord), _p(tsum), _p(flag))
+    wv = None if weights is None else (C.c_uint32 * world)(*[int(v) for v in weights])
+    n = lib().psmo_camera_weighted(C.byref(cfg), _p(np.ascontiguousarray(cam_inv, np.float32)),
+                                   _p(np.ascontiguousarray(proj_inv, np.float32)), C.c_uint32(time),
+                                   C.c_int(rank), C.c_int(world), wv, _p(rays), _p(coord), _p(tsum), _p(flag))
     return rays[:n].copy(), coord, tsum, flag
 
 

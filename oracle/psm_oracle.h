@@ -172,6 +172,10 @@ typedef struct {
 int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
                 uint32_t time, int y0, int y1, psmo_ray* rays, float* texel_coord,
                 float* texel_sum, int32_t* texel_flag);
+int psmo_band_pattern(int world, const uint32_t* weights, uint8_t pattern[64]);
+int psmo_camera_weighted(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                         uint32_t time, int rank, int world, const uint32_t* weights, psmo_ray* rays, float* texel_coord,
+                         float* texel_sum, int32_t* texel_flag);
 int psmo_camera_interleaved(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
                             uint32_t time, int rank, int world, psmo_ray* rays, float* texel_coord,
                             float* texel_sum, int32_t* texel_flag);

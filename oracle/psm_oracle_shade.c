@@ -288,18 +288,50 @@ int psmo_camera(const psmo_frame_cfg* cfg, const float camInv[16], const float p
     return n;
 }
 
-/* interleaved sharding: rank owns the global 8-row bands g with g % world == rank */
-int psmo_camera_interleaved(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
-                            uint32_t time, int rank, int world, psmo_ray* rays, float* texel_coord,
-                            float* texel_sum, int32_t* texel_flag) {
+/* The dealing of the 8-row bands of a tile-sharded frame (not in the reference, which has one GPU; the build's own
+ * definition, csrc/psm_internal.h BandMap): band g belongs to rank pattern[g % P], P = sum of the weights, laid out by a
+ * smooth weighted round-robin -- every step each rank's credit grows by its weight, the largest credit (lowest rank on
+ * ties) takes the band and pays P. weights NULL = 1 each = g % world. Returns P (0: invalid). */
+int psmo_band_pattern(int world, const uint32_t* weights, uint8_t pattern[64]) {
+    if (world < 1 || world > 64) return 0;
+    long long P = 0, cur[64] = {0};
+    for (int r = 0; r < world; r++) P += weights ? weights[r] : 1u;
+    if (P < 1 || P > 64) return 0;
+    for (int p = 0; p < (int)P; p++) {
+        int pick = 0;
+        for (int r = 0; r < world; r++) {
+            cur[r] += weights ? weights[r] : 1u;
+            if (cur[r] > cur[pick]) pick = r;
+        }
+        cur[pick] -= P;
+        pattern[p] = (uint8_t)pick;
+    }
+    return (int)P;
+}
+
+/* sharding by bands: rank owns the global 8-row bands the dealing gives it */
+int psmo_camera_weighted(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                         uint32_t time, int rank, int world, const uint32_t* weights, psmo_ray* rays, float* texel_coord,
+                         float* texel_sum, int32_t* texel_flag) {
     int h = cfg->height;
     int ng = (h + 7) / 8, nb = 0;
+    uint8_t pat[64];
+    int P = psmo_band_pattern(world, weights, pat);
+    if (P == 0) return -1;
     int* by = (int*)malloc(sizeof(int) * (size_t)(ng + 1));
     int* bh = (int*)malloc(sizeof(int) * (size_t)(ng + 1));
-    for (int g = rank; g < ng; g += world) { by[nb] = 8 * g; bh[nb] = (h - 8 * g) < 8 ? (h - 8 * g) : 8; nb++; }
+    for (int g = 0; g < ng; g++)
+        if (pat[g % P] == rank) { by[nb] = 8 * g; bh[nb] = (h - 8 * g) < 8 ? (h - 8 * g) : 8; nb++; }
     int n = camera_bands(cfg, camInv, projInv, time, by, bh, nb, rays, texel_coord, texel_sum, texel_flag);
     free(by); free(bh);
     return n;
+}
+
+/* round-robin dealing: rank owns the global 8-row bands g with g % world == rank */
+int psmo_camera_interleaved(const psmo_frame_cfg* cfg, const float camInv[16], const float projInv[16],
+                            uint32_t time, int rank, int world, psmo_ray* rays, float* texel_coord,
+                            float* texel_sum, int32_t* texel_flag) {
+    return psmo_camera_weighted(cfg, camInv, projInv, time, rank, world, NULL, rays, texel_coord, texel_sum, texel_flag);
 }
 
 /* ------------------------------------------------------------------ */

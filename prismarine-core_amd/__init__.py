@@ -26,15 +26,16 @@ EXPORTS = [
     "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
-    "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved",
+    "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
     "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
-    "psm_dist_unique_id", "psm_dist_init", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
-    "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile",
+    "psm_dist_unique_id", "psm_dist_init", "psm_dist_prepare", "psm_dist_connect", "psm_dist_connect_transport", "psm_dist_connect_hoststaged",
+    "psm_dist_transport_name", "psm_dist_agree", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
+    "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile", "psm_dist_set_band_weights",
 ]
 
 TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)
@@ -456,9 +457,12 @@ class Pipeline:
     def setTile(self, y0, y1):
         self.ctx.check(lib().psm_rt_set_tile(self._h, C.c_uint32(y0), C.c_uint32(y1)), "psm_rt_set_tile")
 
-    def setTileInterleaved(self, rank, world):
-        self.ctx.check(lib().psm_rt_set_tile_interleaved(self._h, C.c_uint32(rank), C.c_uint32(world)),
-                       "psm_rt_set_tile_interleaved")
+    def setTileInterleaved(self, rank, world, weights=None):
+        """8-row bands dealt to the ranks: round-robin, or weights[r] bands of every period of sum(weights) for rank r
+        (psm_rt_set_tile_weighted; dist.band_pattern is the same dealing in Python)."""
+        wv = None if weights is None else (C.c_uint32 * world)(*[int(v) for v in weights])
+        self.ctx.check(lib().psm_rt_set_tile_weighted(self._h, C.c_uint32(rank), C.c_uint32(world), wv),
+                       "psm_rt_set_tile_weighted")
 
     def tile_texels(self):
         n = C.c_uint32()

@@ -666,12 +666,17 @@ int psm_rt_set_tile(psm_rt* r, uint32_t y0, uint32_t y1) {
     r->tile_root = true;
     return PSM_OK;
 }
-int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) {
+int psm_rt_set_tile_weighted(psm_rt* r, uint32_t rank, uint32_t world, const uint32_t* weights) {
     if (!r || world == 0 || rank >= world) return PSM_ERR_INVALID;
+    BandMap m;
+    if (!band_map_make(world, weights, &m))
+        return set_err(r->ctx, PSM_ERR_INVALID, "psm_rt_set_tile_weighted: at most 64 ranks, and the weights must add up to 1..64");
+    r->bands = m;
     r->tile_mode = 1; r->tile_rank = rank; r->tile_world = world;
     r->tile_root = rank == 0;  // tiles are gathered to rank 0 (psm_rt_unpack_texels_dev), which runs sample()
     return PSM_OK;
 }
+int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) { return psm_rt_set_tile_weighted(r, rank, world, nullptr); }
 int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {
     if (!r || !count) return PSM_ERR_INVALID;
     *count = tile_texel_count(r);
@@ -680,19 +685,29 @@ int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {
 int psm_rt_pack_texels_dev(psm_rt* r, float* d_dst) {
     if (!r || !d_dst || !r->t_sum) return PSM_ERR_INVALID;
     (void)hipSetDevice(r->ctx->device);
-    return launch_rt_pack(r, d_dst, 0, r->tile_mode, r->tile_mode ? r->tile_rank : r->y0, r->tile_mode ? r->tile_world : r->y1);
+    return launch_rt_pack(r, r->ctx->stream, d_dst, 0, r->tile_mode ? &r->bands : nullptr, r->tile_mode ? r->tile_rank : r->y0, r->tile_mode ? r->tile_world : r->y1);
+}
+// the dealing a (rank, world) pair of the unpack calls refers to: rt's own when it is sharded over `world` ranks
+// (psm_rt_set_tile_weighted on the gathering rank), the round-robin one otherwise
+static bool dealing_for(const psm_rt* r, uint32_t world, BandMap* m) {
+    if (r->tile_mode == 1 && r->tile_world == world) { *m = r->bands; return true; }
+    return band_map_make(world, nullptr, m);
 }
 int psm_rt_unpack_texels_dev(psm_rt* r, int interleaved, uint32_t a, uint32_t b, const float* d_src) {
     if (!r || !d_src || !r->t_sum) return PSM_ERR_INVALID;
     if (interleaved ? (b == 0 || a >= b) : (a > b || b > r->h)) return PSM_ERR_INVALID;
     (void)hipSetDevice(r->ctx->device);
-    return launch_rt_pack(r, const_cast<float*>(d_src), 1, interleaved ? 1u : 0u, a, b);
+    BandMap m;
+    if (interleaved && !dealing_for(r, b, &m)) return PSM_ERR_INVALID;
+    return launch_rt_pack(r, r->ctx->stream, const_cast<float*>(d_src), 1, interleaved ? &m : nullptr, a, b);
 }
 int psm_rt_unpack_tiles_dev(psm_rt* r, uint32_t world, uint32_t skip_rank, const float* d_all, size_t stride_floats) {
     if (!r || !d_all || !r->t_sum || world == 0 || (stride_floats & 3u)) return PSM_ERR_INVALID;
-    if (stride_floats < (size_t)interleaved_texels(0, world, r->w, r->h) * 4) return set_err(r->ctx, PSM_ERR_CAPACITY, "psm_rt_unpack_tiles_dev: stride smaller than the largest tile");
+    BandMap m;
+    if (!dealing_for(r, world, &m)) return PSM_ERR_INVALID;
+    if (stride_floats < (size_t)max_owned_texels(m, r->w, r->h) * 4) return set_err(r->ctx, PSM_ERR_CAPACITY, "psm_rt_unpack_tiles_dev: stride smaller than the largest tile");
     (void)hipSetDevice(r->ctx->device);
-    return launch_rt_unpack_all(r, d_all, world, skip_rank, stride_floats);
+    return launch_rt_unpack_all(r, r->ctx->stream, d_all, m, skip_rank, stride_floats);
 }
 int psm_rt_ray_count_dev(psm_rt* r, int32_t* d_dst) {
     if (!r || !d_dst) return PSM_ERR_INVALID;

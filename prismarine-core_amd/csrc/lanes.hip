@@ -341,13 +341,12 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
     if (!d || !rts || !bvhs || !cam_inv || !proj_inv || lanes == 0 || lanes > 64 || (frames && !frame_seeds)) return PSM_ERR_INVALID;
     const int rank = psm_dist_rank(d), world = psm_dist_world(d);
     if (rank == 0 && !fold_into) return PSM_ERR_INVALID;
-    for (uint32_t s = 0; s < lanes; s++) {
+    for (uint32_t s = 0; s < lanes; s++)
         if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
-        int e = lane_resources(rts[s]);
-        if (e != PSM_OK) return e;
-    }
     if (frames == 0) return PSM_OK;
     (void)hipSetDevice(rts[0]->ctx->device);
+    int pre = PSM_OK;  // from here on a failure is `local`: the other ranks are on their way into the exchanges
+    for (uint32_t s = 0; s < lanes && pre == PSM_OK; s++) pre = lane_resources(rts[s]);
     for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
     const uint32_t groups = lanes >= 2 ? 2u : 1u;
     const uint32_t h0 = groups == 2 ? lanes / 2 : lanes;         // group 0: lanes [0, h0), group 1: [h0, lanes)
@@ -366,44 +365,57 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
     auto start_batch = [&](const Batch& B) {
         for (uint32_t k = 0; k < B.n; k++) L.start(gbeg[B.g] + k, frame_seeds[B.f0 + k], cam_inv, proj_inv, rebuild, opt);
     };
-    for (size_t b = 0; b < batches.size() && b < groups; b++) start_batch(batches[b]);
-    int rc = L.rc;
+    // `local` is this rank's own failure. A failed rank keeps the collective sequence (rounds = -1 at the exchanges,
+    // placeholder tiles in gathers already decided) until an exchange has told everybody; `rc` is the call's fate as all
+    // ranks see it. Only a failing transport call leaves at once: there is no sequence left to keep.
+    int local = pre != PSM_OK ? pre : dist_reserve(d, rts[0]->w, rts[0]->h), rc = PSM_OK;
+    bool transport_dead = false;
+    if (local == PSM_OK) {
+        for (size_t b = 0; b < batches.size() && b < groups; b++) start_batch(batches[b]);
+        local = L.rc;
+    }
     std::vector<int32_t> mine, all, verdict;
     std::vector<uint32_t> force;
-    for (size_t b = 0; b < batches.size() && rc == PSM_OK; b++) {
+    for (size_t b = 0; b < batches.size() && rc == PSM_OK && !transport_dead; b++) {
         const Batch& B = batches[b];
         const uint32_t g0 = gbeg[B.g], n = B.n;
         mine.assign(2 * (size_t)n, 0); all.assign(2 * (size_t)n * (size_t)world, 0); verdict.assign(n, 0); force.assign(n, 0u);
         std::vector<int32_t> over(n, 0);
-        rc = L.drive(g0, g0 + n);
-        while (rc == PSM_OK) {
-            for (uint32_t k = 0; k < n; k++) {
+        if (local == PSM_OK) local = L.drive(g0, g0 + n);
+        for (;;) {
+            for (uint32_t k = 0; k < n && local == PSM_OK; k++) {
                 psm_rt* r = rts[g0 + k];
-                PSM_HIP(r->ctx, hipStreamSynchronize(r->ctx->stream));  // parked: its last count has been read; cheap
+                hipError_t e = hipStreamSynchronize(r->ctx->stream);  // parked: its last count has been read; cheap
+                if (e != hipSuccess) local = set_err(r->ctx, PSM_ERR_HIP, "hipStreamSynchronize (parked lane)", e);
                 mine[k] = (int32_t)rounds[g0 + k];
                 mine[n + k] = (int32_t)r->ray_count;
             }
+            if (local != PSM_OK) for (uint32_t k = 0; k < n; k++) mine[k] = -1;
+            const std::string keep = d->ctx->err;
             rc = psm_dist_allgather_i32(d, mine.data(), all.data(), 2 * n);
-            if (rc != PSM_OK) break;
+            if (rc != PSM_OK) { transport_dead = true; break; }
             rc = psm_dist_decide((uint32_t)world, n, all.data(), depth, verdict.data(), force.data());
-            if (rc != PSM_OK) break;
+            if (rc != PSM_OK) { if (local != PSM_OK) d->ctx->err = keep; break; }  // everybody leaves at this exchange
             bool done = true;
             for (uint32_t k = 0; k < n; k++) { over[k] |= verdict[k]; done = done && over[k]; }
             if (done) break;
             for (uint32_t k = 0; k < n; k++)
                 if (!over[k]) L.resume(g0 + k, force[k]);
-            rc = L.drive(g0, g0 + n);
+            local = L.rc;
+            if (local == PSM_OK) local = L.drive(g0, g0 + n);
         }
-        for (uint32_t k = 0; k < n && rc == PSM_OK; k++) {  // frame order
-            rc = psm_dist_gather_tiles(d, rts[g0 + k]);
-            if (rc == PSM_OK && rank == 0) rc = psm_rt_sample_from(fold_into, rts[g0 + k]);
+        if (rc != PSM_OK) break;
+        for (uint32_t k = 0; k < n; k++) {  // frame order; a rank that fails here still takes part in the gathers that are due
+            if (!dist_frame_gather(d, rts[g0 + k], fold_into, local)) { transport_dead = true; break; }
             if (rounds_out) rounds_out[B.f0 + k] = rounds[g0 + k];
         }
-        if (rc == PSM_OK && b + groups < batches.size()) {  // this group's next frames (their camera() waits for the gather: stream order)
+        if (!transport_dead && local == PSM_OK && b + groups < batches.size()) {  // this group's next frames (their camera() waits for the gather: stream order)
             start_batch(batches[b + groups]);
-            rc = L.rc;
+            local = L.rc;
         }
     }
+    if (!transport_dead && rc == PSM_OK) rc = psm_dist_agree(d, local);  // a failure after the last decision reaches everybody here
+    if (local != PSM_OK) rc = local;
     for (uint32_t s = 0; s < lanes; s++) {
         (void)hipStreamSynchronize(rts[s]->ctx->stream);
         rts[s]->in_flight = 1;

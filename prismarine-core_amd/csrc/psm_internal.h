@@ -52,6 +52,61 @@ struct Buf {
     size_t bytes = 0;
 };
 
+// Which rank owns the global 8-row band g of a tile-sharded frame: owner[g % P], a periodic dealing of P = sum of the
+// ranks' weights bands in which rank r gets weights[r] (all weights 1: g % world, the round-robin dealing). The period is
+// laid out by a smooth weighted round-robin, so a rank's bands are spread evenly over the image whatever its weight --
+// the gathering rank is given fewer bands than the others because it also unpacks, fills and samples the whole image
+// (DESIGN.md 6.1). The same function in dist.py (band_pattern); the tests hold a third statement of it.
+constexpr uint32_t MAX_BAND_PERIOD = 64;
+struct BandMap {
+    uint32_t P = 1, world = 1;
+    uint8_t owner[MAX_BAND_PERIOD] = {};   // position in the period -> rank
+    uint8_t before[MAX_BAND_PERIOD] = {};  // position -> positions before it with the same owner
+    uint8_t cnt[MAX_BAND_PERIOD] = {1};    // rank -> its bands per period
+    // the band's owner and its index among the owner's bands
+    __host__ __device__ uint32_t rank_of(uint32_t g) const { return owner[g % P]; }
+    __host__ __device__ uint32_t local_band(uint32_t g) const { const uint32_t p = g % P; return (g / P) * cnt[owner[p]] + before[p]; }
+};
+// weights NULL: all 1. False when world or the period exceed MAX_BAND_PERIOD or every weight is 0.
+inline bool band_map_make(uint32_t world, const uint32_t* weights, BandMap* m) {
+    if (world == 0 || world > MAX_BAND_PERIOD) return false;
+    uint64_t P = 0;
+    for (uint32_t r = 0; r < world; r++) P += weights ? weights[r] : 1u;
+    if (P == 0 || P > MAX_BAND_PERIOD) return false;
+    *m = BandMap();
+    m->P = (uint32_t)P; m->world = world;
+    int64_t cur[MAX_BAND_PERIOD] = {0};
+    for (uint32_t r = 0; r < MAX_BAND_PERIOD; r++) m->cnt[r] = 0;
+    for (uint32_t p = 0; p < m->P; p++) {
+        uint32_t pick = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            cur[r] += weights ? weights[r] : 1u;
+            if (cur[r] > cur[pick]) pick = r;
+        }
+        cur[pick] -= (int64_t)P;
+        m->owner[p] = (uint8_t)pick;
+        m->before[p] = m->cnt[pick]++;
+    }
+    return true;
+}
+inline bool band_map_equal(const BandMap& a, const BandMap& b) {
+    if (a.P != b.P || a.world != b.world) return false;
+    for (uint32_t p = 0; p < a.P; p++) if (a.owner[p] != b.owner[p]) return false;
+    return true;
+}
+// texels `rank` owns of a w x h image
+inline uint32_t owned_texels(const BandMap& m, uint32_t rank, uint32_t w, uint32_t h) {
+    uint32_t rows = 0;
+    for (uint32_t g = 0; g * 8 < h; g++)
+        if (m.rank_of(g) == rank) rows += (h - g * 8) < 8u ? (h - g * 8) : 8u;
+    return rows * w;
+}
+inline uint32_t max_owned_texels(const BandMap& m, uint32_t w, uint32_t h) {
+    uint32_t best = 0;
+    for (uint32_t r = 0; r < m.world; r++) { const uint32_t t = owned_texels(m, r, w, h); best = t > best ? t : best; }
+    return best;
+}
+
 }  // namespace psm
 
 struct psm_ctx {
@@ -120,7 +175,8 @@ struct psm_bvh {
 struct psm_rt {
     psm_ctx* ctx = nullptr;
     uint32_t w = 0, h = 0, dw = 0, dh = 0, y0 = 0, y1 = 0;
-    uint32_t tile_mode = 0, tile_rank = 0, tile_world = 1;  // 0: rows [y0,y1); 1: 8-row bands g % world == rank
+    uint32_t tile_mode = 0, tile_rank = 0, tile_world = 1;  // 0: rows [y0,y1); 1: the 8-row bands `bands` deals to tile_rank
+    psm::BandMap bands;           // mode 1: the dealing (psm_rt_set_tile_interleaved / _weighted)
     bool tile_root = true;        // this Pipeline samples the whole image: camera() also fills the texels it does not own
     uint32_t limit = 0;           // currentRayLimit
     int cur = 0;                  // current queue index
@@ -175,6 +231,23 @@ struct psm_rt {
     int samples_lock = 4;         // SAMPLES_LOCK, constants.glsl:35
 };
 
+// a communicator of tile-sharded frames (dist.hip); the two exchanges go through `tr` (psm_dist_transport)
+struct psm_dist {
+    psm_ctx* ctx = nullptr;
+    psm_dist_transport tr = {};
+    bool connected = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int rank = 0, world = 1;
+    int tile_rank = 0, tile_world = 1;  // the tile geometry gathers use: (rank, world) unless psm_dist_emulate_tile changed it
+    psm::BandMap bands;                 // the dealing of the bands (psm_dist_set_band_weights); default round-robin over tile_world
+    float* d_send = nullptr;   // per_floats
+    float* d_recv = nullptr;   // rank 0: world * per_floats
+    size_t per_floats = 0;
+    int32_t* d_i32 = nullptr;  // all-gather staging: send | recv
+    size_t i32_cap = 0;
+};
+
 namespace psm {
 
 // RAII-free helpers -----------------------------------------------------------------------------
@@ -206,15 +279,13 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
 int launch_rt_sample(psm_rt* r, psm_rt* src);
-int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b);
-int launch_rt_unpack_all(psm_rt* r, const float* d_all, uint32_t world, uint32_t skip, size_t stride_floats);
+// pack / unpack the dense tile of rows [a, b) (bands == NULL) or of rank a in the dealing `bands`
+int launch_rt_pack(psm_rt* r, hipStream_t stream, float* d_buf, int unpack, const BandMap* bands, uint32_t a, uint32_t b);
+int launch_rt_unpack_all(psm_rt* r, hipStream_t stream, const float* d_all, const BandMap& bands, uint32_t skip, size_t stride_floats);
+// dist.hip: pieces of the sharded batch that lanes.hip's pipelined scheduler shares
+int dist_reserve(psm_dist* d, uint32_t w, uint32_t h);
+int dist_gather_placeholder(psm_dist* d);
+bool dist_frame_gather(psm_dist* d, psm_rt* rt, psm_rt* fold_into, int& local);
 int launch_rt_gather_queue(psm_rt* r, float4* d_dense, uint32_t m);  // current queue in queue order: A | B | C, m rays each
 uint32_t tile_texel_count(const psm_rt* r);
-// texels rank `rank` of `world` owns when 8-row bands are dealt round-robin (rank 0 owns the most)
-inline uint32_t interleaved_texels(uint32_t rank, uint32_t world, uint32_t w, uint32_t h) {
-    uint32_t rows = 0;
-    for (uint32_t g = rank; g * 8 < h; g += world) rows += (h - g * 8) < 8u ? (h - g * 8) : 8u;
-    return rows * w;
-}
-
 }  // namespace psm

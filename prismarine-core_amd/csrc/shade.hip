@@ -47,16 +47,18 @@ struct Mat16 {
     float m[16];
 };
 
-// tile = the texels a context owns. mode 0: rows [a, b) in bands of 8 from a; mode 1: global 8-row bands
-// g with g % b == a. local_row = index of the row among the owned rows.
+// tile = the texels a context owns. mode 0: rows [a, b) in bands of 8 from a; mode 1: the global 8-row bands the
+// dealing `map` gives to rank a (BandMap, psm_internal.h). local_row = index of the row among the owned rows.
 struct Tile {
     uint32_t mode, a, b, h;
+    BandMap map;
+    uint8_t pos[MAX_BAND_PERIOD];  // mode 1: the positions of the period that rank a owns, ascending
 };
 struct TileRow {
     bool owned;
     uint32_t by, bh, local_base;  // band start row, band height, owned rows before the band
 };
-PSM_HD TileRow tile_row(Tile t, uint32_t y) {
+PSM_HD TileRow tile_row(const Tile& t, uint32_t y) {
     TileRow r;
     if (t.mode == 0) {
         r.owned = y >= t.a && y < t.b;
@@ -66,18 +68,19 @@ PSM_HD TileRow tile_row(Tile t, uint32_t y) {
         r.local_base = band * 8;
     } else {
         uint32_t g = y >> 3;
-        r.owned = (g % t.b) == t.a;
+        r.owned = t.map.rank_of(g) == t.a;
         r.by = g * 8;
         r.bh = (t.h - r.by) < 8u ? (t.h - r.by) : 8u;
-        r.local_base = (g / t.b) * 8;
+        r.local_base = t.map.local_band(g) * 8;
     }
     return r;
 }
 
 // owned texel k (row-major over the owned rows) -> its row; the inverse of tile_row().local_base
-PSM_HD uint32_t tile_owned_row(Tile t, uint32_t local_row) {
+PSM_HD uint32_t tile_owned_row(const Tile& t, uint32_t local_row) {
     if (t.mode == 0) return t.a + local_row;
-    return ((local_row >> 3) * t.b + t.a) * 8 + (local_row & 7u);
+    const uint32_t lb = local_row >> 3, mine = t.map.cnt[t.a];
+    return ((lb / mine) * t.map.P + t.pos[lb % mine]) * 8 + (local_row & 7u);
 }
 
 // jittered sample position of a texel, camera.comp:27-35: a pure function of (texel, time)
@@ -780,53 +783,55 @@ __global__ __launch_bounds__(256) void rt_pack(float4* __restrict__ t_sum, float
     else buf[k] = t_sum[idx];
 }
 
-// the gathering rank's side of the tile gather in ONE launch: `all` holds the dense tiles of ranks 0..world-1 of an
-// interleaved sharding back to back (stride floats4 each, what ncclGather delivers); every texel that `skip` does not
+// the gathering rank's side of the tile gather in ONE launch: `all` holds the dense tiles of ranks 0..world-1 of the
+// dealing `map` back to back (stride floats4 each, what ncclGather delivers); every texel that `skip` does not
 // own takes its radiance from its owner's tile. (One rt_pack launch per peer walked the whole image seven times.)
 __global__ __launch_bounds__(256) void rt_unpack_all(float4* __restrict__ t_sum, const float4* __restrict__ all, uint32_t w,
-                                                     uint32_t h, uint32_t world, uint32_t skip, size_t stride) {
+                                                     uint32_t h, BandMap map, uint32_t skip, size_t stride) {
     uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= w * h) return;
     uint32_t x = idx % w, y = idx / w;
     uint32_t g = y >> 3;
-    uint32_t q = g % world;
+    uint32_t q = map.rank_of(g);
     if (q == skip) return;
-    size_t d = (size_t)((g / world) * 8 + (y - g * 8)) * w + x;   // tile_row(): owned rows before the band + row in the band
+    size_t d = (size_t)(map.local_band(g) * 8 + (y - g * 8)) * w + x;   // tile_row(): owned rows before the band + row in the band
     t_sum[idx] = all[(size_t)q * stride + d];
 }
 
 // ---- launch wrappers ------------------------------------------------------------------------------
-static Tile make_tile(const psm_rt* r) {
-    Tile t;
-    t.mode = r->tile_mode;
-    t.a = r->tile_mode ? r->tile_rank : r->y0;
-    t.b = r->tile_mode ? r->tile_world : r->y1;
-    t.h = r->h;
+static Tile tile_of(uint32_t mode, uint32_t a, uint32_t b, uint32_t h, const BandMap* map) {
+    Tile t = {};
+    t.mode = mode; t.a = a; t.b = b; t.h = h;
+    if (mode && map) {
+        t.map = *map;
+        uint32_t n = 0;
+        for (uint32_t p = 0; p < map->P; p++) if (map->owner[p] == a) t.pos[n++] = (uint8_t)p;
+    }
     return t;
+}
+static Tile make_tile(const psm_rt* r) {
+    return r->tile_mode ? tile_of(1u, r->tile_rank, r->tile_world, r->h, &r->bands) : tile_of(0u, r->y0, r->y1, r->h, nullptr);
 }
 
 uint32_t tile_texel_count(const psm_rt* r) {
     if (r->tile_mode == 0) return (r->y1 - r->y0) * r->w;
-    uint32_t rows = 0;
-    for (uint32_t g = r->tile_rank; g * 8 < r->h; g += r->tile_world) rows += (r->h - g * 8) < 8u ? (r->h - g * 8) : 8u;
-    return rows * r->w;
+    return owned_texels(r->bands, r->tile_rank, r->w, r->h);
 }
 
-int launch_rt_pack(psm_rt* r, float* d_buf, int unpack, uint32_t mode, uint32_t a, uint32_t b) {
+int launch_rt_pack(psm_rt* r, hipStream_t stream, float* d_buf, int unpack, const BandMap* bands, uint32_t a, uint32_t b) {
     psm_ctx* c = r->ctx;
-    Tile t;
-    t.mode = mode; t.a = a; t.b = b; t.h = r->h;
-    uint32_t n = (mode ? interleaved_texels(a, b, r->w, r->h) : (b - a) * r->w);  // texels of the tile
+    Tile t = tile_of(bands ? 1u : 0u, a, b, r->h, bands);
+    uint32_t n = bands ? owned_texels(*bands, a, r->w, r->h) : (b - a) * r->w;  // texels of the tile
     if (n == 0) return PSM_OK;
-    rt_pack<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (float4*)d_buf, r->w, n, t, unpack);
+    rt_pack<<<(n + 255) / 256, 256, 0, stream>>>(r->t_sum, (float4*)d_buf, r->w, n, t, unpack);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }
 
-int launch_rt_unpack_all(psm_rt* r, const float* d_all, uint32_t world, uint32_t skip, size_t stride_floats) {
+int launch_rt_unpack_all(psm_rt* r, hipStream_t stream, const float* d_all, const BandMap& bands, uint32_t skip, size_t stride_floats) {
     psm_ctx* c = r->ctx;
     uint32_t n = r->w * r->h;
-    rt_unpack_all<<<(n + 255) / 256, 256, 0, c->stream>>>(r->t_sum, (const float4*)d_all, r->w, r->h, world, skip, stride_floats / 4);
+    rt_unpack_all<<<(n + 255) / 256, 256, 0, stream>>>(r->t_sum, (const float4*)d_all, r->w, r->h, bands, skip, stride_floats / 4);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }

@@ -26,26 +26,51 @@ class NativeUnavailable(RuntimeError):
 
 
 class NativeDist:
-    """The C ABI's own communicator (psm_dist_*, RCCL directly from libpsm_hip.so): the path's one data-path
-    collective per frame (gather of the tiles' per-texel radiance to rank 0) and the small all-gather of
-    (round, count) pairs, with no torch tensor in between. `bcast_id(bytes or None) -> bytes` hands rank 0's
-    ncclUniqueId to the other ranks over whatever side channel the launcher has (here: torch.distributed)."""
+    """The C ABI's own communicator (psm_dist_*): the path's one data-path collective per frame (gather of the tiles'
+    per-texel radiance to rank 0) and the small all-gather of (round, count) pairs, with no torch tensor in between.
+    Two steps, as the C ABI has them: the constructor creates this rank's LOCAL resources (psm_dist_prepare: cannot
+    block on a peer); connect_rccl / connect_hoststaged install the transport (collective).
 
-    def __init__(self, ctx, rank, world, bcast_id):
+    connect_rccl(bcast_id): RCCL directly from libpsm_hip.so; `bcast_id(bytes or None) -> bytes` hands rank 0's
+    ncclUniqueId to the other ranks over whatever side channel the launcher has (bench.py: torch.distributed).
+    connect_hoststaged(name, slot_bytes): the library's host-staged transport for processes that SHARE one GPU
+    (tests; psm_dist_connect_hoststaged)."""
+
+    def __init__(self, ctx, rank, world, bcast_id=None):
         import ctypes as C
         from . import lib
         self._C, self._lib, self.ctx, self.rank, self.world = C, lib(), ctx, rank, world
-        self._h = None
+        self._h = C.c_void_p()
+        ctx.check(self._lib.psm_dist_prepare(ctx._h, C.c_int(rank), C.c_int(world), C.byref(self._h)), "psm_dist_prepare")
+        if bcast_id is not None:
+            self.connect_rccl(bcast_id)
+
+    def connect_rccl(self, bcast_id):
+        C = self._C
         ident = (C.c_uint8 * 128)()
-        rc = self._lib.psm_dist_unique_id(ident) if rank == 0 else 0
+        rc = self._lib.psm_dist_unique_id(ident) if self.rank == 0 else 0
         # the id always travels (byte 128 = rank 0's return code), so a failure on rank 0 is every rank's failure
         # instead of a hang in the side channel
-        raw = bcast_id(bytes(ident) + bytes([1 if rc else 0]) if rank == 0 else None)
+        raw = bcast_id(bytes(ident) + bytes([1 if rc else 0]) if self.rank == 0 else None)
         if raw[128]:
             raise NativeUnavailable("psm_dist_unique_id failed on rank 0 (rc %d)" % rc)
         ident = (C.c_uint8 * 128).from_buffer_copy(raw[:128])
-        self._h = C.c_void_p()
-        ctx.check(self._lib.psm_dist_init(ctx._h, C.c_int(rank), C.c_int(world), ident, C.byref(self._h)), "psm_dist_init")
+        self.ctx.check(self._lib.psm_dist_connect(self._h, ident), "psm_dist_connect")
+
+    def connect_hoststaged(self, shm_name, slot_bytes, timeout_ms=60000):
+        C = self._C
+        self.ctx.check(self._lib.psm_dist_connect_hoststaged(self._h, shm_name.encode(), C.c_size_t(slot_bytes), C.c_uint32(timeout_ms)),
+                       "psm_dist_connect_hoststaged")
+
+    @property
+    def transport(self):
+        self._lib.psm_dist_transport_name.restype = self._C.c_char_p
+        v = self._lib.psm_dist_transport_name(self._h)
+        return v.decode() if v else None
+
+    def agree(self, local_rc=0):
+        """psm_dist_agree: 0 when every rank passed 0, this rank's code when it failed, PSM_ERR_PEER when only others did."""
+        return self._lib.psm_dist_agree(self._h, self._C.c_int(local_rc))
 
     def gather_tiles(self, rays):
         """ONE collective: rays' owned texels -> rank 0's image (stream-ordered against rays' context, no host sync)."""
@@ -61,6 +86,11 @@ class NativeDist:
 
     def barrier(self):
         self.ctx.check(self._lib.psm_dist_barrier(self._h), "psm_dist_barrier")
+
+    def set_band_weights(self, weights):
+        """the dealing of the bands the gathers use (psm_dist_set_band_weights); None = round-robin"""
+        wv = None if weights is None else (self._C.c_uint32 * len(weights))(*[int(v) for v in weights])
+        self.ctx.check(self._lib.psm_dist_set_band_weights(self._h, wv), "psm_dist_set_band_weights")
 
     def emulate_tile(self, tile_rank, tile_world):
         """one-GPU rehearsal of a worker's per-frame cost (psm_dist_emulate_tile)"""
@@ -117,19 +147,33 @@ class Comm:
             if self.world > 1:
                 self.dist.broadcast(t, src=0)
             return bytes(t.cpu().numpy().tobytes())
+        # step 1, local: stream + events of the communicator. A rank that fails here says so BEFORE anybody enters the
+        # collective ncclCommInitRank (where the others would wait for it for ever)
         err = None
         try:
-            self.native = NativeDist(ctx, self.rank, self.world, bcast)
-        except NativeUnavailable:
-            raise                      # rank 0's failure, already known to every rank
+            self.native = NativeDist(ctx, self.rank, self.world)
+        except Exception as e:
+            err = e
+        if self.min_int(0 if err is not None else 1) == 0:
+            self._drop_native()
+            raise NativeUnavailable("psm_dist_prepare failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
+        # step 2, collective: rank 0's id travels, every rank joins the RCCL communicator
+        try:
+            self.native.connect_rccl(bcast)
+        except NativeUnavailable:      # rank 0's failure, already known to every rank
+            self._drop_native()
+            raise
         except Exception as e:         # this rank's communicator failed: tell the others
             err = e
         if self.min_int(0 if err is not None else 1) == 0:
-            if self.native is not None:
-                self.native.close()
-                self.native = None
-            raise NativeUnavailable("psm_dist_init failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
+            self._drop_native()
+            raise NativeUnavailable("psm_dist_connect failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
         return self.native
+
+    def _drop_native(self):
+        if getattr(self, "native", None) is not None:
+            self.native.close()
+            self.native = None
 
     def min_int(self, v):
         if not self.active or self.world <= 1:
@@ -186,10 +230,52 @@ class Comm:
             self.dist.destroy_process_group()
 
 
+def band_pattern(world, weights=None):
+    """Owner of each position of one period of the band dealing (BandMap, csrc/psm_internal.h): global 8-row band g
+    belongs to rank pattern[g % len(pattern)]. A smooth weighted round-robin: every step each rank's credit grows by its
+    weight, the largest credit (lowest rank on ties) takes the band and pays the period. Weights all 1: 0, 1, .. world-1."""
+    wts = [1] * world if weights is None else [int(v) for v in weights]
+    assert len(wts) == world and 1 <= sum(wts) <= 64 and world <= 64
+    period, cur, out = sum(wts), [0] * world, []
+    for _ in range(period):
+        pick = 0
+        for r in range(world):
+            cur[r] += wts[r]
+            if cur[r] > cur[pick]:
+                pick = r
+        cur[pick] -= period
+        out.append(pick)
+    return out
+
+
+def owned_texels(rank, world, width, height, weights=None):
+    """Texels owned by `rank` when the 8-row bands are dealt by band_pattern (psm_rt_set_tile_interleaved / _weighted)."""
+    pat = band_pattern(world, weights)
+    rows = sum(min(8, height - 8 * g) for g in range((height + 7) // 8) if pat[g % len(pat)] == rank)
+    return rows * width
+
+
+def largest_tile_texels(world, width, height, weights=None):
+    return max(owned_texels(r, world, width, height, weights) for r in range(world))
+
+
 def interleaved_texels(rank, world, width, height):
     """Texels owned by `rank` when 8-row bands are dealt round-robin (psm_rt_set_tile_interleaved)."""
-    rows = sum(min(8, height - 8 * g) for g in range(rank, (height + 7) // 8, world))
-    return rows * width
+    return owned_texels(rank, world, width, height)
+
+
+def default_band_weights(world):
+    """The dealing bench.py uses on `world` GPUs: periods of 23 bands of which the gathering rank takes floor(23 / world)
+    and the workers one more -- shares of 0.087 / 0.130 at 8 GPUs, 0.217 / 0.261 at 4, 0.478 / 0.522 at 2: what equalises
+    the ranks' finishing times when rank 0's unpack + rest-of-image camera + whole-image sample cost 0.10 ms per 1080p
+    frame against 2.36 ms of tracing per full image. None (round-robin) where that does not fit."""
+    if world < 2 or world > 11:
+        return None
+    low = 23 // world
+    rest = 23 - low
+    if rest % (world - 1):
+        return None
+    return [low] + [rest // (world - 1)] * (world - 1)
 
 
 def run_rounds(comm, rays, intersector, materials, depth=16, on_round=None):

@@ -302,3 +302,60 @@ def test_native_decide_equals_python_protocol():
         force = (C.c_uint32 * lanes)()
         assert L.psm_dist_decide(C.c_uint32(world), C.c_uint32(lanes), arr, C.c_uint32(depth), over, force) == 0
         assert [(bool(over[s]), int(force[s])) for s in range(lanes)] == [(bool(o), int(f)) for o, f in want]
+
+
+def test_native_decide_turns_a_poisoned_round_into_every_ranks_error():
+    """A rank that failed locally keeps the collective sequence and reports rounds = -1 (psm_dist_render_frames /
+    _batch); psm_dist_decide then returns PSM_ERR_PEER -- from the same exchange on every rank, since all ranks see the
+    same gathered values -- whatever the other entries say, and leaves its outputs alone."""
+    import ctypes as C
+    psm = importlib.import_module("prismarine-core_amd")
+    L = psm.lib()
+    PSM_ERR_PEER = -6
+    rng = np.random.RandomState(11)
+    for _ in range(200):
+        world, lanes, depth = int(rng.randint(1, 9)), int(rng.randint(1, 7)), 16
+        flat = [int(v) for v in rng.randint(0, 5, world * 2 * lanes)]
+        arr = (C.c_int32 * len(flat))(*flat)
+        over = (C.c_int32 * lanes)(*([7] * lanes))
+        force = (C.c_uint32 * lanes)(*([9] * lanes))
+        assert L.psm_dist_decide(C.c_uint32(world), C.c_uint32(lanes), arr, C.c_uint32(depth), over, force) == 0
+        bad_rank, bad_lane = int(rng.randint(0, world)), int(rng.randint(0, lanes))
+        flat[(bad_rank * 2 + 0) * lanes + bad_lane] = -1
+        arr = (C.c_int32 * len(flat))(*flat)
+        over = (C.c_int32 * lanes)(*([7] * lanes))
+        force = (C.c_uint32 * lanes)(*([9] * lanes))
+        assert L.psm_dist_decide(C.c_uint32(world), C.c_uint32(lanes), arr, C.c_uint32(depth), over, force) == PSM_ERR_PEER
+        assert list(over) == [7] * lanes and list(force) == [9] * lanes
+        # a negative COUNT is not a poison value (counts are never negative; only the rounds row is looked at)
+    assert psm.lib().psm_dist_decide(C.c_uint32(1), C.c_uint32(1), (C.c_int32 * 2)(0, 5), C.c_uint32(4), (C.c_int32 * 1)(), (C.c_uint32 * 1)()) == 0
+
+
+def test_band_dealing_is_the_same_function_everywhere(oracle):
+    """The dealing of the 8-row bands (which rank owns band g) in its three statements: dist.band_pattern (Python host),
+    psmo_band_pattern (oracle) and BandMap (csrc/psm_internal.h -- compared on the GPU through the tile cameras,
+    test_interleaved_tiles_camera_and_gather). Round-robin for equal weights; every rank's share of a period equals its
+    weight; a rank's bands are spread evenly (no two gaps of a rank differ by more than the number of ranks)."""
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    rng = np.random.RandomState(5)
+    for world in range(1, 9):
+        assert pdist.band_pattern(world) == list(range(world)) == oracle.band_pattern(world)
+    for _ in range(300):
+        world = int(rng.randint(1, 9))
+        wts = [int(v) for v in rng.randint(0, 8, world)]
+        if sum(wts) == 0 or sum(wts) > 64:
+            continue
+        pat = pdist.band_pattern(world, wts)
+        assert pat == oracle.band_pattern(world, wts)
+        assert [pat.count(r) for r in range(world)] == wts
+    for world in (2, 4, 8):
+        wts = pdist.default_band_weights(world)
+        pat = pdist.band_pattern(world, wts)
+        assert len(pat) == 23 and wts[0] < wts[1]
+        for r in range(world):
+            pos = [p for p in range(2 * len(pat)) if (pat * 2)[p] == r]
+            gaps = [b - a for a, b in zip(pos, pos[1:])]
+            assert max(gaps) - min(gaps) <= world, (world, r, gaps)
+        total = 1920 * 1080
+        shares = [pdist.owned_texels(r, world, 1920, 1080, wts) / total for r in range(world)]
+        assert abs(sum(shares) - 1.0) < 1e-12 and shares[0] < min(shares[1:])

@@ -665,9 +665,11 @@ def test_tile_sharding_equals_full_frame(psm, ctx, scenes):
     th.close()
 
 
-def test_interleaved_tiles_camera_and_gather(psm, ctx, oracle, scenes):
-    """8-row bands dealt round-robin over 3 ranks: camera queue equals the oracle's, and packing each tile's
-    texel sums into a dense buffer + unpacking on the gathering pipeline reproduces the unsharded frame."""
+@pytest.mark.parametrize("weights", [None, [1, 2, 2], [3, 1, 0]], ids=["round-robin", "1-2-2", "3-1-0"])
+def test_interleaved_tiles_camera_and_gather(psm, ctx, oracle, scenes, weights):
+    """8-row bands dealt over 3 ranks (round-robin; weighted 1:2:2 -- the gathering rank gets fewer; 3:1:0 -- a rank
+    without any band): camera queue equals the oracle's, and packing each tile's texel sums into a dense buffer +
+    unpacking on the gathering pipeline reproduces the unsharded frame."""
     scene = scenes.cornell(open_top=True)
     w, h, world = 72, 52, 3  # 6.5 bands: a partial last band
     th, rt0, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
@@ -697,18 +699,19 @@ def test_interleaved_tiles_camera_and_gather(psm, ctx, oracle, scenes):
     for r in range(world):
         rt = psm.Pipeline(ctx, seed=5)
         rt.resizeBuffers(w, h); rt.resize(w, h)
-        rt.setTileInterleaved(r, world)
-        assert rt.tile_texels() == pdist.interleaved_texels(r, world, w, h)
+        rt.setTileInterleaved(r, world, weights)
+        assert rt.tile_texels() == pdist.owned_texels(r, world, w, h, weights)
         rt.camera_matrices(cam[0], cam[1], time=None)
         pipes.append(rt)
     # camera parity per tile (same seed => same `time` as the oracle draws)
     t0, _ = oracle.rand_next(5)
     for r, rt in enumerate(pipes):
-        orays, *_ = oracle.camera_interleaved(cfg, cam[0], cam[1], t0, r, world)
+        orays, *_ = oracle.camera_interleaved(cfg, cam[0], cam[1], t0, r, world, weights)
         _rays_equal(rt.download_rays(), orays)
+    assert sum(rt.tile_texels() for rt in pipes) == w * h
     lockstep(pipes)
     # gather: tiles 1,2 are packed and unpacked into pipeline 0 (the "root")
-    per = pdist.interleaved_texels(0, world, w, h) * 16
+    per = pdist.largest_tile_texels(world, w, h, weights) * 16
     hb = ctx.buf_alloc(per)
     ptr, _ = ctx.buf_ptr(hb)
     for r in range(1, world):
