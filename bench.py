@@ -17,9 +17,13 @@ per-texel radiance of each tile is gathered to rank 0 (RCCL over xGMI) which run
 Total work is fixed by the config, so scaling is "strong".
 
 Rank 0 prints ONE JSON line.  `value` = rays traced by all ranks / wall time of the K timed frames
-(inputs resident in HBM).  `roofline` prices the traversal kernel: algorithmic bytes
-(R*44 + V*64 + T*36) over its HIP-event time; `cpu_baseline` times the CPU oracle's
-traversal (oracle/, scalar C + OpenMP) on a bounded sample of the same rays.
+(inputs resident in HBM).  `roofline` prices the traversal kernel THE TIMED REGION LAUNCHES (with frames in
+flight: the hand-over kernel rt_traverse<false,false,true>): HIP events around every traversal launch on every
+lane's stream in a repeat of the timed call, algorithmic bytes (R*44 + V*64 + T*36, from per-round
+counters) over that time, and first the physical figures of the committed PMC passes (profiles/traffic_r03.json:
+HBM-side traffic, VALU issue and lane utilisation); the single-launch kernel of a frame running alone is priced
+beside it.  `cpu_baseline` times the CPU oracle's traversal (oracle/, scalar C + OpenMP, every hardware thread)
+on a bounded sample of the same rays.
 """
 import argparse
 import importlib
@@ -49,8 +53,13 @@ def parse():
     ap.add_argument("--depth", type=int, default=16)  # Application.hpp:237
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-build-graph", action="store_true", help="rebuild with plain launches instead of the captured hipGraph (A/B)")
-    ap.add_argument("--cpu-sample-rays", type=int, default=3_000_000)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-sample-rays", type=int, default=7_000_000, help="cap of the CPU baseline's sample (C3: all 6.3 M rays of frame 0, ~25 CPU-seconds per run)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline; 0 (default) = every hardware thread of the box")
+    ap.add_argument("--band-weights", default="default",
+                    help="N > 1: bands per period for each rank, comma separated; 'default' = dist.default_band_weights (the gathering "
+                         "rank owns fewer bands: it also unpacks, fills and samples the whole image); 'none' = round-robin")
+    ap.add_argument("--no-obj-roundtrip", action="store_true",
+                    help="feed the generator's triangle arrays straight to loadTriangles instead of through scenes.write_obj / read_obj")
     ap.add_argument("--emulate-tile", default=None, help="R/W: render only the tile of rank R of W on one GPU, no communication (Amdahl study)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path even on 1 GPU (rehearsal)")
     ap.add_argument("--no-rebuild", action="store_true", help="study only, not the headline workload: build the BVH once")
@@ -119,22 +128,34 @@ class Renderer:
                     r.setTraversePhases([int(v) for v in args.trav_caps.split(",")])
                 r.setTraverseMode(args.traverse)
             self.batch.each(tune)
+        def weights_for(world):
+            if args.band_weights == "none" or world < 2:
+                return None
+            if args.band_weights == "default":
+                return self.pdist.default_band_weights(world)
+            v = [int(x) for x in args.band_weights.split(",")]
+            assert len(v) == world, "--band-weights needs one weight per rank"
+            return v
+        self.weights = None
         if dist.active and not (args.emulate_tile and dist.world == 1):
-            self.batch.each(lambda r: r.setTileInterleaved(dist.rank, dist.world))  # 8-row bands dealt round-robin
+            self.weights = weights_for(dist.world)
+            self.batch.each(lambda r: r.setTileInterleaved(dist.rank, dist.world, self.weights))  # 8-row bands dealt to the ranks
             dist.initial_total = w * h
         elif args.emulate_tile:
             r_, w_ = (int(v) for v in args.emulate_tile.split("/"))
-            self.batch.each(lambda r: r.setTileInterleaved(r_, w_))
+            self.weights = weights_for(w_)
+            self.batch.each(lambda r: r.setTileInterleaved(r_, w_, self.weights))
             dist.initial_total = self.rt.tile_texels()
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if use_native:
             self.native = dist.attach_native(self.ctx)  # collective: every rank creates its RCCL communicator here
             if args.emulate_tile and dist.world == 1:
                 self.native.emulate_tile(r_, w_)
+            self.native.set_band_weights(self.weights)
         if dist.active and self.native is None:
             torch = dist.torch
             gdev = torch.device("cuda", dist.device_index)
-            self.per = self.pdist.interleaved_texels(0, dist.world, w, h) * 4  # rank 0 owns the most bands
+            self.per = self.pdist.largest_tile_texels(dist.world, w, h, self.weights) * 4  # every rank sends the largest tile's size
             self.tile_dev = torch.zeros(self.per, dtype=torch.float32, device=gdev)
             self.lane_tiles = [self.tile_dev] + [torch.zeros(self.per, dtype=torch.float32, device=gdev) for _ in range(self.lanes - 1)]
             self.gather_done = [None] * self.lanes
@@ -214,9 +235,11 @@ class Renderer:
                     batch.fold_one(ln)
         return traced
 
-    def frame(self, record=None):
+    def frame(self, record=None, round_log=None):
         """GltfViewer::process(), Viewer.cpp:296-312 (display excluded): one frame on lane 0, with the rand()
-        stream the FrameBatch policy gives it (one draw of the accumulating stream seeds the frame's own)."""
+        stream the FrameBatch policy gives it (one draw of the accumulating stream seeds the frame's own).
+        round_log: a list that receives (rays, V, T) of every bounce round (counting pass: V and T per round are what
+        each traversal launch schedule is priced with)."""
         rt, th, ms, dist = self.rt, self.th, self.ms, self.dist
         if not hasattr(self, "_master_state"):
             self._master_state = 1000
@@ -226,8 +249,20 @@ class Renderer:
         th.markDirty()
         th.build()
         rt.camera_matrices(self.cam[0], self.cam[1])
-        on_round = (lambda local: record.append(rt.download_rays()) if local > 0 else None) if record is not None else None
-        self.pdist.run_rounds(dist, rt, th, ms, self.args.depth, on_round)
+        snaps = []
+
+        def on_round(local):
+            if record is not None and local > 0:
+                record.append(rt.download_rays())
+            if round_log is not None:
+                st_ = self.ctx.stats()
+                snaps.append((local, st_.node_visits, st_.tri_tests))
+        self.pdist.run_rounds(dist, rt, th, ms, self.args.depth, on_round if (record is not None or round_log is not None) else None)
+        if round_log is not None:
+            st_ = self.ctx.stats()
+            snaps.append((0, st_.node_visits, st_.tri_tests))
+            for a, b in zip(snaps, snaps[1:]):
+                round_log.append((a[0], b[1] - a[1], b[2] - a[2]))
         self._gather()
         if dist.rank == 0:
             rt.sample()
@@ -255,7 +290,8 @@ class Renderer:
 
 
 def cpu_baseline(scene, ray_sets, args):
-    """CPU oracle traversal (scalar C restatement, OpenMP) on a bounded sample of the GPU's ray set."""
+    """CPU oracle traversal (scalar C restatement, OpenMP over rays) on a bounded sample of the GPU's ray set, on every
+    hardware thread of the box; best of 3 after a warm-up."""
     from oracle import oracle as O
     O.build()
     rays = np.concatenate(ray_sets)
@@ -269,20 +305,49 @@ def cpu_baseline(scene, ray_sets, args):
     t0 = time.time()
     O.radix_sort(ob["keys_unsorted"], ob["idx"])
     sort_s = time.time() - t0
-    threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    hw = os.cpu_count() or 1                      # std::thread::hardware_concurrency() of the box
+    try:
+        usable = len(os.sched_getaffinity(0))     # what this process may run on (a container's CPU share)
+    except (AttributeError, OSError):
+        usable = hw
+    quota = None                                  # the container's CPU quota, which affinity does not show (cgroup v2 / v1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else int(t.split()[0]) / int(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            v = parse(open(path).read())
+            if v:
+                quota = max(1, int(np.ceil(v)))
+                break
+        except (OSError, ValueError, IndexError):
+            pass
     origins = np.ascontiguousarray(rays["origin"])
     directs = np.ascontiguousarray(rays["direct"])
-    O.traverse(ob["nodes"], scene["tris"], ob["M"], origins[:20000], directs[:20000], threads, want_hits=False)  # warm-up
+    # every hardware thread the process may use -- unless fewer are faster: a container with a CPU share smaller than the
+    # box (gpurun: 16 of 256) runs 256 threads slower than 16. Calibrated on a slice of the sample, halving from the top.
+    cal = slice(0, min(rays.shape[0], 300_000))
+    O.traverse(ob["nodes"], scene["tris"], ob["M"], origins[cal], directs[cal], min(usable, 16), want_hits=False)  # warm-up
+    tried = {}
+    cands = [args.cpu_threads] if args.cpu_threads > 0 else sorted({usable, quota or usable} | {max(1, usable >> k) for k in range(1, 6)}, reverse=True)
+    for tcount in cands:
+        t0 = time.time()
+        O.traverse(ob["nodes"], scene["tris"], ob["M"], origins[cal], directs[cal], tcount, want_hits=False)
+        tried[tcount] = (cal.stop - cal.start) / (time.time() - t0) / 1e6
+    threads = max(tried, key=tried.get)
     best = None
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.time()
         O.traverse(ob["nodes"], scene["tris"], ob["M"], origins, directs, threads, want_hits=False)
         dt = time.time() - t0
         best = dt if best is None else min(best, dt)
     return {"value": rays.shape[0] / best / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "hardware_concurrency": hw, "usable_threads": usable, "cpu_quota": quota, "threads_tried_mrays_s": {str(k): v for k, v in sorted(tried.items())},
             "build_ms": build_s * 1e3, "sort_mkeys_s": ob["count"] / sort_s / 1e6, "build_sort_cores": 1,
-            "sample": "%d of the %d rays of frame 0 (all bounce rounds, every %d-th ray), oracle psmo_traverse_batch, "
-                      "best of 2; oracle BVH build %.2f s on 1 core" % (rays.shape[0], n, max(1, n // max(rays.shape[0], 1)), build_s)}
+            "sample": "%d of the %d rays of frame 0 (all bounce rounds, every %d-th ray), oracle psmo_traverse_batch on %d threads "
+                      "(box: hardware_concurrency %d, affinity %d, CPU quota of this container %s; thread count = the fastest of %s on a "
+                      "%d-ray slice: a CPU share smaller than the box runs all hardware threads slower than fewer), best of 3 after a "
+                      "warm-up; oracle BVH build %.2f s on 1 core" % (
+                          rays.shape[0], n, max(1, n // max(rays.shape[0], 1)), threads, hw, usable, quota,
+                          ", ".join("%d: %.1f Mrays/s" % (k, v) for k, v in sorted(tried.items())), cal.stop - cal.start, build_s)}
 
 
 L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md: L2 aggregate, streaming
@@ -291,79 +356,86 @@ VALU_QUAD_CYCLES = 4.0       # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MI
 SIMDS = 1024
 
 
-def pmc_entry(scene, width, height, kernel, which=None):
+def pmc_entry(scene, width, height, kernel):
     """Per-launch PMC figures of `kernel` for this workload from the committed rocprofv3 passes (profiles/collect.sh ->
     profiles/make_traffic.py): bench.py cannot run the profiler on itself."""
-    for name in ("traffic_r02.json",):
+    for name in ("traffic_r03.json",):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
         for e in d.get("entries", []):
-            if ((e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel)
-                    and e.get("pass") == which):
+            if (e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel):
                 return e, "profiles/" + name
     return None, None
 
 
-def roofline(st, Rr, V, T, copy_gbs, scene, width, height, lanes_mode):
-    """What bounds the dominant kernel (traversal). `achieved` / `frac` keep SURVEY 8(d)'s algorithmic figure
-    (R*44 + V*64 + T*36 over the launch time) against the HBM peak; `bound` is decided by the counters: when the
-    HBM-side traffic of a launch is a small part of that figure the data is cache-resident and the kernel is priced
-    by VALU issue and by its own records (V*32 + T*48 + R*44) against the cache ceilings instead."""
-    launches = max(st.traverse_launches, 1)
-    avg_ms = st.traverse_ms / launches
-    sec = avg_ms * 1e-3
-    alg = (Rr * 44 + V * 64 + T * 36) / launches
-    own = (Rr * 44 + V * 32 + T * 48) / launches
-    achieved = alg / sec / 1e9 if sec > 0 else 0.0
-    kernel = "rt_traverse<false, false, false>"
+def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, height, how):
+    """One traversal kernel priced over `launches` launches that took `total_ms` (HIP events on the launching streams) and
+    traced R rays with V node visits and T triangle tests in `rounds` intersections."""
+    launches = max(int(launches), 1)
+    sec = total_ms * 1e-3
+    alg = R * 44 + V * 64 + T * 36           # SURVEY 8(d)
+    own = R * 44 + V * 32 + T * 48           # what the kernel's own records amount to (DESIGN.md 3)
+    out = {"kernel": kernel, "launches": launches, "rounds": int(rounds), "launches_per_round": launches / max(rounds, 1),
+           "avg_launch_ms": total_ms / launches, "ms_per_step": total_ms / steps, "measured": how,
+           "achieved": alg / sec / 1e9 if sec > 0 else 0.0, "algorithmic_bytes_per_launch": alg / launches,
+           "own_record_bytes_per_launch": own / launches, "own_record_gbs": own / sec / 1e9 if sec > 0 else 0.0,
+           "node_visits_per_s": V / sec if sec > 0 else None, "R": int(R), "V": int(V), "T": int(T)}
     e, src = pmc_entry(scene, width, height, kernel)
-    out = {"bound": "unknown: no committed PMC pass for this workload", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "launches": int(st.traverse_launches),
-           "avg_launch_ms": avg_ms,
-           "measured": ("kernel pass: the timed region's frames one after another on one stream, HIP events per launch: the "
-                        "single-launch traversal kernel running alone. The timed region itself keeps several frames in "
-                        "flight, whose intersections run the same per-ray loop as the ballot-triggered hand-over schedule "
-                        "(rt_traverse<false,false,true>, <= 3 launches per round, overlapping other frames' kernels), which "
-                        "has no per-launch time of its own to price") if lanes_mode
-                       else "timed region, HIP events per launch",
-           "algorithmic_bytes_per_launch": alg, "own_record_bytes_per_launch": own,
-           "own_record_gbs": own / sec / 1e9 if sec > 0 else 0.0,
-           "own_record_frac_of_l2_peak": own / sec / 1e9 / L2_PEAK_GBS if sec > 0 else None,
-           "own_record_frac_of_infinity_cache_gather": own / sec / 1e9 / MALL_GATHER_GBS if sec > 0 else None,
-           "node_visits_per_s": V / (st.traverse_ms * 1e-3) if st.traverse_ms > 0 else None,
-           "measured_copy_gbs": copy_gbs, "R": int(Rr), "V": int(V), "T": int(T), "rank": 0}
-    if out["frac"] > 1.0:
-        out["frac_note"] = ("above 1: SURVEY 8(d)'s algorithmic figure prices a node visit at 64 B where the kernel fetches one 32-B "
-                            "record, most of them from L2 / Infinity Cache -- it is not an HBM utilisation (that is hbm_frac); "
-                            "own_record_* is what the kernel moves")
-    if e is None:
-        return out
-    traffic = e.get("traffic_bytes_per_launch")
-    out["traffic"] = traffic
-    out["traffic_source"] = src + ": " + e.get("source", "")
-    out["traffic_fetch_raw"] = e.get("fetch_bytes_per_launch_raw")
-    hbm_frac = traffic / sec / 1e9 / HBM_PEAK_GBS if (traffic and sec > 0) else None
-    out["hbm_frac"] = hbm_frac                                    # HBM-side bytes of the counters over the launch time
-    out["hbm_frac_of_measured_copy"] = (traffic / sec / 1e9 / copy_gbs) if (traffic and sec > 0 and copy_gbs > 0) else None
-    out["traffic_over_own_record_bytes"] = traffic / own if (traffic and own) else None
-    if e.get("l2_hit") is not None:
-        out["l2_hit"] = e["l2_hit"]
-    sq = e.get("sq_per_launch") or {}
-    if sq.get("SQ_ACTIVE_INST_VALU") and e.get("kernel_trace_avg_us"):
-        # share of the launch during which a SIMD's VALU is executing an instruction (profiled launch, 2.4 GHz nominal)
-        out["valu_issue_utilisation"] = sq["SQ_ACTIVE_INST_VALU"] * VALU_QUAD_CYCLES / SIMDS / (e["kernel_trace_avg_us"] * 1e-6 * 2.4e9)
-        out["valu_lane_utilisation"] = e.get("valu_lane_utilisation")
-        out["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU")
-    t, _ = pmc_entry(scene, width, height, "rt_traverse<false, false, true>", "as timed (frames in flight)")
-    if t is not None and lanes_mode:
-        # the hand-over kernels the timed region runs: lane utilisation over all their launches (SQ pass of the bench as timed)
-        out["timed_schedule_valu_lane_utilisation"] = t.get("valu_lane_utilisation")
-    if hbm_frac is not None and traffic >= 0.5 * own:
-        out["bound"] = "hbm" if hbm_frac >= 0.4 else "hbm latency (HBM-resident records, divergent 32-byte gathers)"
+    if e is not None and sec > 0:
+        traffic = e.get("traffic_bytes_per_launch")
+        out["traffic"] = traffic
+        out["traffic_source"] = src + ": " + e.get("source", "")
+        out["traffic_fetch_raw"] = e.get("fetch_bytes_per_launch_raw")
+        if traffic:
+            # the counters' launches and this run's launches are the same kernel on the same workload (same launches per
+            # frame): per-launch traffic over per-launch time is the HBM-side rate of ONE launch while it runs
+            out["hbm_gbs_of_one_launch"] = traffic * launches / sec / 1e9
+            out["hbm_frac"] = out["hbm_gbs_of_one_launch"] / HBM_PEAK_GBS   # replaced below where launches overlap
+            out["traffic_over_own_record_bytes"] = traffic * launches / own if own else None
+        if e.get("l2_hit") is not None:
+            out["l2_hit"] = e["l2_hit"]
+        sq = e.get("sq_per_launch") or {}
+        if sq.get("SQ_ACTIVE_INST_VALU") and e.get("alone_avg_us"):
+            # share of the launch (running alone, as the profiler serialises it) during which a SIMD's VALU executes
+            out["valu_issue_utilisation"] = sq["SQ_ACTIVE_INST_VALU"] * VALU_QUAD_CYCLES / SIMDS / (e["alone_avg_us"] * 1e-6 * 2.4e9)
+            out["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU")
+        if e.get("valu_lane_utilisation") is not None:
+            out["valu_lane_utilisation"] = e["valu_lane_utilisation"]
+    return out
+
+
+def roofline(timed, whole, bytes_per_step, ms_per_step, copy_gbs):
+    """What bounds the dominant kernel of the TIMED region: `timed` = price() of the traversal kernel the timed schedule
+    launches (HIP events on every lane's stream while the frames are in flight), `whole` = the single-launch kernel of a
+    frame running alone, for comparison. The counters' figures lead; `achieved` / `frac` keep SURVEY 8(d)'s algorithmic
+    bytes over the launch time for continuity -- that figure prices a node visit at 64 B where the kernel fetches one 32-B
+    record, most of them from cache, so it is NOT an HBM utilisation (hbm_frac is)."""
+    t = timed
+    traffic, own = t.get("traffic"), t["own_record_bytes_per_launch"]
+    if t.get("hbm_frac") is not None and traffic >= 0.5 * own:
+        bound = "hbm" if t["hbm_frac"] >= 0.4 else "hbm latency (HBM-resident records, divergent 32-byte gathers)"
+    elif t.get("hbm_frac") is not None:
+        bound = "cache/VALU: records served by L2 + Infinity Cache, VALU issue under divergence"
     else:
-        out["bound"] = "cache/VALU: records served by L2 + Infinity Cache, VALU issue under divergence"
+        bound = "unknown: no committed PMC pass for this kernel and workload"
+    out = {"bound": bound, "hbm_frac": t.get("hbm_frac"), "valu_issue_utilisation": t.get("valu_issue_utilisation"),
+           "timed_schedule_valu_lane_utilisation": t.get("valu_lane_utilisation"),
+           "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t["achieved"] / HBM_PEAK_GBS,
+           "traffic": traffic}
+    step_gbs = bytes_per_step / (ms_per_step * 1e-3) / 1e9
+    if step_gbs > HBM_PEAK_GBS or out["frac"] > 1.0:
+        out["frac_note"] = ("SURVEY 8(d)'s algorithmic bytes per step over ms_per_step = %.0f GB/s, above the %.0f GB/s peak: the figure "
+                            "prices a node visit at 64 B where the kernel fetches one 32-B record, most of them from L2 / Infinity "
+                            "Cache. `frac` is kept for continuity and is not an HBM utilisation; hbm_frac (PMC counters) is" % (
+                                step_gbs, HBM_PEAK_GBS))
+    out.update({k: v for k, v in t.items() if k not in out})
+    out["own_record_frac_of_l2_peak"] = t["own_record_gbs"] / L2_PEAK_GBS
+    out["own_record_frac_of_infinity_cache_gather"] = t["own_record_gbs"] / MALL_GATHER_GBS
+    out["measured_copy_gbs"] = copy_gbs
+    out["rank"] = 0
+    out["single_launch_kernel_alone"] = whole
     return out
 
 
@@ -425,18 +497,39 @@ def main():
     dist = pdist.Comm(world, force=args.force_dist)
     scenes = importlib.import_module("prismarine-core_amd.scenes")
     scene = {"sponza_like": scenes.sponza_like, "cornell": scenes.cornell, "stress": scenes.stress}[args.scene]()
+    obj_note = "generator arrays fed to loadTriangles directly"
+    if not args.no_obj_roundtrip and args.scene != "stress":
+        # north_star: synthetic OBJ scenes. The generator's scene goes through the OBJ writer and reader once (outside every
+        # timed region): what is rendered is what the OBJ file holds (v / vn / f with %.9g floats: the arrays round-trip exactly)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, args.scene + ".obj")
+            scenes.write_obj(path, scene)
+            back = scenes.read_obj(path)
+            obj_bytes = os.path.getsize(path)
+        assert back["tris"].shape == scene["tris"].shape and np.array_equal(back["tris"], scene["tris"]), "OBJ round trip changed the triangles"
+        assert np.array_equal(back["mats"], scene["mats"]), "OBJ round trip changed the material ids"
+        assert len(back["materials"]) == len(scene["materials"]) and np.abs(back["normals"] - scene["normals"]).max() < 1e-6
+        # normals: the reader normalises what it reads (loader.comp:119-128), one ulp off the generator's here and there;
+        # materials: Kd / Ks / Ke carry 6 decimals in the .mtl, the generator's are kept
+        scene = dict(scene, tris=back["tris"], normals=back["normals"], mats=back["mats"])
+        obj_note = "scene written by scenes.write_obj and read back by scenes.read_obj (%d bytes of OBJ)" % obj_bytes
+    elif args.scene == "stress":
+        obj_note += " (a 10 M-triangle OBJ is 1.5 GB of text: the stress scene skips the file)"
     if args.textured:
         scene = scenes.textured(scene)
     try:
         R = Renderer(psm, scenes, scene, args, dist)
     except pdist.NativeUnavailable as e:
-        # every rank gets this together (Comm.attach_native agrees on it): all fall back to torch.distributed collectives
+        # every rank gets this together (Comm.attach_native agrees on it). No silent fall-back: a scaling run that is green
+        # on torch.distributed collectives would say nothing about the path SURVEY 8(e) describes. PSM_DIST_NATIVE=0 asks
+        # for the torch.distributed collectives explicitly.
         if dist.rank == 0:
-            print("bench: the C ABI's RCCL communicator is unavailable (%s); using torch.distributed collectives" % e, file=sys.stderr)
-        os.environ["PSM_DIST_NATIVE"] = "0"
-        R = Renderer(psm, scenes, scene, args, dist)
+            print("bench: the C ABI's RCCL communicator is unavailable (%s); set PSM_DIST_NATIVE=0 to run on torch.distributed "
+                  "collectives instead" % e, file=sys.stderr)
+        dist.close()
+        sys.exit(3)
     ctx = R.ctx
-    lanes_mode = True
 
     def run_steps(k):
         if dist.active:
@@ -456,29 +549,59 @@ def main():
     R.batch.sync()
 
     # counting pass: the frames of the timed region (same rand() streams), one after another on lane 0,
-    # counters on: V, T, R are deterministic per seed
+    # counters on: V, T, R are deterministic per seed; logged per bounce round
     reseed()
     ctx.stats_enable(False, True)
     ctx.stats_reset()
     ray_sets = [] if (dist.rank == 0 and not args.no_cpu_baseline) else None
+    round_log = []
     for i in range(args.steps):
-        R.frame(record=ray_sets if i == 0 else None)
+        R.frame(record=ray_sets if i == 0 else None, round_log=round_log)
     cnt = ctx.stats()
     V, T, Rr = cnt.node_visits, cnt.tri_tests, cnt.rays_traced
+    assert sum(r[1] for r in round_log) == V and sum(r[2] for r in round_log) == T and sum(r[0] for r in round_log) == Rr
 
-    # kernel pass: the same frames again, one after another, HIP events on every launch (on the launching
-    # stream): per-stage times and the traversal kernel's own launch duration for the roofline
-    if lanes_mode:
-        reseed()
-        R.batch.sync()
-        ctx.stats_enable(True, False)
-        ctx.stats_reset()
-        for i in range(args.steps):
-            R.frame()
-        ctx.sync()
-        kst = ctx.stats()
-        assert kst.rays_traced == Rr, (kst.rays_traced, Rr)
-        ctx.stats_enable(False, False)
+    # kernel pass, serial: the same frames again, one after another on lane 0, HIP events on every launch (on the launching
+    # stream): per-stage times, and the single-launch traversal kernel running alone
+    reseed()
+    R.batch.sync()
+    ctx.stats_enable(True, False)
+    ctx.stats_reset()
+    for i in range(args.steps):
+        R.frame()
+    ctx.sync()
+    kst = ctx.stats()
+    assert kst.rays_traced == Rr, (kst.rays_traced, Rr)
+    ctx.stats_enable(False, False)
+
+    # kernel pass, as timed: the call of the timed region with HIP events around every traversal launch on every lane's own
+    # stream (psm_stats_enable(2, 0): traversal launches only, so the rebuild keeps its captured graph and the schedule is
+    # the timed one). Prices the kernel the timed region actually launches.
+    reseed()
+    for ln in R.batch.lanes:
+        ln.ctx.stats_enable(2, False)
+        ln.ctx.stats_reset()
+        ln.ctx.stats_reference(R.batch.lanes[0].ctx)   # one time axis for all lanes' launches
+    dist.barrier()
+    R.batch.sync()
+    e0 = time.perf_counter()
+    traced_ev = run_steps(args.steps)
+    R.batch.sync()
+    ev_elapsed = time.perf_counter() - e0
+    assert traced_ev == Rr, (traced_ev, Rr)
+    lane_stats = [ln.ctx.stats() for ln in R.batch.lanes]
+    spans = sorted(iv for ln in R.batch.lanes for iv in ln.ctx.traverse_intervals())
+    busy_ms, edge = 0.0, -1e30        # union of the traversal launches' intervals: time with at least one of them on the chip
+    for a, b in spans:
+        if b > edge:
+            busy_ms += b - max(a, edge)
+            edge = b
+    for ln in R.batch.lanes:
+        ln.ctx.stats_enable(False, False)
+    ho_launches = sum(s_.handover_launches for s_ in lane_stats)
+    ho_ms = sum(s_.handover_ms for s_ in lane_stats)
+    wh_launches = sum(s_.traverse_launches for s_ in lane_stats) - ho_launches
+    wh_ms = sum(s_.traverse_ms for s_ in lane_stats) - ho_ms
 
     # timed region: exactly K steps
     reseed()
@@ -519,7 +642,49 @@ def main():
     if dist.rank == 0:
         img = R.batch.snapHdr()
         copy_gbs = ctx.copy_bandwidth(1 << 30, 5)  # the box's achievable ceiling next to the vendor peak
-        roof = roofline(st, Rr, V, T, copy_gbs, args.scene, args.width, args.height, lanes_mode)  # rank 0's launches
+        # which rounds of the timed region ran the hand-over kernel: plan_traverse's rule (csrc/trace.hip) -- frames in flight
+        # (or a forced hand-over schedule) and at least phase_min_rays rays in the round
+        min_rays = 1 << 19
+        if args.trav_adaptive and len(args.trav_adaptive.split(",")) >= 5:
+            min_rays = int(args.trav_adaptive.split(",")[4])
+        hand = args.traverse in ("phased", "adaptive") or (args.traverse == "auto" and R.lanes > 1)
+        ho_rounds = [r for r in round_log if hand and r[0] >= min_rays]
+        wh_rounds = [r for r in round_log if not (hand and r[0] >= min_rays)]
+        assert (ho_launches > 0) == (len(ho_rounds) > 0), (ho_launches, len(ho_rounds))
+        ms_step = elapsed / args.steps * 1e3
+        how = ("the call of the timed region repeated with HIP events around every traversal launch on every lane's stream "
+               "(%d frame(s) in flight: a launch shares the chip with the other frames' kernels); that pass ran at %.3f ms per "
+               "step against %.3f timed" % (R.lanes, ev_elapsed / args.steps * 1e3, ms_step))
+        sums = lambda rs: (sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs))
+        if ho_rounds:
+            timed_k = price("rt_traverse<false, false, true>", ho_launches, ho_ms, *sums(ho_rounds), len(ho_rounds), args.steps,
+                            args.scene, args.width, args.height, how)
+            if wh_launches:
+                timed_k["rounds_below_min_rays_run_single_launch"] = price(
+                    "rt_traverse<false, false, false>", wh_launches, wh_ms, *sums(wh_rounds), len(wh_rounds), args.steps,
+                    args.scene, args.width, args.height, how)
+        else:
+            timed_k = price("rt_traverse<false, false, false>", wh_launches, wh_ms, *sums(wh_rounds), len(wh_rounds), args.steps,
+                            args.scene, args.width, args.height, how)
+        whole_k = price("rt_traverse<false, false, false>", st.traverse_launches, st.traverse_ms, Rr, V, T, len(round_log), args.steps,
+                        args.scene, args.width, args.height,
+                        "serial kernel pass: the same frames one after another on one stream, every launch alone on the chip")
+        # launches of different frames overlap: their summed durations exceed the wall time; the union of their intervals is
+        # the time during which traversal is on the chip at all, and the ratio is how many run side by side on average
+        timed_k["traversal_busy_ms_per_step"] = busy_ms / args.steps
+        timed_k["launches_side_by_side"] = (ho_ms + wh_ms) / busy_ms if busy_ms > 0 else None
+        timed_k["achieved_over_busy_time"] = (Rr * 44 + V * 64 + T * 36) / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else None
+        if timed_k.get("traffic") and busy_ms > 0:
+            # chip level: the HBM-side bytes of all traversal launches of a step over the time traversal is on the chip
+            tot = timed_k["traffic"] * timed_k["launches"]
+            small = timed_k.get("rounds_below_min_rays_run_single_launch")
+            if small and small.get("traffic"):
+                tot += small["traffic"] * small["launches"] * (small["algorithmic_bytes_per_launch"] / max(whole_k["algorithmic_bytes_per_launch"], 1.0))
+            timed_k["hbm_gbs"] = tot / (busy_ms * 1e-3) / 1e9
+            timed_k["hbm_frac"] = timed_k["hbm_gbs"] / HBM_PEAK_GBS
+            timed_k["hbm_frac_note"] = ("HBM-side bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, committed passes) of all traversal "
+                                        "launches of a step over traversal_busy_ms_per_step, the time at least one of them is on the chip")
+        roof = roofline(timed_k, whole_k, (Rr * 44 + V * 64 + T * 36) / args.steps, ms_step, copy_gbs)  # rank 0's launches
         out = {
             "metric": "Mrays/sec + ms/frame, Sponza 1920x1080 4spp",
             "value": total_rays / elapsed / 1e6,
@@ -536,14 +701,14 @@ def main():
                                        args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth,
                                        R.lanes),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes,
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "input": obj_note,
+                       "band_weights": R.weights,
                        "collectives": ("none" if not dist.active else
                                        "psm_dist_* (RCCL from libpsm_hip.so)" if R.native is not None else "torch.distributed " + dist.backend)},
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
-            "stage_ms_per_frame_measured": ("kernel pass: the same frames one after another on one stream (serial path; with "
-                                            "frames in flight the stages of different frames overlap, so these do not add "
-                                            "up to ms_per_step)") if lanes_mode else "timed region",
+            "stage_ms_per_frame_measured": ("serial kernel pass: the same frames one after another on one stream (with frames in "
+                                            "flight the stages of different frames overlap, so these do not add up to ms_per_step)"),
             "stage_ms_per_frame": {"build": st.build_ms / args.steps, "bounds": st.bounds_ms / args.steps,
                                    "morton": st.morton_ms / args.steps, "sort": st.sort_ms / args.steps,
                                    "emit_refit": st.emit_ms / args.steps,

@@ -453,9 +453,22 @@ typedef struct {
      * (s_memtime) and in ticks of the constant 100 MHz clock (s_memrealtime) -- their ratio x 100 MHz is the clock the chip
      * held while they ran -- the wave-steps they took and their number */
     uint64_t wave_clock_ticks, wave_real_ticks, wave_steps, waves;
+    /* the part of traverse_launches / traverse_ms that are launches of the hand-over kernel (rt_traverse<*, false, true>:
+     * the PHASED / ADAPTIVE schedules, what AUTO runs with frames in flight); the rest are single-launch traversals */
+    uint32_t handover_launches;
+    float handover_ms;
 } psm_stats;
+/* timing: 0 off; 1 HIP events around every launch, per stage (the rebuild then runs as plain launches instead of its
+ * captured graph); 2 traversal launches only -- light enough to stay on while frames are in flight, the build keeps
+ * its graph. counting: V, T and the drop counters (the counting instantiations of the kernels). */
 int psm_stats_enable(psm_ctx* ctx, int timing, int counting);
 int psm_stats_reset(psm_ctx* ctx);
+/* one time axis for the traversal launches of several contexts of a device (frames in flight): psm_stats_reference(ctx,
+ * ctx) records the origin on ctx's stream, psm_stats_reference(other, ctx) makes `other` share it (the origin context must
+ * outlive the sharing ones' next reference); psm_stats_traverse_intervals then returns start, end in ms after the origin of
+ * every traversal launch timed since the last reset (start_end_ms[2 * cap_launches], *count = launches recorded) */
+int psm_stats_reference(psm_ctx* ctx, psm_ctx* origin);
+int psm_stats_traverse_intervals(psm_ctx* ctx, float* start_end_ms, uint32_t cap_launches, uint32_t* count);
 int psm_stats_get(psm_ctx* ctx, psm_stats* out); /* synchronises */
 
 #ifdef __cplusplus

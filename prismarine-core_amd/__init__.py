@@ -32,7 +32,7 @@ EXPORTS = [
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
-    "psm_stats_enable", "psm_stats_reset", "psm_stats_get",
+    "psm_stats_enable", "psm_stats_reset", "psm_stats_get", "psm_stats_reference", "psm_stats_traverse_intervals",
     "psm_dist_unique_id", "psm_dist_init", "psm_dist_prepare", "psm_dist_connect", "psm_dist_connect_transport", "psm_dist_connect_hoststaged",
     "psm_dist_transport_name", "psm_dist_agree", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
     "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile", "psm_dist_set_band_weights",
@@ -86,7 +86,7 @@ class Stats(C.Structure):
                 ("sort_ms", C.c_float), ("shade_ms", C.c_float), ("camera_ms", C.c_float),
                 ("sample_ms", C.c_float), ("rounds", C.c_uint32), ("bounds_ms", C.c_float), ("morton_ms", C.c_float),
                 ("emit_ms", C.c_float), ("wave_clock_ticks", C.c_uint64), ("wave_real_ticks", C.c_uint64),
-                ("wave_steps", C.c_uint64), ("waves", C.c_uint64)]
+                ("wave_steps", C.c_uint64), ("waves", C.c_uint64), ("handover_launches", C.c_uint32), ("handover_ms", C.c_float)]
 
 
 _lib = None
@@ -146,7 +146,20 @@ class Context:
         return v.value
 
     def stats_enable(self, timing=True, counting=False):
+        """timing: False / True (HIP events around every launch) / 2 (traversal launches only: light, for frames in flight)"""
         self.check(lib().psm_stats_enable(self._h, C.c_int(int(timing)), C.c_int(int(counting))), "psm_stats_enable")
+
+    def stats_reference(self, origin=None):
+        """time origin of traverse_intervals(): recorded now on this context's stream, or shared with `origin`'s"""
+        self.check(lib().psm_stats_reference(self._h, (origin or self)._h), "psm_stats_reference")
+
+    def traverse_intervals(self):
+        """(start, end) in ms after the reference of every traversal launch timed since the last reset"""
+        n = C.c_uint32()
+        self.check(lib().psm_stats_traverse_intervals(self._h, None, C.c_uint32(0), C.byref(n)), "psm_stats_traverse_intervals")
+        buf = (C.c_float * (2 * max(n.value, 1)))()
+        self.check(lib().psm_stats_traverse_intervals(self._h, buf, C.c_uint32(n.value), C.byref(n)), "psm_stats_traverse_intervals")
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n.value)]
 
     def stats_reset(self):
         self.check(lib().psm_stats_reset(self._h), "psm_stats_reset")

@@ -28,7 +28,7 @@ int set_err(psm_ctx* c, int code, const char* what, hipError_t e) {
 }
 
 TimedScope::TimedScope(psm_ctx* ctx, int cat) : c(ctx) {
-    if (!c->timing) return;
+    if (!c->timing || (c->timing == 2 && cat != CAT_TRAVERSE && cat != CAT_TRAVERSE_HANDOVER)) return;
     psm_ctx::Timed t;
     for (hipEvent_t* ev : {&t.a, &t.b}) {
         if (!c->free_events.empty()) {
@@ -53,6 +53,12 @@ static void collect_timing(psm_ctx* c) {
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             c->cat_ms[t.cat] += ms;
             c->cat_launches[t.cat]++;
+            if (t.cat == CAT_TRAVERSE_HANDOVER) { c->cat_ms[CAT_TRAVERSE] += ms; c->cat_launches[CAT_TRAVERSE]++; }
+            if (c->ref_event && (t.cat == CAT_TRAVERSE || t.cat == CAT_TRAVERSE_HANDOVER)) {
+                float t0 = 0.f;
+                if (hipEventElapsedTime(&t0, c->ref_event, t.a) == hipSuccess) { c->intervals.push_back(t0); c->intervals.push_back(t0 + ms); }
+                else (void)hipGetLastError();
+            }
         }
         c->free_events.push_back(t.a);
         c->free_events.push_back(t.b);
@@ -124,6 +130,7 @@ int psm_ctx_destroy(psm_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_timing(c);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->ref_event && c->ref_owner == c) (void)hipEventDestroy(c->ref_event);
     for (auto& b : c->bufs) if (b.ptr) (void)hipFree(b.ptr);
     dev_free(c->sort_keys_tmp);
     dev_free(c->sort_vals_tmp);
@@ -467,7 +474,7 @@ int psm_bvh_build(psm_bvh* b, const double* opt) {
     }
     // Plain launches: the first build of a configuration (a scene that is built once gains nothing from a capture, and
     // it allocates the sort's buffers), per-stage timing (events between the stages), or graphs switched off.
-    if (!b->use_graph || c->timing || b->tri_count == 0 || b->plain_builds == 0) {
+    if (!b->use_graph || c->timing == 1 || b->tri_count == 0 || b->plain_builds == 0) {
         int rc = bvh_build_plain(b, opt);
         b->plain_builds = (rc == PSM_OK) ? b->plain_builds + 1 : 0;
         b->graph_tris = b->tri_count, b->graph_algo = c->sort_algorithm, b->graph_sort_gen = c->sort_gen;
@@ -1021,7 +1028,7 @@ int psm_rt_download_texels(psm_rt* r, float* sum_rgba, float* coord_xy, int32_t*
 // ---- statistics ---------------------------------------------------------------------------------
 int psm_stats_enable(psm_ctx* c, int timing, int counting) {
     if (!c) return PSM_ERR_INVALID;
-    c->timing = timing != 0;
+    c->timing = timing < 0 ? 0 : (timing > 2 ? 1 : timing);
     c->counting = counting != 0;
     return PSM_OK;
 }
@@ -1031,9 +1038,40 @@ int psm_stats_reset(psm_ctx* c) {
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     collect_timing(c);
     for (int i = 0; i < CAT_COUNT; i++) { c->cat_ms[i] = 0.f; c->cat_launches[i] = 0; }
+    c->intervals.clear();
     c->rays_traced = 0;
     c->rounds = 0;
     PSM_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(DevCounters), c->stream));
+    return PSM_OK;
+}
+// Time origin for psm_stats_traverse_intervals: an event recorded now on `origin`'s stream (origin == c, or another
+// context of the same device whose origin `c` shares, so that the launches of several lanes land on one time axis).
+int psm_stats_reference(psm_ctx* c, psm_ctx* origin) {
+    if (!c || !origin || c->device != origin->device) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    if (origin == c) {
+        if (!c->ref_event || c->ref_owner != c) {
+            hipEvent_t e = nullptr;
+            PSM_HIP(c, hipEventCreate(&e));
+            c->ref_event = e; c->ref_owner = c;
+        }
+        PSM_HIP(c, hipEventRecord(c->ref_event, c->stream));
+        PSM_HIP(c, hipEventSynchronize(c->ref_event));
+    } else {
+        if (!origin->ref_event || origin->ref_owner != origin) return set_err(c, PSM_ERR_STATE, "psm_stats_reference: the origin context has no reference of its own yet");
+        c->ref_event = origin->ref_event; c->ref_owner = origin;
+    }
+    return PSM_OK;
+}
+// start / end (ms after the reference) of every traversal launch timed since the last reset; synchronises
+int psm_stats_traverse_intervals(psm_ctx* c, float* start_end_ms, uint32_t cap_launches, uint32_t* count) {
+    if (!c || !count) return PSM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    const uint32_t n = (uint32_t)(c->intervals.size() / 2);
+    *count = n;
+    if (start_end_ms) for (uint32_t i = 0; i < n && i < cap_launches; i++) { start_end_ms[2 * i] = c->intervals[2 * i]; start_end_ms[2 * i + 1] = c->intervals[2 * i + 1]; }
     return PSM_OK;
 }
 int psm_stats_get(psm_ctx* c, psm_stats* out) {
@@ -1067,6 +1105,8 @@ int psm_stats_get(psm_ctx* c, psm_stats* out) {
     out->wave_real_ticks = d.wave_real_ticks;
     out->wave_steps = d.wave_steps;
     out->waves = d.waves;
+    out->handover_launches = c->cat_launches[CAT_TRAVERSE_HANDOVER];
+    out->handover_ms = c->cat_ms[CAT_TRAVERSE_HANDOVER];
     return PSM_OK;
 }
 

@@ -37,7 +37,8 @@ struct TravState {      // structure of arrays in ONE allocation, `capacity` ent
     __host__ __device__ int32_t* lastTri() const { return (int32_t*)(base + (size_t)32 * capacity); }
     __host__ __device__ int32_t* stack() const { return (int32_t*)(base + (size_t)36 * capacity); }
 };
-enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_BOUNDS, CAT_MORTON, CAT_EMIT, CAT_COUNT };
+enum StatCat { CAT_TRAVERSE = 0, CAT_BUILD, CAT_SORT, CAT_SHADE, CAT_CAMERA, CAT_SAMPLE, CAT_BOUNDS, CAT_MORTON, CAT_EMIT,
+               CAT_TRAVERSE_HANDOVER /* launches of the hand-over kernel rt_traverse<*, false, true>; also counted in CAT_TRAVERSE */, CAT_COUNT };
 
 // device-resident counters (one block per context)
 struct DevCounters {
@@ -115,7 +116,8 @@ struct psm_ctx {
     bool own_stream = true;
     std::string err;
     std::vector<psm::Buf> bufs;  // handle = index+1
-    bool timing = false, counting = false;
+    int timing = 0;      // 0: none; 1: HIP events around every launch (the rebuild then runs as plain launches); 2: traversal launches only
+    bool counting = false;
     psm::DevCounters* d_counters = nullptr;
     struct Timed {
         hipEvent_t a, b;
@@ -123,6 +125,9 @@ struct psm_ctx {
     };
     std::vector<Timed> timed;
     std::vector<hipEvent_t> free_events;
+    hipEvent_t ref_event = nullptr;     // psm_stats_reference: the time origin of `intervals` (owned by ref_owner)
+    psm_ctx* ref_owner = nullptr;
+    std::vector<float> intervals;       // start, end (ms after ref_event) of every timed traversal launch since the last reset
     float cat_ms[psm::CAT_COUNT] = {0};
     uint32_t cat_launches[psm::CAT_COUNT] = {0};
     uint64_t rays_traced = 0;

@@ -575,7 +575,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
                     g = (uint32_t)(need < RESUME_GRID_CAP ? need : RESUME_GRID_CAP);
                     if (g == 0) g = 1;
                 }
-                TimedScope ts(c, CAT_TRAVERSE);
+                TimedScope ts(c, CAT_TRAVERSE_HANDOVER);
                 if (c->counting) rt_traverse<true, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
                 else rt_traverse<false, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
                 if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);

@@ -2,7 +2,9 @@
 """Turn the PMC passes of profiles/collect.sh into the per-launch figures bench.py's `roofline` object quotes.
 
 usage: profiles/make_traffic.py <out.json> <tag> <scene> <width> <height> [<tag> <scene> <width> <height> ...]
-reads gpurun_out/<tag>_{fetch,write,sq,tcc}/**/counter_collection.csv and gpurun_out/<tag>_kt1/**/kernel_stats.csv
+reads gpurun_out/<tag>_{fetch,write,sq,tcc}/**/counter_collection.csv and gpurun_out/<tag>_{kt,kt1,kt1a}/**/kernel_stats.csv
+(round 3: the PMC passes profile the bench AS TIMED, so the hand-over kernel of the timed region, rt_traverse<false, false,
+true>, has counters of its own next to the single-launch kernel of the serial passes)
 
 Per traversal kernel (the dominant kernel), averaged over its launches:
   fetch_bytes_raw   FETCH_SIZE x 1024          (gfx950: half the bytes of wide streaming reads, MI355X_MICROARCH.md HBM)
@@ -37,8 +39,8 @@ def per_kernel(tag, sub, want):
     return out
 
 
-def kernel_avg_us(tag, want):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_kt1" % tag, "**", "*kernel_stats.csv"), recursive=True)
+def kernel_avg_us(tag, want, sub="kt1"):
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, sub), "**", "*kernel_stats.csv"), recursive=True)
     res = {}
     if files:
         for r in csv.DictReader(open(files[0])):
@@ -54,9 +56,16 @@ def main():
     args = sys.argv[2:]
     for q in range(0, len(args), 4):
         tag, scene, w, h = args[q], args[q + 1], int(args[q + 2]), int(args[q + 3])
-        fetch, write = per_kernel(tag, "fetch", "rt_traverse"), per_kernel(tag, "write", "rt_traverse")
-        sq, tcc = per_kernel(tag, "sq", "rt_traverse"), per_kernel(tag, "tcc", "rt_traverse")
-        times = kernel_avg_us(tag, "rt_traverse")
+        # hand-over kernel: the passes of the bench as timed; single-launch kernels: the --lanes 1 passes (whole rounds only)
+        def both(sub):
+            a, b = per_kernel(tag, sub, "rt_traverse"), per_kernel(tag, sub + "1", "rt_traverse")
+            out = {k: v for k, v in a.items() if k.endswith("true>")}
+            out.update({k: v for k, v in (b if b else a).items() if not k.endswith("true>")})
+            return out
+        fetch, write, sq, tcc = both("fetch"), both("write"), both("sq"), both("tcc")
+        alone = kernel_avg_us(tag, "rt_traverse", "kt1")        # --lanes 1: single-launch kernel, every launch alone
+        alone.update({k: v for k, v in kernel_avg_us(tag, "rt_traverse", "kt1a").items() if k.endswith("true>")})  # hand-over kernel alone
+        flight = kernel_avg_us(tag, "rt_traverse", "kt")        # as timed: launches of different frames overlap
         for k in sorted(fetch):
             n, v = fetch[k]["FETCH_SIZE"]
             e = {"scene": scene, "width": w, "height": h, "kernel": k, "launches_sampled": n,
@@ -72,23 +81,17 @@ def main():
             if k in tcc and "TCC_HIT_sum" in tcc[k]:
                 hit, miss = tcc[k]["TCC_HIT_sum"][1], tcc[k]["TCC_MISS_sum"][1]
                 e["l2_hit"] = hit / max(hit + miss, 1.0)
-            if k in times:
-                e["kernel_trace_avg_us"] = times[k]["avg_us"]
-                e["kernel_trace_calls"] = times[k]["calls"]
+            if k in alone:
+                e["alone_avg_us"] = alone[k]["avg_us"]
+                e["alone_calls"] = alone[k]["calls"]
+            if k in flight:
+                e["in_flight_avg_us"] = flight[k]["avg_us"]
+                e["in_flight_calls"] = flight[k]["calls"]
             e["source"] = ("rocprofv3 --pmc passes of profiles/collect.sh %s (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own "
-                           "pass, --lanes 1), bench.py --scene %s --width %d --height %d" % (tag, scene, w, h))
+                           "pass of the bench as timed; launches serialised by the profiler), bench.py --scene %s --width %d --height %d; "
+                           "alone_avg_us from the --lanes 1 kernel traces, in_flight_avg_us from the trace of the bench as timed" % (
+                               tag, scene, w, h))
             entries.append(e)
-        # the schedule of the timed region (frames in flight): the SQ pass of the bench as timed, per traversal kernel
-        sq4 = per_kernel(tag, "sq4", "rt_traverse")
-        for k in sorted(sq4):
-            c = sq4[k]
-            if "SQ_ACTIVE_INST_VALU" not in c:
-                continue
-            act, thr, ins = c["SQ_ACTIVE_INST_VALU"], c.get("SQ_THREAD_CYCLES_VALU", [0, 0.0]), c.get("SQ_INSTS_VALU", [0, 0.0])
-            entries.append({"scene": scene, "width": w, "height": h, "kernel": k, "pass": "as timed (frames in flight)",
-                            "launches_sampled": act[0], "valu_insts_total": ins[1], "valu_lane_utilisation": thr[1] / (act[1] * 64.0),
-                            "source": "rocprofv3 --pmc SQ_* pass of profiles/collect.sh %s with the bench's default frames in flight "
-                                      "(5 frames of the timed schedule, then the bench's counting and serial kernel passes)" % tag})
     json.dump({"entries": entries}, open(out_path, "w"), indent=1)
     print("wrote %d entries to %s" % (len(entries), out_path))
 
