@@ -445,8 +445,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     // the canonical order -- with a flag; every index below is a constant, so the slots live in registers, not in scratch
     OutRay outs[4];
     bool have[4] = {false, false, false, false};
-    if (it < a.nrays) {
-        const uint32_t loc = queue_loc(a.q.bases, a.q.nb, a.nrays, it);
+    const uint32_t nrays = min(a.nrays, a.q.bases[a.q.nb]);  // never past what the queue holds (psm_rt_set_ray_count)
+    if (it < nrays) {
+        const uint32_t loc = queue_loc(a.q.bases, a.q.nb, nrays, it);
         float4 A = a.q.A[loc], B = a.q.B[loc], C = a.q.C[loc];
         int in_texel = __float_as_int(A.w);
         uint32_t in_pkey = __float_as_uint(C.w);
@@ -718,7 +719,8 @@ __global__ __launch_bounds__(1024) void rt_scan_blocks(const uint32_t* __restric
 // the current queue in queue order (debug / parity download): A | B | C, m rays each
 __global__ __launch_bounds__(256) void rt_gather_queue(RayQueue q, uint32_t total, uint32_t m, float4* __restrict__ dense) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
+    total = min(total, q.bases[q.nb]);
+    if (i >= m || i >= total) return;
     const uint32_t loc = queue_loc(q.bases, q.nb, total, i);
     dense[i] = q.A[loc];
     dense[(size_t)m + i] = q.B[loc];

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const float4* __restrict__ qA = ka.qA;
     const float4* __restrict__ qB = ka.qB;
     const uint32_t* __restrict__ qbases = ka.qbases;
-    const uint32_t qnb = ka.qnb, nrays = ka.nrays;
+    const uint32_t qnb = ka.qnb;
+    // never past what the queue holds: a host-supplied count (psm_rt_set_ray_count) larger than the queue's total would
+    // resolve to slots beyond its last segment
+    const uint32_t nrays = min(ka.nrays, qbases[qnb]);
     const uint4* __restrict__ node32 = ka.node32;
     const float4* __restrict__ tri48 = ka.tri48;
     const uint32_t* __restrict__ sm = ka.sm;

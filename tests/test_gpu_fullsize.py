@@ -9,6 +9,8 @@ from util import bits, box_union, canonical_nodes
 
 pytestmark = pytest.mark.gpu
 
+C5_FRAME_RAYS = 14_756_576   # S-stress 9 999 616 tris, 3840x2160, seed of the test: rays handed to traverse in one frame
+
 
 @pytest.mark.parametrize("algo", [0, 1], ids=["three-kernel", "onesweep"])
 def test_sort_10m_keys_properties(psm, ctx, algo):
@@ -240,7 +242,8 @@ def test_c5_stress_10m_triangles_build_bit_exact_and_4k_frame(psm, ctx, oracle, 
     img1, st1, total1, rounds1, dep1, checked = frame(True)
     img2, st2, total2, rounds2, dep2, _ = frame(False)
     assert checked > 100_000
-    assert st1.rays_traced == total1 and rounds1 >= 3 and total1 > w * h
+    # the frame's ray count is a deterministic function of scene, camera and seed: pinned (8 294 400 primary rays + three bounce rounds that meet the 32-ray rule)
+    assert st1.rays_traced == total1 and rounds1 >= 3 and total1 == C5_FRAME_RAYS, (total1, rounds1)
     assert st1.iter_caps == 0 and st1.stack_drops < 1e-4 * total1
     assert np.isfinite(img1).all() and (img1[..., :3] >= 0).all() and img1[..., :3].mean() > 0.05
     assert (dep1 >= 1).all()

@@ -602,6 +602,37 @@ def test_queue_overflow_drops_past_the_ray_limit_in_queue_order(psm, ctx, oracle
     th.close()
 
 
+def test_ray_count_larger_than_the_queue_is_clamped_on_the_device(psm, ctx, scenes):
+    """psm_rt_set_ray_count accepts any count up to currentRayLimit; the segmented queue of a later round holds fewer
+    rays than that. A count beyond the queue's total must not be resolved to slots past its last segment: the kernels clamp
+    it to what the queue holds (bases[nb]), so the round equals the one run with the true count."""
+    scene = scenes.sponza_like(n_tris=20011)
+    w, h = 96, 54
+    outs = []
+    for bump in (0, 777, 4 * w * h):
+        th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+        rt.camera_matrices(cam[0], cam[1], time=31)
+        rt.applyMaterials(ms)
+        rt.intersection(th)
+        rt.shade(time=5)
+        n = rt.raycountCache                      # the real length of the (segmented) queue
+        assert 32 < n < 4 * w * h
+        rt.set_ray_count(min(4 * w * h, n + bump))
+        rt.intersection(th, force=True)
+        rt.shade(time=6)
+        assert rt.raycountCache > 32
+        rays = rt.download_rays()
+        tsum, _, _ = rt.download_texels()
+        outs.append((n, rays, tsum))
+        rt.close()
+        th.close()
+    for n, rays, tsum in outs[1:]:
+        assert n == outs[0][0]
+        _rays_equal(rays, outs[0][1])
+        assert np.array_equal(tsum[:, 3], outs[0][2][:, 3])
+        np.testing.assert_allclose(tsum[:, :3], outs[0][2][:, :3], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("name,w,h,frames", [("cornell_open", 64, 64, 3), ("sponza_small", 128, 72, 2),
                                              ("cornell_open+tex", 64, 64, 3), ("sponza_small+tex", 128, 72, 2),
                                              ("cornell_open", 37, 29, 2)])
