@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
@@ -65,7 +66,7 @@ static double run(const uint4* tab, int log2n, int live, int pad, uint32_t* out)
     return recs / (ms * 1e-3) * 1e-9;   // G records per second
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int maxlog = 24;   // 16 Mi records x 32 B = 512 MiB
     std::vector<uint32_t> h((size_t)8 << maxlog);
     uint32_t s = 1;
@@ -75,6 +76,20 @@ int main() {
     hipMalloc(&out, 256 * 16 * 128 * 4);
     hipMemcpy(tab, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     printf("G records/s (32-byte record = 2 x dwordx4 unless noted); 8 waves per SIMD, dependent chain of 256 fetches per lane\n");
+    if (argc > 1 && !strcmp(argv[1], "slab")) {
+        // round 3: what the packed-fp16 slab test (the reference's AMD_F16_BVH build) would buy the traversal loop. The fp32
+        // step is +96 half-rate VALU per fetch here (12 x 8); the fp16 step replaces 28 of its instructions by 20 (valu_rate:
+        // "fp16 slab mix" against "fp32 slab mix"), i.e. +88 at equal rates and +80 / +72 if the packed instructions ran
+        // at twice / four times the rate of the ones they replace
+        for (int log2n : {18, 24}) {
+            for (int pad : {12, 11, 10, 9}) {
+                printf("table %4d MiB tree    +%3d VALU:", (32 << log2n) >> 20, 8 * pad);
+                for (int live : {16, 24, 32, 48, 64}) printf("  live %2d: %6.1f", live, run<2, true>(tab, log2n, live, pad, out));
+                printf("\n");
+            }
+        }
+        return 0;
+    }
     for (int log2n : {15, 18, 20, 24}) {   // 1 MiB, 8 MiB, 32 MiB, 512 MiB tables
         for (int tree = 0; tree < 2; tree++) {
             for (int pad : {0, 6, 12, 18}) {

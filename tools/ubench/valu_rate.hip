@@ -35,6 +35,39 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, int
                 asm volatile("v_min3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
                              "v_min3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 10) {  // packed fp16 FMA: the reference's shipped slab test (AMD_F16_BVH, mathlib.glsl:144-164)
+                asm volatile("v_pk_fma_f16 %0, %0, %8, %9\n v_pk_fma_f16 %1, %1, %8, %9\n v_pk_fma_f16 %2, %2, %8, %9\n v_pk_fma_f16 %3, %3, %8, %9\n"
+                             "v_pk_fma_f16 %4, %4, %8, %9\n v_pk_fma_f16 %5, %5, %8, %9\n v_pk_fma_f16 %6, %6, %8, %9\n v_pk_fma_f16 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 11) {  // packed fp16 min / max
+                asm volatile("v_pk_min_f16 %0, %0, %8\n v_pk_max_f16 %1, %1, %8\n v_pk_min_f16 %2, %2, %8\n v_pk_max_f16 %3, %3, %8\n"
+                             "v_pk_min_f16 %4, %4, %8\n v_pk_max_f16 %5, %5, %8\n v_pk_min_f16 %6, %6, %8\n v_pk_max_f16 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 12) {  // fp16 -> fp32 conversions (low half, and high half through SDWA)
+                asm volatile("v_cvt_f32_f16 %0, %8\n v_cvt_f32_f16_sdwa %1, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                             "v_cvt_f32_f16 %2, %9\n v_cvt_f32_f16_sdwa %3, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                             "v_cvt_f32_f16 %4, %8\n v_cvt_f32_f16_sdwa %5, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                             "v_cvt_f32_f16 %6, %9\n v_cvt_f32_f16_sdwa %7, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 13) {  // the fp16 slab step's VALU mix for both children: 6 pk_fma + 10 pk_min/max + 4 cvt (20 instructions)
+                asm volatile("v_pk_fma_f16 %0, %0, %8, %9\n v_pk_fma_f16 %1, %1, %8, %9\n v_pk_fma_f16 %2, %2, %8, %9\n"
+                             "v_pk_fma_f16 %3, %3, %8, %9\n v_pk_fma_f16 %4, %4, %8, %9\n v_pk_fma_f16 %5, %5, %8, %9\n"
+                             "v_pk_min_f16 %6, %0, %3\n v_pk_max_f16 %7, %0, %3\n v_pk_min_f16 %0, %1, %4\n v_pk_max_f16 %3, %1, %4\n"
+                             "v_pk_min_f16 %1, %2, %5\n v_pk_max_f16 %4, %2, %5\n"
+                             "v_pk_max_f16 %6, %6, %0\n v_pk_max_f16 %6, %6, %1\n v_pk_min_f16 %7, %7, %3\n v_pk_min_f16 %7, %7, %4\n"
+                             "v_cvt_f32_f16 %2, %6\n v_cvt_f32_f16_sdwa %5, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                             "v_cvt_f32_f16 %0, %7\n v_cvt_f32_f16_sdwa %1, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 14) {  // the fp32 slab step's VALU mix for both children as rt_traverse issues it: 12 fma_mix + 12 min/max + 4 min3/max3 (28)
+                asm volatile("v_fma_mix_f32 %0, %8, %0, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %1, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %8, %2, %9 op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %3, %8, %3, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %8, %4, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %5, %9 op_sel_hi:[1,0,0]\n"
+                             "v_min_f32 %6, %0, %3\n v_max_f32 %7, %0, %3\n v_min_f32 %0, %1, %4\n v_max_f32 %3, %1, %4\n v_min_f32 %1, %2, %5\n v_max_f32 %4, %2, %5\n"
+                             "v_max3_f32 %6, %6, %0, %1\n v_min3_f32 %7, %7, %3, %4\n"
+                             "v_fma_mix_f32 %0, %8, %6, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %7, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %8, %2, %9 op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %3, %8, %3, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %8, %4, %9 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %5, %9 op_sel_hi:[1,0,0]\n"
+                             "v_min_f32 %6, %0, %3\n v_max_f32 %7, %0, %3\n v_min_f32 %0, %1, %4\n v_max_f32 %3, %1, %4\n v_min_f32 %1, %2, %5\n v_max_f32 %4, %2, %5\n"
+                             "v_max3_f32 %6, %6, %0, %1\n v_min3_f32 %7, %7, %3, %4\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             } else if (KIND == 7) {   // 8 half-rate VALU + 8 SALU mask operations (independent of the VALU ones) per group
                 asm volatile("v_min_f32 %0, %0, %8\n s_and_b64 s[20:21], s[22:23], s[24:25]\n v_max_f32 %1, %1, %8\n s_or_b64 s[26:27], s[20:21], s[24:25]\n"
                              "v_min_f32 %2, %2, %8\n s_andn2_b64 s[22:23], s[26:27], s[24:25]\n v_max_f32 %3, %3, %8\n s_xor_b64 s[20:21], s[22:23], s[26:27]\n"
@@ -107,5 +140,11 @@ int main() {
     run<7>("v_min/max + 1 SALU each", 8);
     run<8>("v_min/max + 2 SALU each", 8);
     run<9>("s_op -> v_cndmask(sgpr)", 8);
+    // the reference's shipped slab arithmetic (AMD_F16_BVH: both children at once in packed fp16) against the fp32 one
+    run<10>("v_pk_fma_f16", 8);
+    run<11>("v_pk_min/v_pk_max_f16", 8);
+    run<12>("v_cvt_f32_f16 (lo / sdwa hi)", 8);
+    run<13>("fp16 slab mix (20 inst)", 20);
+    run<14>("fp32 slab mix (28 inst)", 28);
     return 0;
 }
