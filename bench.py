@@ -68,6 +68,10 @@ def parse():
                          "accumulating image in frame order; 1 = one frame after another; 0 (default) = 4 on one GPU, "
                          "8 per GPU on several (a tile's launches are small and latency-bound: more frames in flight "
                          "fill the chip; measured with --force-dist --emulate-tile R/W, profiles/r02_tile_emulation.txt)")
+    ap.add_argument("--split", type=int, default=1,
+                    help="one GPU: trace every frame with this many Pipelines that own its 8-row bands round-robin and run their "
+                         "bounce rounds independently (psm_lanes_render_split): a part's traversal tail overlaps the other parts' "
+                         "rounds inside the frame; with --lanes 1 this is one frame at a time, the reference's call pattern")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous check only: every rank builds its communicator (gloo, no GPU), proves the group works "
                          "with one all-reduce, prints one line and exits")
@@ -104,13 +108,21 @@ class Renderer:
             torch = dist.torch
             self.lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(self.lanes - 1)]
             streams = [st.cuda_stream for st in self.lane_streams]
-        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams)
-        self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
-        self.batch.allocate(scene["tris"].shape[0])
-        if args.no_build_graph:
-            for ln in self.batch.lanes:
-                ln.th.setBuildGraph(False)
-        self.batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
+        assert args.split == 1 or not dist.active, "--split is the one-GPU schedule; tile-sharded runs keep frames in flight instead"
+        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams, split=args.split)
+        self.batches = [self.batch]
+        if args.split > 1:   # the serial passes (counters, per-stage times) render whole frames on an unsplit lane of their own
+            self.serial = psm.FrameBatch(1, w, h, device=dist.device_index, seed=1000)
+            self.batches.append(self.serial)
+            self.ctx, self.th, self.rt = self.serial.lanes[0].ctx, self.serial.lanes[0].th, self.serial.lanes[0].rays
+        else:
+            self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
+        for b in self.batches:
+            b.allocate(scene["tris"].shape[0])
+            if args.no_build_graph:
+                for ln in b.lanes:
+                    ln.th.setBuildGraph(False)
+            b.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene.get("texcoords"))
         self.ms = psm.MaterialSet()
         for m in scene["materials"]:
             self.ms.addSubmat(m)
@@ -119,7 +131,8 @@ class Renderer:
             for slot in sorted(scene["textures"]):
                 assert ts.loadTexture(scene["textures"][slot]) == slot
             self.ms.setTextureSet(ts)
-        self.batch.applyMaterials(self.ms)
+        for b in self.batches:
+            b.applyMaterials(self.ms)
         if args.traverse != "auto" or args.trav_adaptive:
             def tune(r):
                 if args.trav_adaptive:
@@ -578,10 +591,11 @@ def main():
     # stream (psm_stats_enable(2, 0): traversal launches only, so the rebuild keeps its captured graph and the schedule is
     # the timed one). Prices the kernel the timed region actually launches.
     reseed()
-    for ln in R.batch.lanes:
-        ln.ctx.stats_enable(2, False)
-        ln.ctx.stats_reset()
-        ln.ctx.stats_reference(R.batch.lanes[0].ctx)   # one time axis for all lanes' launches
+    tctx = list(R.batch.contexts())        # every context that traces in the timed region (all parts of all frames in flight)
+    for c_ in tctx:
+        c_.stats_enable(2, False)
+        c_.stats_reset()
+        c_.stats_reference(tctx[0])        # one time axis for all their launches
     dist.barrier()
     R.batch.sync()
     e0 = time.perf_counter()
@@ -589,15 +603,15 @@ def main():
     R.batch.sync()
     ev_elapsed = time.perf_counter() - e0
     assert traced_ev == Rr, (traced_ev, Rr)
-    lane_stats = [ln.ctx.stats() for ln in R.batch.lanes]
-    spans = sorted(iv for ln in R.batch.lanes for iv in ln.ctx.traverse_intervals())
+    lane_stats = [c_.stats() for c_ in tctx]
+    spans = sorted(iv for c_ in tctx for iv in c_.traverse_intervals())
     busy_ms, edge = 0.0, -1e30        # union of the traversal launches' intervals: time with at least one of them on the chip
     for a, b in spans:
         if b > edge:
             busy_ms += b - max(a, edge)
             edge = b
-    for ln in R.batch.lanes:
-        ln.ctx.stats_enable(False, False)
+    for c_ in tctx:
+        c_.stats_enable(False, False)
     ho_launches = sum(s_.handover_launches for s_ in lane_stats)
     ho_ms = sum(s_.handover_ms for s_ in lane_stats)
     wh_launches = sum(s_.traverse_launches for s_ in lane_stats) - ho_launches
@@ -647,10 +661,14 @@ def main():
         min_rays = 1 << 19
         if args.trav_adaptive and len(args.trav_adaptive.split(",")) >= 5:
             min_rays = int(args.trav_adaptive.split(",")[4])
-        hand = args.traverse in ("phased", "adaptive") or (args.traverse == "auto" and R.lanes > 1)
-        ho_rounds = [r for r in round_log if hand and r[0] >= min_rays]
-        wh_rounds = [r for r in round_log if not (hand and r[0] >= min_rays)]
-        assert (ho_launches > 0) == (len(ho_rounds) > 0), (ho_launches, len(ho_rounds))
+        hand = args.traverse in ("phased", "adaptive") or (args.traverse == "auto" and R.lanes * args.split > 1)
+        # (a frame split over several Pipelines: every part traces about 1 / split of a round's rays)
+        ho_rounds = [r for r in round_log if hand and r[0] / args.split >= min_rays]
+        wh_rounds = [r for r in round_log if not (hand and r[0] / args.split >= min_rays)]
+        if args.split == 1:
+            assert (ho_launches > 0) == (len(ho_rounds) > 0), (ho_launches, len(ho_rounds))
+        elif (ho_launches > 0) != (len(ho_rounds) > 0):   # parts near the threshold: price what was launched
+            ho_rounds, wh_rounds = (round_log, []) if ho_launches > 0 else ([], round_log)
         ms_step = elapsed / args.steps * 1e3
         how = ("the call of the timed region repeated with HIP events around every traversal launch on every lane's stream "
                "(%d frame(s) in flight: a launch shares the chip with the other frames' kernels); that pass ran at %.3f ms per "
@@ -697,11 +715,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
-                                   "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU" % (
+                                   "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU%s" % (
                                        args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth,
-                                       R.lanes),
+                                       R.lanes, ", each split over %d Pipelines" % args.split if args.split > 1 else ""),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "input": obj_note,
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "frame_split": args.split, "input": obj_note,
                        "band_weights": R.weights,
                        "collectives": ("none" if not dist.active else
                                        "psm_dist_* (RCCL from libpsm_hip.so)" if R.native is not None else "torch.distributed " + dist.backend)},

@@ -336,6 +336,19 @@ typedef struct {
 int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
                      const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
                      int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
+/* One frame split over several Pipelines of ONE GPU (new): the frames-in-flight scheduler hides a round's traversal tail
+ * behind OTHER frames; the reference's own call pattern is one frame at a time (Viewer.cpp:296-312). Here the frame's 8-row
+ * bands are dealt to `split` Pipelines ("parts": rts[q * split + k] = part k of frame slot q, carrying
+ * psm_rt_set_tile_interleaved(rt, k, split) and psm_rt_share_texels(rt, part 0 of the slot)), each with its own ray queue on
+ * its own stream, all reading the slot's hierarchy bvhs[q] (on part 0's context, rebuilt once per frame). No part waits for
+ * another part's round, so one part's tail runs under the others' next rounds; the `fewer than 32 rays -> stop` rule is
+ * applied to the frame's total (the parts park on their local counts, psm_dist_decide on their (round, count) pairs, no
+ * exchange: they are local). Up to `lanes` frames in flight (1: one frame at a time); results[f].rays sums the parts.
+ * The image equals psm_lanes_render's for the same seeds (deposit counts exactly, radiance to float-atomic order). */
+int psm_rt_share_texels(psm_rt* rt, psm_rt* owner);
+int psm_lanes_render_split(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t split, const float cam_inv[16],
+                           const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
+                           int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
 /* The same frames when they are tile-sharded over several GPUs: the `fewer than 32 rays -> stop` rule then looks
  * at each frame's GLOBAL count. A rank with >= 32 local rays knows the global count is >= 32 too, so every lane
  * runs free (as above) until its LOCAL count drops below 32 or `depth` is reached, and then parks with its queue

@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_render_split", "psm_rt_share_texels", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -722,9 +722,14 @@ class FrameBatch:
         def __init__(self, ctx, th, rays):
             self.ctx, self.th, self.rays = ctx, th, rays
 
-    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None):
+    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None, split=1):
+        """split > 1: every frame is traced by `split` Pipelines ("parts") that own the frame's 8-row bands round-robin,
+        share one hierarchy and one set of texel arrays and run their rounds independently (psm_lanes_render_split), so
+        that a part's traversal tail overlaps the other parts' rounds INSIDE the frame; lanes = frames in flight."""
         self.n = lanes
+        self.split = split
         self.lanes = []
+        self.parts = []          # parts 1..split-1 of every frame slot: (ctx, Pipeline)
         for s in range(lanes):
             ctx = Context(device, stream=None if streams is None else streams[s])
             th = TriangleHierarchy(ctx)
@@ -732,6 +737,18 @@ class FrameBatch:
             rt.resizeBuffers(width, height)
             rt.resize(*(display or (width, height)))
             self.lanes.append(FrameBatch.Lane(ctx, th, rt))
+            extra = []
+            for k in range(1, split):
+                pc = Context(device)
+                pr = Pipeline(pc, seed=seed)
+                pr.resizeBuffers(width, height)
+                pr.resize(*(display or (width, height)))
+                pr.ctx.check(lib().psm_rt_share_texels(pr._h, rt._h), "psm_rt_share_texels")
+                pr.setTileInterleaved(k, split)
+                extra.append((pc, pr))
+            if split > 1:
+                rt.setTileInterleaved(0, split)
+            self.parts.append(extra)
         # the accumulating Pipeline only samples: it has its own context so that folding a finished frame
         # never queues behind a lane's tracing kernels
         self.master_ctx = Context(device, stream=master_stream)
@@ -740,6 +757,13 @@ class FrameBatch:
         self.master.resize(*(display or (width, height)))
         self.width, self.height = width, height
         self.frames_rendered = 0
+
+    def pipelines(self):
+        """every Pipeline that traces (all parts of all frame slots)"""
+        for ln, extra in zip(self.lanes, self.parts):
+            yield ln.rays
+            for _, pr in extra:
+                yield pr
 
     # -- scene: every lane holds the same scene ------------------------------------------------------
     def allocate(self, n):
@@ -760,12 +784,12 @@ class FrameBatch:
 
     def each(self, fn):
         """Apply a setter to every lane's Pipeline: batch.each(lambda r: r.setSkybox(img))."""
-        for ln in self.lanes:
-            fn(ln.rays)
+        for r in self.pipelines():
+            fn(r)
 
     def applyMaterials(self, materials):
-        for ln in self.lanes:
-            ln.rays.applyMaterials(materials)
+        for r in self.pipelines():
+            r.applyMaterials(materials)
 
     def setSeed(self, seed):
         self.master.setSeed(seed)
@@ -781,6 +805,8 @@ class FrameBatch:
         k = len(seeds)
         if k == 0:
             return []
+        if self.split > 1:
+            return self._trace_split(cam_inv, proj_inv, seeds, depth, rebuild, optimization, fold)
         n = min(self.n, k)
         rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes[:n]])
         bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
@@ -796,6 +822,29 @@ class FrameBatch:
         for ln in self.lanes[:n]:
             ln.th._dirty = False
             ln.rays._obj = ln.th
+        return [(res[f].rounds, res[f].rays) for f in range(k)]
+
+    def _trace_split(self, cam_inv, proj_inv, seeds, depth, rebuild, optimization, fold):
+        assert fold, "split frames always fold into the accumulating Pipeline"
+        k, n, sp = len(seeds), min(self.n, len(seeds)), self.split
+        hs = []
+        for ln, extra in list(zip(self.lanes, self.parts))[:n]:
+            hs += [ln.rays._h] + [pr._h for _, pr in extra]
+        rts = (C.c_void_p * (n * sp))(*hs)
+        bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
+        sd = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
+        res = (LaneResult * k)()
+        ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
+        pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
+        opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
+        rc = lib().psm_lanes_render_split(rts, bvhs, C.c_uint32(n), C.c_uint32(sp), _p(ci), _p(pi), sd, C.c_uint32(k), C.c_uint32(depth),
+                                          C.c_int(int(rebuild)), _p(opt) if opt is not None else None, self.master._h, res)
+        self.lanes[0].ctx.check(rc, "psm_lanes_render_split")
+        for ln, extra in list(zip(self.lanes, self.parts))[:n]:
+            ln.th._dirty = False
+            ln.rays._obj = ln.th
+            for _, pr in extra:
+                pr._obj = ln.th
         return [(res[f].rounds, res[f].rays) for f in range(k)]
 
     def fold(self, k):
@@ -881,12 +930,23 @@ class FrameBatch:
     def clearSampler(self):
         self.master.clearSampler()
 
+    def contexts(self):
+        for ln, extra in zip(self.lanes, self.parts):
+            yield ln.ctx
+            for pc, _ in extra:
+                yield pc
+
     def sync(self):
-        for ln in self.lanes:
-            ln.ctx.sync()
+        for c in self.contexts():
+            c.sync()
         self.master_ctx.sync()
 
     def close(self):
+        for extra in self.parts:      # the parts borrow their slot's texel arrays: they go first
+            for pc, pr in extra:
+                pr.close()
+                pc.close()
+        self.parts = []
         for ln in self.lanes:
             ln.rays.close()
             ln.th.close()

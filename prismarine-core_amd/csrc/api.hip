@@ -563,6 +563,7 @@ static void rt_free_grid(psm_rt* r) {
     for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); dev_free(r->q_bases[q]); }
     dev_free(r->d_block);
     dev_free(r->hit0); dev_free(r->hitN); dev_free(r->pool);
+    if (r->texels_shared) { r->t_coord = nullptr; r->t_sum = nullptr; r->t_flag = nullptr; r->texels_shared = false; }
     dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag);
 }
 
@@ -616,7 +617,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     (void)hipSetDevice(c->device);
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     rt_free_grid(r);
-    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0; r->tile_root = true;
+    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0; r->tile_root = true; r->texels_lent = false;
     uint64_t wr = (uint64_t)w * h;
     uint64_t lim = std::min<uint64_t>(wr * 4, 4096ull * 4096ull);  // Pipeline.inl:187-189
     r->limit = (uint32_t)lim;
@@ -680,10 +681,32 @@ int psm_rt_set_tile_weighted(psm_rt* r, uint32_t rank, uint32_t world, const uin
         return set_err(r->ctx, PSM_ERR_INVALID, "psm_rt_set_tile_weighted: at most 64 ranks, and the weights must add up to 1..64");
     r->bands = m;
     r->tile_mode = 1; r->tile_rank = rank; r->tile_world = world;
-    r->tile_root = rank == 0;  // tiles are gathered to rank 0 (psm_rt_unpack_texels_dev), which runs sample()
+    r->tile_root = rank == 0 && !r->texels_shared && !r->texels_lent;  // tiles are gathered to rank 0 (psm_rt_unpack_texels_dev), which runs sample()
     return PSM_OK;
 }
 int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) { return psm_rt_set_tile_weighted(r, rank, world, nullptr); }
+// Several Pipelines that each trace a part of ONE frame (psm_lanes_render_split: the frame's bands dealt to `split`
+// Pipelines on one GPU, so that one part's traversal tail overlaps the other parts' rounds): they write the per-texel
+// results -- jitter position, radiance sum, flag -- of the texels they own into the SAME arrays, the owner's. Texels are
+// disjoint between the parts, so no two Pipelines touch the same texel. rt gives up its own arrays; camera() of every
+// sharing Pipeline (and of the owner) then touches its own texels only. Undone by rt's next resizeBuffers; to be
+// called again after the owner's.
+int psm_rt_share_texels(psm_rt* r, psm_rt* owner) {
+    if (!r || !owner || r == owner || !r->t_sum || !owner->t_sum) return PSM_ERR_INVALID;
+    psm_ctx* c = r->ctx;
+    if (r->w != owner->w || r->h != owner->h || c->device != owner->ctx->device)
+        return set_err(c, PSM_ERR_INVALID, "psm_rt_share_texels: the Pipelines differ in ray-grid size or device");
+    if (owner->texels_shared) return set_err(c, PSM_ERR_INVALID, "psm_rt_share_texels: the owner itself borrows its texels");
+    (void)hipSetDevice(c->device);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (!r->texels_shared) { dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag); }
+    r->t_coord = owner->t_coord; r->t_sum = owner->t_sum; r->t_flag = owner->t_flag;
+    r->texels_shared = true;
+    r->tile_root = false;
+    owner->tile_root = false;
+    owner->texels_lent = true;
+    return PSM_OK;
+}
 int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {
     if (!r || !count) return PSM_ERR_INVALID;
     *count = tile_texel_count(r);

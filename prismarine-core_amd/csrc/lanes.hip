@@ -227,10 +227,11 @@ struct ShardedLanes {
     uint32_t* rounds;
     std::vector<uint32_t> force_until;
     std::vector<LaneState> st;
+    std::vector<uint64_t> traced;  // rays handed to traverse per lane since its frame began
     int rc = PSM_OK;
 
     ShardedLanes(psm_rt* const* r, psm_bvh* const* b, uint32_t n, uint32_t d, uint32_t* rs, uint32_t* rd)
-        : rts(r), bvhs(b), lanes(n), depth(d), rand_state(rs), rounds(rd), force_until(n, 0u), st(n, FINISHED) {}
+        : rts(r), bvhs(b), lanes(n), depth(d), rand_state(rs), rounds(rd), force_until(n, 0u), st(n, FINISHED), traced(n, 0ull) {}
 
     int step(uint32_t s) {  // park, or queue one more round
         psm_rt* r = rts[s];
@@ -238,6 +239,7 @@ struct ShardedLanes {
         uint32_t t = lcg_next(rand_state[s]);  // drawn every round, ray or no ray
         rounds[s]++;
         if (r->ray_count == 0) return PSM_OK;  // nothing to trace: the lane is re-examined at once
+        traced[s] += r->ray_count;
         int e = psm_rt_traverse(r, bvhs[s]);
         if (e != PSM_OK) return e;
         e = psm_rt_shade(r, bvhs[s], t);
@@ -250,13 +252,31 @@ struct ShardedLanes {
     // begin a new frame on lane s: build (if rebuild) + camera, then rounds until it parks or a round is in flight
     void start(uint32_t s, uint32_t seed, const float* cam_inv, const float* proj_inv, int rebuild, const double* opt) {
         if (rc != PSM_OK) return;
+        if (rebuild) rc = psm_bvh_build(bvhs[s], opt);
+        begin(s, seed, cam_inv, proj_inv);
+    }
+    // the same without the build (the hierarchy has been rebuilt by somebody else and this lane's stream waits for it)
+    void begin(uint32_t s, uint32_t seed, const float* cam_inv, const float* proj_inv) {
+        if (rc != PSM_OK) return;
         rand_state[s] = seed;
         rounds[s] = 0;
         force_until[s] = 0;
-        if (rebuild) rc = psm_bvh_build(bvhs[s], opt);
-        if (rc == PSM_OK) rc = psm_rt_camera(rts[s], cam_inv, proj_inv, lcg_next(rand_state[s]));
+        traced[s] = 0;
+        rc = psm_rt_camera(rts[s], cam_inv, proj_inv, lcg_next(rand_state[s]));
         st[s] = IDLE;
         while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+    }
+    // one non-blocking look at lane s: true when its round in flight has ended (the lane has then been stepped on)
+    bool poll(uint32_t s) {
+        if (rc != PSM_OK || st[s] != RUNNING) return false;
+        hipError_t q = hipEventQuery(rts[s]->ev_cnt);
+        if (q == hipErrorNotReady) return false;
+        if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); return false; }
+        rts[s]->ray_count = *rts[s]->h_cnt;
+        rts[s]->count_valid = true;
+        st[s] = IDLE;
+        while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+        return true;
     }
     // continue a parked lane at least up to round `until`
     void resume(uint32_t s, uint32_t until) {
@@ -421,5 +441,162 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
         rts[s]->in_flight = 1;
     }
     if (fold_into) (void)hipStreamSynchronize(fold_into->ctx->stream);
+    return rc;
+}
+
+
+// ---- one frame split over several Pipelines of ONE GPU --------------------------------------------------------------
+//
+// The reference renders one frame at a time (Viewer.cpp:296-312), and a frame's bounce round cannot end before its
+// longest ray: a frame that runs alone leaves the chip almost idle for a third of every round. The
+// frames-in-flight scheduler above hides those tails behind OTHER frames. This one hides them inside a frame: the
+// frame's 8-row bands are dealt to `split` Pipelines ("parts") that share the frame's hierarchy and write into one set
+// of texel arrays (psm_rt_share_texels), each with its own ray queue on its own stream -- exactly the tile sharding of
+// the multi-GPU path, with the "ranks" living on one device. No part waits for another part's round, so one part's
+// traversal tail can run under the other parts' next rounds; rays never cross parts (radiance is per texel,
+// sampler.comp:53-66; secondary rays inherit their texel, rayslib.glsl:148). The `fewer than 32 rays -> stop` rule
+// (Pipeline.inl:459-461) looks at the frame's total, as in the sharded path: parts park on their local counts and
+// psm_dist_decide is applied to the parts' (round, count) pairs -- here without any exchange, the parts being local.
+// The image equals the unsplit one (deposit counts exactly, radiance to float-atomic order).
+//
+// MEASURED (round 3, C3): it does not pay. One frame at a time 3.74 ms unsplit against 4.17 / 4.03 / 3.84 /
+// 4.71 ms split over 2 / 3 / 4 / 6 parts: the parts start together and have equal work, so their tails coincide, and the
+// fold at the end of the frame puts them back in step every frame -- where two FRAMES in flight drift apart and reach
+// 2.9 ms per frame. Starting part k when part k-1's first traversal launch has ended (anti-phase on purpose) gave
+// 4.05-4.26 ms. Kept as a selectable, parity-tested schedule (bench.py --split), not a default.
+//
+// rts[q * split + k]: part k of frame slot q -- psm_rt_set_tile_interleaved(rt, k, split), texels shared with part 0 of
+// the slot; bvhs[q]: the slot's hierarchy, on part 0's context. Up to `lanes` frames are in flight (lanes = 1: one frame
+// at a time); frames fold into fold_into in frame order.
+extern "C" int psm_lanes_render_split(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t split, const float cam_inv[16],
+                                      const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
+                                      int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results) {
+    if (!rts || !bvhs || !cam_inv || !proj_inv || lanes == 0 || split == 0 || split > 16 || lanes * split > 64 || (frames && !frame_seeds))
+        return PSM_ERR_INVALID;
+    if (!fold_into) return PSM_ERR_INVALID;
+    const uint32_t total = lanes * split;
+    for (uint32_t q = 0; q < lanes; q++) {
+        if (!bvhs[q]) return PSM_ERR_INVALID;
+        for (uint32_t k = 0; k < split; k++) {
+            psm_rt* r = rts[q * split + k];
+            if (!r) return PSM_ERR_INVALID;
+            psm_ctx* c = r->ctx;
+            if (fold_into->w != r->w || fold_into->h != r->h) return set_err(c, PSM_ERR_INVALID, "psm_lanes_render_split: fold_into and the parts differ in ray-grid size");
+            if (split > 1 && (r->tile_mode != 1 || r->tile_world != split || r->tile_rank != k || r->tile_root))
+                return set_err(c, PSM_ERR_STATE, "psm_lanes_render_split: part k of a frame must carry psm_rt_set_tile_interleaved(k, split) and share part 0's texels");
+            if (k > 0 && (r->t_sum != rts[q * split]->t_sum || !r->texels_shared))
+                return set_err(c, PSM_ERR_STATE, "psm_lanes_render_split: the parts of a frame must share part 0's texels (psm_rt_share_texels)");
+            for (uint32_t p = 0; p < q * split + k; p++)
+                if (rts[p] == r || rts[p]->ctx->stream == c->stream)
+                    return set_err(c, PSM_ERR_INVALID, "psm_lanes_render_split: every part needs its own context (stream) and ray buffers");
+            int e = lane_resources(r);
+            if (e != PSM_OK) return e;
+        }
+        if (bvhs[q]->ctx != rts[q * split]->ctx)
+            return set_err(rts[q * split]->ctx, PSM_ERR_INVALID, "psm_lanes_render_split: a slot's hierarchy must live on the context of its part 0");
+    }
+    if (frames == 0) return PSM_OK;
+    (void)hipSetDevice(rts[0]->ctx->device);
+    for (uint32_t s = 0; s < total; s++) rts[s]->in_flight = total;
+    std::vector<uint32_t> state(total, 0u), rounds(total, 0u);
+    std::vector<psm_bvh*> lane_bvh(total);
+    for (uint32_t s = 0; s < total; s++) lane_bvh[s] = bvhs[s / split];
+    ShardedLanes L(rts, lane_bvh.data(), total, depth, state.data(), rounds.data());
+    struct Slot { LaneState state = IDLE; int frame = -1; };
+    std::vector<Slot> slots(lanes);
+    std::vector<int32_t> all(2 * (size_t)split), verdict(1);
+    std::vector<uint32_t> force(1);
+    int rc = PSM_OK;
+    auto start = [&](uint32_t q, uint32_t f) -> int {
+        psm_rt* r0 = rts[q * split];
+        psm_ctx* c0 = r0->ctx;
+        if (rebuild) {  // the slot's hierarchy, once, on part 0's stream; the other parts' streams wait for it
+            int e = psm_bvh_build(bvhs[q], opt);
+            if (e != PSM_OK) return e;
+        }
+        if (split > 1) {
+            PSM_HIP(c0, hipEventRecord(r0->ev_fold, c0->stream));
+            for (uint32_t k = 1; k < split; k++) PSM_HIP(c0, hipStreamWaitEvent(rts[q * split + k]->ctx->stream, r0->ev_fold, 0));
+        }
+        for (uint32_t k = 0; k < split; k++) L.begin(q * split + k, frame_seeds[f], cam_inv, proj_inv);
+        slots[q].state = RUNNING;
+        slots[q].frame = (int)f;
+        return L.rc;
+    };
+    uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
+    while (rc == PSM_OK && next_fold < frames) {
+        bool progressed = false;
+        for (uint32_t q = 0; q < lanes && rc == PSM_OK; q++) {
+            Slot& S = slots[q];
+            if (S.state == IDLE && next_frame < frames) {
+                rc = start(q, next_frame++);
+                progressed = true;
+            }
+            if (S.state != RUNNING || rc != PSM_OK) continue;
+            bool parked = true;
+            for (uint32_t k = 0; k < split; k++) {
+                const uint32_t s = q * split + k;
+                if (L.poll(s)) progressed = true;
+                parked = parked && L.st[s] == FINISHED;
+            }
+            rc = L.rc;
+            if (!parked || rc != PSM_OK) continue;
+            // every part stands parked: the stop rule on the frame's total (the parts are the "ranks" of psm_dist_decide)
+            for (uint32_t k = 0; k < split; k++) {
+                all[(size_t)k * 2 + 0] = (int32_t)rounds[q * split + k];
+                all[(size_t)k * 2 + 1] = (int32_t)rts[q * split + k]->ray_count;
+            }
+            rc = psm_dist_decide(split, 1u, all.data(), depth, verdict.data(), force.data());
+            if (rc != PSM_OK) break;
+            progressed = true;
+            if (verdict[0]) {
+                S.state = FINISHED;
+                if (results) {
+                    uint64_t rays = 0;
+                    for (uint32_t k = 0; k < split; k++) rays += L.traced[q * split + k];
+                    results[S.frame].rounds = rounds[q * split];
+                    results[S.frame].rays = rays;
+                }
+            } else {
+                for (uint32_t k = 0; k < split; k++) L.resume(q * split + k, force[0]);
+                rc = L.rc;
+            }
+        }
+        // sample() in frame order: the owner's texel arrays hold the whole frame once every part's stream has drained
+        for (bool again = true; again && rc == PSM_OK;) {
+            again = false;
+            for (uint32_t q = 0; q < lanes; q++) {
+                Slot& S = slots[q];
+                if (S.state != FINISHED || (uint32_t)S.frame != next_fold) continue;
+                psm_ctx* mc = fold_into->ctx;
+                for (uint32_t k = 1; k < split && rc == PSM_OK; k++) {  // parts 1.. -> the accumulating stream (part 0: inside fold())
+                    psm_rt* r = rts[q * split + k];
+                    if (hipEventRecord(r->ev_fold, r->ctx->stream) != hipSuccess || hipStreamWaitEvent(mc->stream, r->ev_fold, 0) != hipSuccess)
+                        rc = set_err(r->ctx, PSM_ERR_HIP, "psm_lanes_render_split: ordering a part before the fold");
+                }
+                if (rc == PSM_OK) rc = fold(fold_into, rts[q * split]);
+                for (uint32_t k = 1; k < split && rc == PSM_OK; k++) {  // the parts' next cameras wait for the fold (part 0 does already)
+                    psm_rt* r = rts[q * split + k];
+                    if (hipStreamWaitEvent(r->ctx->stream, rts[q * split]->ev_fold, 0) != hipSuccess)
+                        rc = set_err(r->ctx, PSM_ERR_HIP, "psm_lanes_render_split: ordering the fold before a part's next frame");
+                }
+                S.state = IDLE;
+                S.frame = -1;
+                next_fold++;
+                again = progressed = true;
+                break;
+            }
+        }
+        if (!progressed) {
+            if (++idle_spins > 256) std::this_thread::yield();
+        } else {
+            idle_spins = 0;
+        }
+    }
+    for (uint32_t s = 0; s < total; s++) {
+        (void)hipStreamSynchronize(rts[s]->ctx->stream);
+        rts[s]->in_flight = 1;
+    }
+    (void)hipStreamSynchronize(fold_into->ctx->stream);
     return rc;
 }

@@ -183,6 +183,8 @@ struct psm_rt {
     uint32_t tile_mode = 0, tile_rank = 0, tile_world = 1;  // 0: rows [y0,y1); 1: the 8-row bands `bands` deals to tile_rank
     psm::BandMap bands;           // mode 1: the dealing (psm_rt_set_tile_interleaved / _weighted)
     bool tile_root = true;        // this Pipeline samples the whole image: camera() also fills the texels it does not own
+    bool texels_shared = false;   // t_coord / t_sum / t_flag belong to another Pipeline (psm_rt_share_texels): not freed here
+    bool texels_lent = false;     // ... or are written by other Pipelines too: camera() leaves the texels it does not own alone
     uint32_t limit = 0;           // currentRayLimit
     int cur = 0;                  // current queue index
     uint32_t ray_count = 0;       // host mirror of the current queue length (valid after sync points)

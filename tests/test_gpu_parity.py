@@ -1042,6 +1042,39 @@ def test_frame_batch_lanes_equal_sequential_frames(psm, oracle, scenes):
     batch.close()
 
 
+@pytest.mark.parametrize("name,w,h,lanes,split,frames", [("cornell_open", 64, 48, 1, 4, 3), ("sponza_small", 160, 90, 1, 3, 3),
+                                                         ("sponza_small", 128, 72, 2, 2, 5), ("cornell_open", 64, 16, 1, 4, 2)])
+def test_frame_split_over_parts_equals_unsplit_frames(psm, oracle, scenes, name, w, h, lanes, split, frames):
+    """psm_lanes_render_split: every frame is traced by `split` Pipelines that own the frame's bands round-robin, share
+    the slot's hierarchy and one set of texel arrays and run their bounce rounds independently (one part's traversal
+    tail under the others' rounds), with the `fewer than 32 rays -> stop` rule applied to the frame's total. The image,
+    the rounds and the rays traced per frame equal psm_lanes_render's for the same seeds; one frame at a time
+    (lanes = 1) and two frames in flight; 64x16 = two bands on four parts (parts without a band)."""
+    scene = _scene(scenes, name)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+
+    def run(sp, ln):
+        b = psm.FrameBatch(ln, w, h, seed=41, split=sp)
+        b.allocate(scene["tris"].shape[0])
+        b.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+        b.applyMaterials(ms)
+        res = b.render(frames, scene["eye"], scene["view"])
+        img = b.snapHdr()
+        b.close()
+        return img, res
+    want, wres = run(1, lanes)
+    got, gres = run(split, lanes)
+    assert gres == wres, (gres, wres)                  # rounds and rays per frame
+    assert np.array_equal(got[..., 3], want[..., 3])
+    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+    assert want[..., :3].max() > 0.05
+    if name == "cornell_open" and h == 48:             # and against the oracle's frames
+        ref, _ = oracle.render_frames(scene, w, h, frames=frames, seed=41, frame_streams=True)
+        np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+
+
 def _three_lights(oracle):
     L = oracle.default_lights(3)
     L[1]["lightVector"] = (-0.5, 0.8, 0.6, 30.0)
