@@ -304,11 +304,11 @@ PSM_D Surf surface_eval(float4 hit, const SurfSrc& src) {
     return s;
 }
 
-// include/random.glsl:48-69
-PSM_D v3 randomCosine(Rng& g, v3 normal) {
-    float up = sqrtf(g.next());
+// include/random.glsl:48-69 (u0, u1: the two random() draws it takes, in that order)
+PSM_D v3 randomCosineU(float u0, float u1, v3 normal) {
+    float up = sqrtf(u0);
     float over = sqrtf(1.f - up * up);
-    float around = g.next() * TWO_PI_F;
+    float around = u1 * TWO_PI_F;
     v3 p0 = mk3(0, 0, 1);
     if (pabs(normal.x) < SQRT_OF_ONE_THIRD_F) p0 = mk3(1, 0, 0);
     else if (pabs(normal.y) < SQRT_OF_ONE_THIRD_F) p0 = mk3(0, 1, 0);
@@ -319,11 +319,16 @@ PSM_D v3 randomCosine(Rng& g, v3 normal) {
                fmaf(normal.z, up, fmaf(p1.z, ca, p2.z * sa)));
     return normalize3(v);
 }
-// include/random.glsl:71-76
-PSM_D v3 randomDirectionInSphere(Rng& g) {
-    float up = fmaf(g.next(), 2.0f, -1.0f);
+PSM_D v3 randomCosine(Rng& g, v3 normal) {
+    float u0 = g.next();
+    float u1 = g.next();
+    return randomCosineU(u0, u1, normal);
+}
+// include/random.glsl:71-76 (u0, u1: its two draws)
+PSM_D v3 randomDirectionInSphereU(float u0, float u1) {
+    float up = fmaf(u0, 2.0f, -1.0f);
     float over = sqrtf(1.f - up * up);
-    float around = g.next() * TWO_PI_F;
+    float around = u1 * TWO_PI_F;
     return normalize3(mk3(up, pcos(around) * over, psin(around) * over));
 }
 // shadinglib.glsl:22-26
@@ -549,68 +554,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
         float prom = 1.0f - c_albedo[3];
         float aprom = (type == 2) ? prom : ((g.next() < prom) ? 1.f : 0.f);
 
-        WRay diffuseRay = ray, reflectionRay = ray, emissiveRay = ray;
-        diffuseRay.fin = diffuseRay.fin * 0.0f;
-        reflectionRay.fin = reflectionRay.fin * 0.0f;
-        emissiveRay.fin = emissiveRay.fin * 0.0f;
-        if (!skipping) ray.fin = ray.fin * 0.f;
-
-        if (R_ACTIVE(ray.bf) > 0 && !skipping) {
-            ray.fin = ray.fin * 0.0f;
-            {  // diffuse(), shadinglib.glsl:106-119
-                WRay& r = diffuseRay;
-                r.color = r.color * mk3(c_albedo[0], c_albedo[1], c_albedo[2]);
-                r.direct = normalize3(randomCosine(g, normal));
-                r.origin = fma3(r.direct, GAP, r.origin);
-                S_ACTIVE(r.bf, R_TYPE(r.bf) == 2 ? 0 : R_ACTIVE(r.bf));
-                S_BOUNCE(r.bf, R_BOUNCE(r.bf) < 2 ? R_BOUNCE(r.bf) : 2);
-                S_TYPE(r.bf, 1);
-                S_DL(r.bf, 0);
-            }
-            {  // reflection(), shadinglib.glsl:139-148
-                WRay& r = reflectionRay;
-                v3 col = mk3(pclamp(sc.x / spca, 0.0f, 1.0f), pclamp(sc.y / spca, 0.0f, 1.0f), pclamp(sc.z / spca, 0.0f, 1.0f));
-                float dn = dot3(normal, r.direct);
-                v3 refl = mk3(r.direct.x - 2.0f * dn * normal.x, r.direct.y - 2.0f * dn * normal.y, r.direct.z - 2.0f * dn * normal.z);
-                v3 rc = randomCosine(g, normal);
-                float al = pclamp(refly * g.next(), 0.0f, 1.0f);
-                r.direct = normalize3(mk3(mixf(refl.x, rc.x, al), mixf(refl.y, rc.y, al), mixf(refl.z, rc.z, al)));
-                r.color = r.color * col;
-                r.origin = fma3(r.direct, GAP, r.origin);
-                S_DL(r.bf, (R_TYPE(r.bf) == 1) ? 0 : 1);
-                S_TYPE(r.bf, 0);
-                S_BOUNCE(r.bf, R_BOUNCE(r.bf) < 3 ? R_BOUNCE(r.bf) : 3);
-                S_ACTIVE(r.bf, R_TYPE(r.bf) == 2 ? 0 : R_ACTIVE(r.bf));
-            }
-            {  // emissive(), shadinglib.glsl:127-137
-                WRay& r = emissiveRay;
-                r.fin = mk3(pmax(r.color.x * c_emission[0], 0.0f), pmax(r.color.y * c_emission[1], 0.0f), pmax(r.color.z * c_emission[2], 0.0f));
-                if (R_TYPE(r.bf) == 1) r.fin = mk3(0.f, 0.f, 0.f);
-                else r.fin = mk3(pmax(r.fin.x, 0.0f), pmax(r.fin.y, 0.0f), pmax(r.fin.z, 0.0f));
-                r.color = r.color * 0.0f;
-                r.direct = normalize3(randomCosine(g, normal));
-                r.origin = fma3(r.direct, GAP, r.origin);
-                S_BOUNCE(r.bf, 0);
-                S_ACTIVE(r.bf, 0);
-                S_DL(r.bf, 0);
-            }
+        // From here on the reference builds three copies of the ray (diffuse, reflection, emissive) and a fourth (shadow) from
+        // the diffuse one, edits them in branches and merges them again (:195-275). A ray that is `skipping` emits none of
+        // them (:263), and `!skipping` implies an active ray (:159-161 above), so everything about the secondary rays lives
+        // in ONE region that only non-skipping rays enter, each ray built from the fields it actually changes -- same
+        // operations in the same order on the same values, bit for bit, without the per-field selects of the merges.
+        const bool go = !skipping;
+        const v3 hitp = ray.origin;       // the hit point, :155-156
+        const v3 incol = ray.color;       // the ray's colour after the light / background tests (unchanged for a `go` ray)
+        const int inbf = ray.bf;
+        if (go) {
+            ray.fin = ray.fin * 0.f;
+            ray.fin = ray.fin * 0.0f;     // :195 (two products in the reference: the sign of a zero survives them alike)
             // promised(), shadinglib.glsl:121-125
             S_BOUNCE(ray.bf, R_BOUNCE(ray.bf) + 1);
             ray.origin = fma3(ray.direct, GAP, ray.origin);
             ray.color = ray.color * aprom;
             ray.fin = ray.fin * aprom;
-        } else {
-            reflectionRay.color = reflectionRay.color * 0.0f;
-            emissiveRay.color = emissiveRay.color * 0.0f;
-            diffuseRay.color = diffuseRay.color * 0.0f;
-            diffuseRay.fin = diffuseRay.fin * 0.0f;
-        }
-        if (!skipping) {
-            float om = 1.0f - aprom;
-            diffuseRay.color = diffuseRay.color * om;
-            diffuseRay.fin = diffuseRay.fin * om;
-            reflectionRay.color = reflectionRay.color * om;
-            emissiveRay.fin = emissiveRay.fin * ((1.0f - aprom) * (1.0f - pclamp(spca, 0.0f, 1.0f)));
         }
         if (R_BASIS(ray.bf) == 1 && aprom < 0.1f) S_BASIS(ray.bf, 0);
 
@@ -630,45 +590,85 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
                 o.C = make_float4(ray.color.x, ray.color.y, ray.color.z, __uint_as_float(in_pkey));
             }
         }
-        // emit new rays, :263-275
-        if (!skipping) {
-            float coef = pclamp((g.next() < spca) ? 1.0f : 0.0f, 0.0f, 1.0f);
-            reflectionRay.color = reflectionRay.color * coef;
-            diffuseRay.color = diffuseRay.color * (1.0f - coef);
-            WRay shadowRay = diffuseRay;
-            {  // directLight(0, diffuseRay, 1, normal), shadinglib.glsl:75-93
-                WRay& r = shadowRay;
-                S_ACTIVE(r.bf, R_TYPE(r.bf) == 2 ? 0 : R_ACTIVE(r.bf));
-                S_DL(r.bf, 1);
-                S_TYPE(r.bf, 2);
-                S_TARGET(r.bf, 0);
-                S_BOUNCE(r.bf, R_BOUNCE(r.bf) < 1 ? R_BOUNCE(r.bf) : 1);
+        // the secondary rays, :195-210, :219-224, :263-275
+        if (go) {
+            const float om = 1.0f - aprom;
+            // the ten random() draws of the region in the reference's order -- diffuse (#2, #3), reflection (#4, #5, #6),
+            // emissive (#7, #8: its direction is drawn and never used, the ray is born inactive and only deposits `final`),
+            // the lobe (#9), the shadow ray (#10, #11) -- taken first, so that each ray can be finished (and its registers
+            // released into its output slot) before the next one is begun
+            const float u2 = g.next(), u3 = g.next(), u4 = g.next(), u5 = g.next(), u6 = g.next();
+            (void)g.next();
+            (void)g.next();
+            const float coef = pclamp((g.next() < spca) ? 1.0f : 0.0f, 0.0f, 1.0f);   // :267
+            const float u10 = g.next(), u11 = g.next();
+
+            // ---- diffuse ray: diffuse(), shadinglib.glsl:106-119
+            WRay dr;
+            dr.color = incol * mk3(c_albedo[0], c_albedo[1], c_albedo[2]);
+            dr.color = dr.color * om;                       // :219
+            dr.color = dr.color * (1.0f - coef);            // :268
+            dr.direct = normalize3(randomCosineU(u2, u3, normal));
+            dr.origin = fma3(dr.direct, GAP, hitp);
+            dr.fin = mk3(0.f, 0.f, 0.f);
+            dr.bf = inbf;
+            S_ACTIVE(dr.bf, R_TYPE(dr.bf) == 2 ? 0 : R_ACTIVE(dr.bf));
+            S_BOUNCE(dr.bf, R_BOUNCE(dr.bf) < 2 ? R_BOUNCE(dr.bf) : 2);
+            S_TYPE(dr.bf, 1);
+            S_DL(dr.bf, 0);
+            // ---- shadow ray = directLight(0, diffuseRay, 1, normal), shadinglib.glsl:75-93, then applyLight :181-189
+            {
+                WRay sr = dr;
+                S_ACTIVE(sr.bf, R_TYPE(sr.bf) == 2 ? 0 : R_ACTIVE(sr.bf));
+                S_DL(sr.bf, 1);
+                S_TYPE(sr.bf, 2);
+                S_TARGET(sr.bf, 0);
+                S_BOUNCE(sr.bf, R_BOUNCE(sr.bf) < 1 ? R_BOUNCE(sr.bf) : 1);
                 v3 ctr = lightCenter(a.lights[0]);
-                v3 sd = randomDirectionInSphere(g);
+                v3 sd = randomDirectionInSphereU(u10, u11);
                 v3 sl = fma3(sd, a.lights[0].lightColor[3] - 0.0001f, ctr);
-                v3 ldirect = normalize3(sl - r.origin);
-                float dist = len3(ctr - r.origin);
+                v3 ldirect = normalize3(sl - sr.origin);
+                float dist = len3(ctr - sr.origin);
                 float q = a.lights[0].lightColor[3] / dist;
                 float weight = 1.0f - sqrtf(1.0f - pclamp(dot3(ldirect, normal) * 2.f * (q * q), 0.f, 1.f));
-                r.origin = fma3(r.direct, -GAP, r.origin);
-                r.direct = ldirect;
-                r.color = r.color * (1.0f * weight);
-                r.fin = r.fin * 0.f;
-                r.origin = fma3(r.direct, GAP, r.origin);
+                sr.origin = fma3(sr.direct, -GAP, sr.origin);
+                sr.direct = ldirect;
+                sr.color = sr.color * (1.0f * weight);
+                sr.origin = fma3(sr.direct, GAP, sr.origin);
+                bool off = (R_TYPE(dr.bf) == 2) || (dot3(c_normal, sr.direct) < 0.f);
+                S_ACTIVE(sr.bf, off ? 0 : R_ACTIVE(sr.bf));
+                have[3] = create_ray(sr, in_texel, child_key(in_pkey, 3u), outs[3], a.t_sum, a.t_flag);
             }
-            have[1] = create_ray(diffuseRay, in_texel, child_key(in_pkey, 1u), outs[1], a.t_sum, a.t_flag);
-            have[2] = create_ray(reflectionRay, in_texel, child_key(in_pkey, 2u), outs[2], a.t_sum, a.t_flag);
+            have[1] = create_ray(dr, in_texel, child_key(in_pkey, 1u), outs[1], a.t_sum, a.t_flag);
+            // ---- reflection ray: reflection(), shadinglib.glsl:139-148
             {
-                float ce = pclamp(emis, 0.0f, 1.0f);
-                emissiveRay.color = emissiveRay.color * ce;
-                emissiveRay.fin = emissiveRay.fin * ce;
-                OutRay dummy;
-                (void)create_ray(emissiveRay, in_texel, child_key(in_pkey, 4u), dummy, a.t_sum, a.t_flag);  // never active
+                WRay rr;
+                float dn = dot3(normal, ray.direct);
+                v3 refl = mk3(ray.direct.x - 2.0f * dn * normal.x, ray.direct.y - 2.0f * dn * normal.y, ray.direct.z - 2.0f * dn * normal.z);
+                v3 rc = randomCosineU(u4, u5, normal);
+                float al = pclamp(refly * u6, 0.0f, 1.0f);
+                rr.direct = normalize3(mk3(mixf(refl.x, rc.x, al), mixf(refl.y, rc.y, al), mixf(refl.z, rc.z, al)));
+                v3 col = mk3(pclamp(sc.x / spca, 0.0f, 1.0f), pclamp(sc.y / spca, 0.0f, 1.0f), pclamp(sc.z / spca, 0.0f, 1.0f));
+                rr.color = incol * col;
+                rr.color = rr.color * om;                   // :220
+                rr.color = rr.color * coef;                 // :267
+                rr.origin = fma3(rr.direct, GAP, hitp);
+                rr.fin = mk3(0.f, 0.f, 0.f);
+                rr.bf = inbf;
+                S_DL(rr.bf, (R_TYPE(rr.bf) == 1) ? 0 : 1);
+                S_TYPE(rr.bf, 0);
+                S_BOUNCE(rr.bf, R_BOUNCE(rr.bf) < 3 ? R_BOUNCE(rr.bf) : 3);
+                S_ACTIVE(rr.bf, R_TYPE(rr.bf) == 2 ? 0 : R_ACTIVE(rr.bf));
+                have[2] = create_ray(rr, in_texel, child_key(in_pkey, 2u), outs[2], a.t_sum, a.t_flag);
             }
-            {  // applyLight, shadinglib.glsl:181-189
-                bool off = (R_TYPE(diffuseRay.bf) == 2) || (dot3(c_normal, shadowRay.direct) < 0.f);
-                S_ACTIVE(shadowRay.bf, off ? 0 : R_ACTIVE(shadowRay.bf));
-                have[3] = create_ray(shadowRay, in_texel, child_key(in_pkey, 3u), outs[3], a.t_sum, a.t_flag);
+            // ---- emissive: only its deposit (createRay of an inactive ray, rayslib.glsl:162-203)
+            {
+                v3 ef = mk3(pmax(incol.x * c_emission[0], 0.0f), pmax(incol.y * c_emission[1], 0.0f), pmax(incol.z * c_emission[2], 0.0f));
+                if (R_TYPE(inbf) == 1) ef = mk3(0.f, 0.f, 0.f);
+                else ef = mk3(pmax(ef.x, 0.0f), pmax(ef.y, 0.0f), pmax(ef.z, 0.0f));
+                ef = ef * ((1.0f - aprom) * (1.0f - pclamp(spca, 0.0f, 1.0f)));   // :222-223
+                ef = ef * pclamp(emis, 0.0f, 1.0f);                               // :271
+                if (mlength3(ef) >= 0.0001f) deposit(ef, in_texel, a.t_sum, a.t_flag);
             }
         }
     }
