@@ -78,7 +78,8 @@ def parse():
     ap.add_argument("--diag-clock", action="store_true",
                     help="diagnosis only: a second pass of the timed region with the counting kernels on every lane; reports "
                          "the shader clock the traversal waves ran at (s_memtime / s_memrealtime) and their wave-steps to stderr")
-    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive"],
+    ap.add_argument("--trav-refill", default="", help="refill: refill_min,waves_per_cu,min_rays")
+    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive", "refill"],
                     help="tuning study: traversal kernel schedule (psm_rt_set_traverse_mode); results never depend on it")
     ap.add_argument("--trav-caps", default="96", help="phased: wave-step caps, comma separated")
     ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
@@ -133,8 +134,10 @@ class Renderer:
             self.ms.setTextureSet(ts)
         for b in self.batches:
             b.applyMaterials(self.ms)
-        if args.traverse != "auto" or args.trav_adaptive:
+        if args.traverse != "auto" or args.trav_adaptive or args.trav_refill:
             def tune(r):
+                if args.trav_refill:
+                    r.setTraverseRefill(*[int(v) for v in args.trav_refill.split(",")])
                 if args.trav_adaptive:
                     r.setTraverseAdaptive(*[int(v) for v in args.trav_adaptive.split(",")])
                 if args.traverse == "phased":
@@ -661,7 +664,9 @@ def main():
         min_rays = 1 << 19
         if args.trav_adaptive and len(args.trav_adaptive.split(",")) >= 5:
             min_rays = int(args.trav_adaptive.split(",")[4])
-        hand = args.traverse in ("phased", "adaptive") or (args.traverse == "auto" and R.lanes * args.split > 1)
+        if args.traverse == "refill":
+            min_rays = int(args.trav_refill.split(",")[2]) if len(args.trav_refill.split(",")) >= 3 else 1 << 15
+        hand = args.traverse in ("phased", "adaptive", "refill") or (args.traverse == "auto" and R.lanes * args.split > 1)
         # (a frame split over several Pipelines: every part traces about 1 / split of a round's rays)
         ho_rounds = [r for r in round_log if hand and r[0] / args.split >= min_rays]
         wh_rounds = [r for r in round_log if not (hand and r[0] / args.split >= min_rays)]
@@ -675,7 +680,7 @@ def main():
                "step against %.3f timed" % (R.lanes, ev_elapsed / args.steps * 1e3, ms_step))
         sums = lambda rs: (sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs))
         if ho_rounds:
-            timed_k = price("rt_traverse<false, false, true>", ho_launches, ho_ms, *sums(ho_rounds), len(ho_rounds), args.steps,
+            timed_k = price("rt_traverse_refill<false>" if args.traverse == "refill" else "rt_traverse<false, false, true>", ho_launches, ho_ms, *sums(ho_rounds), len(ho_rounds), args.steps,
                             args.scene, args.width, args.height, how)
             if wh_launches:
                 timed_k["rounds_below_min_rays_run_single_launch"] = price(

@@ -253,8 +253,15 @@ int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
  *               kernels fill the tails the extra launches add; +5 % on C3, +9 % on C5's scene), WHOLE for a frame on its own (it is bound
  *               by its longest ray, which extra launches serialise) and for intersections under min_rays rays.
  *               Further hierarchies of a multi-BVH queue always run WHOLE. */
-enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3 };
+enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3, PSM_TRAVERSE_REFILL = 4 };
 int psm_rt_set_traverse_mode(psm_rt* rt, int mode);
+/* REFILL (round 3): one launch of persistent waves over the round's rays as a pool behind one atomic counter. A lane whose
+ * ray has ended keeps its result in registers until at least refill_min lanes of its wave are idle (or nobody has work
+ * left); then the idle lanes write their results, the wave takes that many new rays with ONE atomic and the idle lanes
+ * run the ray set-up together -- so set-up and result writes run with a good part of the wave, the node steps with at
+ * least 64 - refill_min + 1 lanes with work until the pool is dry, and nothing is handed over through memory.
+ * waves_per_cu (even, 2..32): size of the persistent grid; intersections under min_rays rays run WHOLE. */
+int psm_rt_set_traverse_refill(psm_rt* rt, uint32_t refill_min, uint32_t waves_per_cu, uint32_t min_rays);
 /* PHASED: count caps (1..7) -> count + 1 launches, for intersections over at least min_rays rays; count = 0 selects
  * WHOLE. Selects PSM_TRAVERSE_PHASED. */
 int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count, uint32_t min_rays);

@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_render_split", "psm_rt_share_texels", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_refill", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_render_split", "psm_rt_share_texels", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -38,8 +38,9 @@ EXPORTS = [
     "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile", "psm_dist_set_band_weights",
 ]
 
-TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)
-TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE}
+TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE, TRAVERSE_REFILL = range(5)
+TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE,
+                  "refill": TRAVERSE_REFILL}
 
 (BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
  BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS, BVH_TEXCOORDS) = range(12)
@@ -565,6 +566,11 @@ class Pipeline:
         self.ctx.check(lib().psm_rt_set_traverse_adaptive(self._h, C.c_uint32(min_live), C.c_uint32(min_steps),
                                                           C.c_uint32(final_rays), C.c_uint32(max_launches),
                                                           C.c_uint32(min_rays)), "psm_rt_set_traverse_adaptive")
+
+    def setTraverseRefill(self, refill_min=32, waves_per_cu=28, min_rays=1 << 15):
+        """psm_rt_set_traverse_refill: parameters of the "refill" schedule (does not select it)."""
+        self.ctx.check(lib().psm_rt_set_traverse_refill(self._h, C.c_uint32(refill_min), C.c_uint32(waves_per_cu),
+                                                        C.c_uint32(min_rays)), "psm_rt_set_traverse_refill")
 
     def resetHits(self):
         """Forget the hit chains of the current queue (ray.hit = -1): the next intersection() starts afresh."""

@@ -859,7 +859,7 @@ int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
 }
 
 int psm_rt_set_traverse_mode(psm_rt* r, int mode) {
-    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_ADAPTIVE) return PSM_ERR_INVALID;
+    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_REFILL) return PSM_ERR_INVALID;
     r->trav_mode = mode;
     return PSM_OK;
 }
@@ -883,6 +883,14 @@ int psm_rt_set_traverse_adaptive(psm_rt* r, uint32_t min_live, uint32_t min_step
     r->adapt_final_rays = final_rays;
     r->adapt_max_launches = max_launches;
     r->phase_min_rays = min_rays;
+    return PSM_OK;
+}
+
+int psm_rt_set_traverse_refill(psm_rt* r, uint32_t refill_min, uint32_t waves_per_cu, uint32_t min_rays) {
+    if (!r || refill_min < 1 || refill_min > 64 || waves_per_cu < 2 || waves_per_cu > 32 || (waves_per_cu & 1u)) return PSM_ERR_INVALID;
+    r->refill_min = refill_min;
+    r->refill_waves_per_cu = waves_per_cu;
+    r->refill_min_rays = min_rays;
     return PSM_OK;
 }
 

@@ -446,6 +446,10 @@ TRAVERSE_SCHEDULES = [
     ("adaptive", {"min_live": 64, "min_steps": 0, "final_rays": 0, "max_launches": 15}),   # hand over at the first idle lane
     ("adaptive", {"min_live": 2, "min_steps": 1, "final_rays": 0, "max_launches": 3}),
     ("adaptive", {"min_live": 24, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
+    ("refill", {"refill_min": 16, "waves_per_cu": 32}),
+    ("refill", {"refill_min": 1, "waves_per_cu": 2}),     # every idle lane refills at once; a small persistent grid
+    ("refill", {"refill_min": 64, "waves_per_cu": 8}),    # a wave refills only when all its lanes are idle
+    ("refill", {"refill_min": 33, "waves_per_cu": 4}),
 ]
 
 
@@ -454,6 +458,8 @@ def _select_schedule(rt, mode, kw):
         rt.setTraversePhases(kw["caps"], min_rays=0)
     elif mode == "adaptive":
         rt.setTraverseAdaptive(min_rays=0, **kw)
+    elif mode == "refill":
+        rt.setTraverseRefill(min_rays=0, **kw)
     rt.setTraverseMode(mode)
 
 
@@ -485,8 +491,9 @@ def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, k
     th.close()
 
 
-@pytest.mark.parametrize("mode,kw", [("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 64, "max_launches": 8}),
-                                     ("phased", {"caps": [5, 9]})], ids=["adaptive", "phased"])
+@pytest.mark.parametrize("mode,kw", [("refill", {"refill_min": 16, "waves_per_cu": 4}), ("refill", {"refill_min": 3, "waves_per_cu": 32}),
+                                     ("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 64, "max_launches": 8}),
+                                     ("phased", {"caps": [5, 9]})], ids=["refill-16", "refill-3", "adaptive", "phased"])
 def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes, mode, kw):
     """Rays that carry an equal-distance chain of two or more hits cannot hand over (their chain lives in registers):
     they finish in the launch they are in. Duplicated coplanar triangles make thousands of them."""
