@@ -91,6 +91,15 @@ namespace NSM {
             for (size_t s = 0; s < n; s++) rays[s]->noteTraced(objs[s]);
         }
 
+        // The tile of a sharded frame every lane traces: the 8-row bands dealt to `world` ranks -- round-robin, or weights[r]
+        // bands of every period for rank r (psm_rt_set_tile_weighted: the gathering rank also unpacks, fills and samples the
+        // whole image, so bench.py gives it fewer bands) -- and the same dealing on the communicator whose gathers carry it.
+        void setTile(psm_dist * dist, uint32_t rank, uint32_t world, const std::vector<uint32_t> & weights = {}) {
+            const uint32_t * w = weights.empty() ? nullptr : weights.data();
+            for (auto p : rays) check(psm_rt_set_tile_weighted(p->handle(), rank, world, w), "FrameBatch::setTile");
+            if (dist) check(psm_dist_set_band_weights(dist, w), "FrameBatch::setTile (communicator)");
+        }
+
         // The same frames tile-sharded over the GPUs of a node (one process per GPU; psm_dist_init has built `dist` and
         // every lane carries psm_rt_set_tile_interleaved(rank, world)): psm_dist_render_frames over all the frames -- the
         // path's one collective per frame is the tile gather to rank 0, whose accumulator() holds the image. Every rank
