@@ -194,26 +194,26 @@ __global__ __launch_bounds__(256) void radix_onesweep(const uint64_t* __restrict
 // ---- the three-kernel pass (default, psm_sort_set_algorithm(ctx, 0)): per pass a per-tile histogram, a scan of the
 // tile counts per digit, and the scatter ----
 
-template <int ITEMS>
-__global__ __launch_bounds__(256) void radix_hist(const uint64_t* __restrict__ keys, uint32_t* __restrict__ ghist,
-                                                  uint32_t numTiles, uint32_t n_max,
-                                                  const uint32_t* __restrict__ d_n, int shift) {
-    constexpr uint32_t TILE = 256 * ITEMS;
+template <int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_hist(const uint64_t* __restrict__ keys, uint32_t* __restrict__ ghist,
+                                                      uint32_t numTiles, uint32_t n_max,
+                                                      const uint32_t* __restrict__ d_n, int shift) {
+    constexpr uint32_t TILE = THREADS * ITEMS;
     __shared__ uint32_t h[256];
     uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     uint32_t tile = blockIdx.x, tid = threadIdx.x;
     uint32_t base = tile * TILE;
-    h[tid] = 0;
+    if (tid < 256) h[tid] = 0;
     __syncthreads();
     if (base < n) {
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            uint32_t idx = base + i * 256 + tid;
+            uint32_t idx = base + i * THREADS + tid;
             if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
         }
     }
     __syncthreads();
-    ghist[tid * numTiles + tile] = h[tid];
+    if (tid < 256) ghist[tid * numTiles + tile] = h[tid];
 }
 
 // One workgroup per digit: exclusive scan of that digit's row of per-tile counts in place
@@ -236,19 +236,20 @@ __global__ __launch_bounds__(256) void radix_scan(uint32_t* __restrict__ g, uint
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <int ITEMS>
-__global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                     uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                     const uint32_t* __restrict__ gscan,
-                                                     const uint32_t* __restrict__ totals, uint32_t numTiles,
-                                                     uint32_t n_max, const uint32_t* __restrict__ d_n, int shift) {
-    constexpr uint32_t TILE = 256 * ITEMS;
+template <int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                         uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                         const uint32_t* __restrict__ gscan,
+                                                         const uint32_t* __restrict__ totals, uint32_t numTiles,
+                                                         uint32_t n_max, const uint32_t* __restrict__ d_n, int shift) {
+    constexpr uint32_t TILE = THREADS * ITEMS;
+    constexpr int NW = THREADS / 64;
     __shared__ uint64_t sk[TILE];
     __shared__ uint32_t sv[TILE];
-    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t wcount[NW][256];
     __shared__ uint32_t tstart[256];
     __shared__ uint32_t gbase[256];
-    __shared__ uint32_t tmp[8];
+    __shared__ uint32_t tmp[THREADS / 64 + 1];
     uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     uint32_t tile = blockIdx.x, tid = threadIdx.x;
     uint32_t base = tile * TILE;
@@ -256,8 +257,7 @@ __global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict_
     uint32_t w = tid >> 6;
     int l = lane_id();
     uint64_t lt = lanemask_lt();
-#pragma unroll
-    for (int q = 0; q < 4; q++) wcount[q][tid] = 0;
+    for (uint32_t q = tid; q < NW * 256u; q += THREADS) (&wcount[0][0])[q] = 0;
     __syncthreads();
 
     uint64_t k[ITEMS];
@@ -289,18 +289,22 @@ __global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict_
         r[i] = old + before;
     }
     __syncthreads();
-    {
+    {   // thread tid < 256 owns digit tid (the other threads of a wider workgroup only take part in the scans)
         uint32_t run = 0;
+        if (tid < 256) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t t = wcount[q][tid];
-            wcount[q][tid] = run;
-            run += t;
+            for (int q = 0; q < NW; q++) {
+                uint32_t t = wcount[q][tid];
+                wcount[q][tid] = run;
+                run += t;
+            }
         }
-        uint32_t ts = block_scan_excl<256>(run, tmp, nullptr);
-        tstart[tid] = ts;
-        uint32_t dbase = block_scan_excl<256>(totals[tid], tmp, nullptr);  // keys with a smaller digit
-        gbase[tid] = dbase + gscan[tid * numTiles + tile];
+        uint32_t ts = block_scan_excl<THREADS>(run, tmp, nullptr);
+        uint32_t dbase = block_scan_excl<THREADS>(tid < 256 ? totals[tid] : 0u, tmp, nullptr);  // keys with a smaller digit
+        if (tid < 256) {
+            tstart[tid] = ts;
+            gbase[tid] = dbase + gscan[tid * numTiles + tile];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void radix_scatter(const uint64_t* __restrict_
     uint32_t tileN = min(TILE, n - base);
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        uint32_t j = i * 256 + tid;
+        uint32_t j = i * THREADS + tid;
         if (j < tileN) {
             uint64_t key = sk[j];
             uint32_t d = (uint32_t)(key >> shift) & 255u;
@@ -350,9 +354,18 @@ static int sort_buffers(psm_ctx* c, size_t n_max, size_t E) {
     return PSM_OK;
 }
 
-static bool sort_uses_passes(const psm_ctx* c, size_t n_max) { return c->sort_algorithm == 0 || n_max >= (1u << 30); }
+static bool sort_uses_passes(const psm_ctx* c, size_t n_max) { return c->sort_algorithm != 1 || n_max >= (1u << 30); }
+// keys per tile of the three-kernel pass, measured on MI355X (round 3, tools/sort_bench.py, profiles/r03_sort_bench.txt):
+// the wider the workgroup over a tile the better -- 1024 threads x 4 keys against round 2's 256 x 16 over the same 4096
+// keys: 0.79 against 0.88 ms at 10 M keys (16 waves per CU hide the scatter's latency where 54 KB of LDS per tile allowed
+// 8), 0.21 against 0.32 ms at 2 M (which ran 256 x 4); small sorts are launch-bound and want enough tiles to fill the chip
+static uint32_t pass_tile(size_t n_max) {
+    if (n_max <= (1u << 17)) return 1024u;   // 256 threads x 4 keys
+    if (n_max <= (1u << 19)) return 2048u;   // 1024 threads x 2 (C3: 262 267 keys, 0.113 against 0.122 ms)
+    return 4096u;                            // 1024 threads x 4
+}
 static size_t sort_words(const psm_ctx* c, size_t n_max) {
-    uint32_t tile = 256u * (n_max <= (1u << 21) ? 4u : 16u);
+    uint32_t tile = sort_uses_passes(c, n_max) ? pass_tile(n_max) : 256u * (n_max <= (1u << 21) ? 4u : 16u);
     size_t numTiles = (n_max + tile - 1) / tile;
     return sort_uses_passes(c, n_max) ? (size_t)256 * numTiles + 256 : (size_t)CB_WORDS + (size_t)8 * numTiles * 256;
 }
@@ -365,9 +378,9 @@ int sort_reserve(psm_ctx* c, size_t n_max) {
     return sort_buffers(c, n_max, sort_words(c, n_max));
 }
 
-template <int ITEMS>
+template <int ITEMS, int THREADS>
 static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n) {
-    constexpr uint32_t TILE = 256 * ITEMS;
+    constexpr uint32_t TILE = THREADS * ITEMS;
     uint32_t numTiles = (uint32_t)((n_max + TILE - 1) / TILE);
     size_t E = (size_t)256 * numTiles + 256;  // per-tile counts + 256 digit totals
     { int rc = sort_buffers(c, n_max, E); if (rc != PSM_OK) return rc; }
@@ -375,10 +388,10 @@ static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
     uint64_t* kout = c->sort_keys_tmp; uint32_t* vout = c->sort_vals_tmp;
     for (int pass = 0; pass < 8; pass++) {  // Radix.hpp:57: 64-bit keys, 8 passes
         int shift = pass * 8;
-        radix_hist<ITEMS><<<numTiles, 256, 0, c->stream>>>(kin, c->sort_hist, numTiles, (uint32_t)n_max, d_n, shift);
+        radix_hist<ITEMS, THREADS><<<numTiles, THREADS, 0, c->stream>>>(kin, c->sort_hist, numTiles, (uint32_t)n_max, d_n, shift);
         uint32_t* totals = c->sort_hist + (size_t)256 * numTiles;
         radix_scan<<<256, 256, 0, c->stream>>>(c->sort_hist, numTiles, totals);
-        radix_scatter<ITEMS><<<numTiles, 256, 0, c->stream>>>(kin, vin, kout, vout, c->sort_hist, totals, numTiles,
+        radix_scatter<ITEMS, THREADS><<<numTiles, THREADS, 0, c->stream>>>(kin, vin, kout, vout, c->sort_hist, totals, numTiles,
                                                               (uint32_t)n_max, d_n, shift);
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
@@ -420,8 +433,9 @@ int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, co
     TimedScope ts(c, CAT_SORT);
     if (sort_uses_passes(c, n_max)) {  // (the one-sweep status words hold 30-bit counts)
         c->sort_error_word = nullptr;  // no look-back, nothing to time out (and the buffer it pointed into is reused)
-        if (n_max <= (1u << 21)) return sort_passes<4>(c, d_keys, d_vals, n_max, d_n);
-        return sort_passes<16>(c, d_keys, d_vals, n_max, d_n);
+        if (n_max <= (1u << 17)) return sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n);
+        if (n_max <= (1u << 19)) return sort_passes<2, 1024>(c, d_keys, d_vals, n_max, d_n);
+        return sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n);
     }
     if (n_max <= (1u << 21)) return sort_onesweep<4>(c, d_keys, d_vals, n_max, d_n);
     return sort_onesweep<16>(c, d_keys, d_vals, n_max, d_n);

@@ -35,7 +35,7 @@ def _scene(scenes, name):
 
 # ---------------------------------------------------------------------------- sort
 @pytest.mark.parametrize("algo", [0, 1], ids=["three-kernel", "onesweep"])
-@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 1024, 1025, 4097, 100003, 2 ** 21 + 77])
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 1024, 1025, 4097, 100003, 2 ** 17 + 1, 300007, 2 ** 19 + 3, 2 ** 21 + 77])
 def test_sort_matches_oracle(psm, ctx, oracle, n, algo):
     """Both sort implementations (psm_sort_set_algorithm): one histogram sweep + look-back scatter, and the
     histogram / scan / scatter kernels per pass."""
