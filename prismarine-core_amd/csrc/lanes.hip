@@ -29,7 +29,8 @@ static inline uint32_t lcg_next(uint32_t& state) {  // the CRT rand() stand-in o
 
 static int lane_resources(psm_rt* r) {
     psm_ctx* c = r->ctx;
-    if (!r->h_cnt) PSM_HIP(c, hipHostMalloc((void**)&r->h_cnt, sizeof(uint32_t), hipHostMallocDefault));
+    // (coherent: rt_scan_blocks writes the next ray count into it from the device, the host reads it after the event)
+    if (!r->h_cnt) PSM_HIP(c, hipHostMalloc((void**)&r->h_cnt, sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
     if (!r->ev_cnt) PSM_HIP(c, hipEventCreateWithFlags(&r->ev_cnt, hipEventDisableTiming));
     if (!r->ev_fold) PSM_HIP(c, hipEventCreateWithFlags(&r->ev_fold, hipEventDisableTiming));
     return PSM_OK;
@@ -107,7 +108,6 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         e = psm_rt_shade(r, ln.bvh, lcg_next(ln.rand));
         if (e != PSM_OK) return e;
         ln.round++;
-        PSM_HIP(r->ctx, hipMemcpyAsync(r->h_cnt, r->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, r->ctx->stream));
         PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
         return PSM_OK;
     };
@@ -244,7 +244,6 @@ struct ShardedLanes {
         if (e != PSM_OK) return e;
         e = psm_rt_shade(r, bvhs[s], t);
         if (e != PSM_OK) return e;
-        PSM_HIP(r->ctx, hipMemcpyAsync(r->h_cnt, r->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, r->ctx->stream));
         PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
         st[s] = RUNNING;
         return PSM_OK;

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
 // bases of the next queue (exclusive scan of the workgroups' output counts; bases[nb] = total)
 __global__ __launch_bounds__(1024) void rt_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t limit,
                                                        uint32_t* __restrict__ bases, uint32_t* __restrict__ cnt,
-                                                       DevCounters* __restrict__ ctr) {
+                                                       DevCounters* __restrict__ ctr, uint32_t* __restrict__ host_cnt) {
     __shared__ uint32_t tmp[32];
     uint32_t tid = threadIdx.x;
     uint32_t chunk = (nb + 1023u) / 1024u;
@@ -713,6 +713,9 @@ __global__ __launch_bounds__(1024) void rt_scan_blocks(const uint32_t* __restric
         cnt[1] = next;
         cnt[0] = next;
         cnt[2] = 0;  // chain pool cursor
+        // the count the host's scheduler waits for (frames in flight), straight into its pinned slot: no copy launch
+        // between this kernel and the event the host polls
+        if (host_cnt) *(volatile uint32_t*)host_cnt = next;
     }
 }
 
@@ -909,7 +912,7 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
         else if (any_tex) rt_shade<true, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         else if (multi) rt_shade<false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         else rt_shade<false, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->q_bases[nxt], r->d_cnt, c->d_counters);
+        rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->q_bases[nxt], r->d_cnt, c->d_counters, r->h_cnt);
     }
     r->q_nb[nxt] = nb;
     PSM_HIP(c, hipGetLastError());
