@@ -95,7 +95,8 @@ class Renderer:
         self.native = None
         # the C ABI's own RCCL communicator carries the collectives unless PSM_DIST_NATIVE=0 (or the one-GPU rehearsal of
         # another rank's tile, whose tile is not this rank's)
-        use_native = dist.active and dist.backend == "nccl" and os.environ.get("PSM_DIST_NATIVE", "1") != "0"
+        self.hoststaged = os.environ.get("PSM_DIST_TRANSPORT", "rccl") == "hoststaged"   # rehearsal on a shared GPU, asked for explicitly
+        use_native = dist.active and (dist.backend == "nccl" or self.hoststaged) and os.environ.get("PSM_DIST_NATIVE", "1") != "0"
         if dist.active and dist.backend == "nccl" and not use_native:
             # torch.distributed collectives: run the kernels on torch's stream, so RCCL calls and kernels are ordered
             # without host syncs. (Default: the C ABI's own communicator, psm_dist_*, ordered by events.)
@@ -164,7 +165,8 @@ class Renderer:
             dist.initial_total = self.rt.tile_texels()
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if use_native:
-            self.native = dist.attach_native(self.ctx)  # collective: every rank creates its RCCL communicator here
+            self.native = dist.attach_native(  # collective: every rank creates its communicator here (RCCL unless a rehearsal asked otherwise)
+                self.ctx, self.pdist.largest_tile_texels(dist.world, w, h, self.weights) * 16)
             if args.emulate_tile and dist.world == 1:
                 self.native.emulate_tile(r_, w_)
             self.native.set_band_weights(self.weights)
@@ -386,7 +388,7 @@ def pmc_entry(scene, width, height, kernel):
     return None, None
 
 
-def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, height, how):
+def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, height, how, use_pmc=True):
     """One traversal kernel priced over `launches` launches that took `total_ms` (HIP events on the launching streams) and
     traced R rays with V node visits and T triangle tests in `rounds` intersections."""
     launches = max(int(launches), 1)
@@ -398,7 +400,8 @@ def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, heig
            "achieved": alg / sec / 1e9 if sec > 0 else 0.0, "algorithmic_bytes_per_launch": alg / launches,
            "own_record_bytes_per_launch": own / launches, "own_record_gbs": own / sec / 1e9 if sec > 0 else 0.0,
            "node_visits_per_s": V / sec if sec > 0 else None, "R": int(R), "V": int(V), "T": int(T)}
-    e, src = pmc_entry(scene, width, height, kernel)
+    # the committed counter passes are of whole frames on one GPU: a tile's launches are smaller, their traffic is not these
+    e, src = pmc_entry(scene, width, height, kernel) if use_pmc else (None, None)
     if e is not None and sec > 0:
         traffic = e.get("traffic_bytes_per_launch")
         out["traffic"] = traffic
@@ -679,19 +682,20 @@ def main():
                "(%d frame(s) in flight: a launch shares the chip with the other frames' kernels); that pass ran at %.3f ms per "
                "step against %.3f timed" % (R.lanes, ev_elapsed / args.steps * 1e3, ms_step))
         sums = lambda rs: (sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs))
+        whole_frame = not dist.active and not args.emulate_tile and args.split == 1
         if ho_rounds:
             timed_k = price("rt_traverse_refill<false>" if args.traverse == "refill" else "rt_traverse<false, false, true>", ho_launches, ho_ms, *sums(ho_rounds), len(ho_rounds), args.steps,
-                            args.scene, args.width, args.height, how)
+                            args.scene, args.width, args.height, how, whole_frame)
             if wh_launches:
                 timed_k["rounds_below_min_rays_run_single_launch"] = price(
                     "rt_traverse<false, false, false>", wh_launches, wh_ms, *sums(wh_rounds), len(wh_rounds), args.steps,
-                    args.scene, args.width, args.height, how)
+                    args.scene, args.width, args.height, how, whole_frame)
         else:
             timed_k = price("rt_traverse<false, false, false>", wh_launches, wh_ms, *sums(wh_rounds), len(wh_rounds), args.steps,
-                            args.scene, args.width, args.height, how)
+                            args.scene, args.width, args.height, how, whole_frame)
         whole_k = price("rt_traverse<false, false, false>", st.traverse_launches, st.traverse_ms, Rr, V, T, len(round_log), args.steps,
                         args.scene, args.width, args.height,
-                        "serial kernel pass: the same frames one after another on one stream, every launch alone on the chip")
+                        "serial kernel pass: the same frames one after another on one stream, every launch alone on the chip", whole_frame)
         # launches of different frames overlap: their summed durations exceed the wall time; the union of their intervals is
         # the time during which traversal is on the chip at all, and the ratio is how many run side by side on average
         timed_k["traversal_busy_ms_per_step"] = busy_ms / args.steps
@@ -727,7 +731,8 @@ def main():
                        "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "frame_split": args.split, "input": obj_note,
                        "band_weights": R.weights,
                        "collectives": ("none" if not dist.active else
-                                       "psm_dist_* (RCCL from libpsm_hip.so)" if R.native is not None else "torch.distributed " + dist.backend)},
+                                       "psm_dist_* (transport %s%s)" % (R.native.transport, ": a REHEARSAL, the ranks share a GPU and exchange through host memory -- not a scaling measurement" if R.hoststaged else " from libpsm_hip.so")
+                                       if R.native is not None else "torch.distributed " + dist.backend)},
             "rays_per_frame": total_rays / args.steps,
             "traverse_mrays_s": (Rr / (st.traverse_ms * 1e-3) / 1e6) if st.traverse_ms > 0 else None,
             "stage_ms_per_frame_measured": ("serial kernel pass: the same frames one after another on one stream (with frames in "

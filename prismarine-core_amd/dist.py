@@ -133,11 +133,32 @@ class Comm:
             if init and not dist.is_initialized():
                 dist.init_process_group(backend=self.backend, rank=self.rank, world_size=world)
 
-    def attach_native(self, ctx):
+    def attach_native(self, ctx, slot_bytes=0):
         """Create the C ABI's RCCL communicator on ctx's device (backend nccl only); rank 0's id travels by a
-        torch.distributed broadcast. PSM_DIST_NATIVE=0 keeps every collective on torch.distributed."""
+        torch.distributed broadcast. PSM_DIST_NATIVE=0 keeps every collective on torch.distributed.
+        PSM_DIST_TRANSPORT=hoststaged (explicit, a rehearsal: ranks that SHARE a GPU, torch side channel over gloo)
+        installs the library's host-staged transport instead of RCCL; slot_bytes = the largest tile of a gather."""
         self.native = None
-        if not self.active or self.backend != "nccl" or os.environ.get("PSM_DIST_NATIVE", "1") == "0":
+        if not self.active or os.environ.get("PSM_DIST_NATIVE", "1") == "0":
+            return None
+        if os.environ.get("PSM_DIST_TRANSPORT", "rccl") == "hoststaged":
+            err = None
+            try:
+                self.native = NativeDist(ctx, self.rank, self.world)
+            except Exception as e:
+                err = e
+            if self.min_int(0 if err is not None else 1) == 0:
+                self._drop_native()
+                raise NativeUnavailable("psm_dist_prepare failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
+            try:
+                self.native.connect_hoststaged("/psm-bench-%s" % os.environ.get("MASTER_PORT", "0"), max(int(slot_bytes), 4096))
+            except Exception as e:
+                err = e
+            if self.min_int(0 if err is not None else 1) == 0:
+                self._drop_native()
+                raise NativeUnavailable("psm_dist_connect_hoststaged failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
+            return self.native
+        if self.backend != "nccl":
             return None
 
         def bcast(raw):
