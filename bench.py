@@ -72,6 +72,9 @@ def parse():
                     help="one GPU: trace every frame with this many Pipelines that own its 8-row bands round-robin and run their "
                          "bounce rounds independently (psm_lanes_render_split): a part's traversal tail overlaps the other parts' "
                          "rounds inside the frame; with --lanes 1 this is one frame at a time, the reference's call pattern")
+    ap.add_argument("--group", type=int, default=0,
+                    help="one GPU: the frames in flight form groups of this many that trace every bounce round in ONE launch over all "
+                         "their queues (psm_lanes_render_grouped); --lanes must be a multiple. 0 = the default of the schedule")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous check only: every rank builds its communicator (gloo, no GPU), proves the group works "
                          "with one all-reduce, prints one line and exits")
@@ -111,7 +114,7 @@ class Renderer:
             self.lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(self.lanes - 1)]
             streams = [st.cuda_stream for st in self.lane_streams]
         assert args.split == 1 or not dist.active, "--split is the one-GPU schedule; tile-sharded runs keep frames in flight instead"
-        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams, split=args.split)
+        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams, split=args.split, group=max(args.group, 1))
         self.batches = [self.batch]
         if args.split > 1:   # the serial passes (counters, per-stage times) render whole frames on an unsplit lane of their own
             self.serial = psm.FrameBatch(1, w, h, device=dist.device_index, seed=1000)
@@ -677,7 +680,7 @@ def main():
         # (a frame split over several Pipelines: every part traces about 1 / split of a round's rays)
         ho_rounds = [r for r in round_log if hand and r[0] / args.split >= min_rays]
         wh_rounds = [r for r in round_log if not (hand and r[0] / args.split >= min_rays)]
-        if args.split == 1:
+        if args.split == 1 and args.group <= 1:
             assert (ho_launches > 0) == (len(ho_rounds) > 0), (ho_launches, len(ho_rounds))
         elif (ho_launches > 0) != (len(ho_rounds) > 0):   # parts near the threshold: price what was launched
             ho_rounds, wh_rounds = (round_log, []) if ho_launches > 0 else ([], round_log)
@@ -730,9 +733,10 @@ def main():
             "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
                                    "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU%s" % (
                                        args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth,
-                                       R.lanes, ", each split over %d Pipelines" % args.split if args.split > 1 else ""),
+                                       R.lanes, ", each split over %d Pipelines" % args.split if args.split > 1 else
+                                       (", in groups of %d that share their traversal launches" % args.group if args.group > 1 else "")),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "frame_split": args.split, "input": obj_note,
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "frame_split": args.split, "frames_per_traversal_launch": max(args.group, 1), "input": obj_note,
                        "band_weights": R.weights,
                        "collectives": ("none" if not dist.active else
                                        "psm_dist_* (transport %s%s)" % (R.native.transport, ": a REHEARSAL, the ranks share a GPU and exchange through host memory -- not a scaling measurement" if R.hoststaged else " from libpsm_hip.so")

@@ -239,6 +239,21 @@ int psm_rt_ray_count(psm_rt* rt, int32_t* count);
  * hierarchies of < 2^27 triangles each per queue; psm_rt_shade() then interpolates each hit from the
  * hierarchy that produced it (its `bvh` argument is used when only one was traversed). */
 int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
+/* Several hierarchies whose traversal records share ONE allocation (new). psm_arena_create reserves the node records and
+ * triangle records of `slots` hierarchies of up to max_tris triangles each (slots x max_tris <= 2^27);
+ * psm_bvh_create_in_arena is psm_bvh_create(ctx, max_tris) with the hierarchy's traversal records in slot `slot`, its child
+ * links and triangle ids counting from the start of the arena (what psm_bvh_download / psm_rt_download_hits hand out stays
+ * relative to the hierarchy). Everything else about the hierarchy is unchanged; the arena must outlive it. The point:
+ * psm_rt_traverse_group walks the current ray queues of up to 8 Pipelines -- each against its own hierarchy, e.g. several
+ * frames in flight that each rebuilt theirs -- in ONE launch. A bounce round's launch cannot end before its longest ray, so a
+ * launch over 4 frames' rays costs 18-28 % less than 4 launches (tools/merge_probe.py); per ray nothing changes (hits,
+ * chains and counters bit-exact). The launch goes to `on`'s stream (NULL: rts[0]'s); the caller orders it after the queues'
+ * writers and before the hits' readers. */
+typedef struct psm_arena psm_arena;
+int psm_arena_create(psm_ctx* ctx, uint32_t slots, size_t max_tris, psm_arena** out);
+int psm_arena_destroy(psm_arena* arena);
+int psm_bvh_create_in_arena(psm_ctx* ctx, psm_arena* arena, uint32_t slot, psm_bvh** out);
+int psm_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on);
 /* Which kernel schedule an intersection() runs as. A tuning knob: hits, chains and counters never depend on it
  * (every schedule performs, per ray, the node steps and triangle tests of directTraverse.comp:333-484 in the
  * same order). A wave64 steps as long as its slowest ray; the schedules differ in how they keep lanes busy:
@@ -356,6 +371,15 @@ int psm_rt_share_texels(psm_rt* rt, psm_rt* owner);
 int psm_lanes_render_split(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t split, const float cam_inv[16],
                            const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
                            int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
+/* Frames in flight whose traversal launches are shared (new): the lanes form lanes / group groups of `group` frames that
+ * advance in lock step and trace each bounce round in ONE launch over all their queues (psm_rt_traverse_group; the
+ * hierarchies of a group are slots of one psm_arena), so that a group pays one launch tail per round instead of `group`;
+ * rebuild, camera, shade and the count read-back stay per frame on the lanes' own streams, and the groups run
+ * asynchronously (one group's shading and rebuilds under another's traversal). Per frame the calls, and so the image,
+ * the rounds and the rays, are psm_lanes_render's. rts[g * group + k] / bvhs[...]: lane k of group g. */
+int psm_lanes_render_grouped(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t group, const float cam_inv[16],
+                             const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
+                             int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
 /* The same frames when they are tile-sharded over several GPUs: the `fewer than 32 rays -> stop` rule then looks
  * at each frame's GLOBAL count. A rank with >= 32 local rays knows the global count is >= 32 too, so every lane
  * runs free (as above) until its LOCAL count drops below 32 or `depth` is reached, and then parks with its queue

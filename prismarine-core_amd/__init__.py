@@ -23,12 +23,12 @@ EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_copy_bandwidth", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev", "psm_sort_set_algorithm",
-    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
+    "psm_bvh_create", "psm_arena_create", "psm_arena_destroy", "psm_bvh_create_in_arena", "psm_rt_traverse_group", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_refill", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_render_split", "psm_rt_share_texels", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_refill", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_render_grouped", "psm_lanes_render_split", "psm_rt_share_texels", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -234,6 +234,22 @@ class RadixSort:
             self.ctx.buf_free(hv)
 
 
+class Arena:
+    """psm_arena: the traversal records (node records, triangle records) of `slots` hierarchies of up to max_tris triangles
+    in one allocation, links arena-wide -- what lets one traversal launch walk the rays of several frames, each against its
+    own rebuilt hierarchy (psm_rt_traverse_group, FrameBatch(group=G))."""
+
+    def __init__(self, ctx, slots, max_tris):
+        self.ctx, self.slots, self.max_tris = ctx, slots, max_tris
+        self._h = C.c_void_p()
+        ctx.check(lib().psm_arena_create(ctx._h, C.c_uint32(slots), C.c_size_t(max_tris), C.byref(self._h)), "psm_arena_create")
+
+    def close(self):
+        if self._h:
+            lib().psm_arena_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class TriangleHierarchy:
     """psm::TriangleHierarchy (Include/Prismarine/TriangleHierarchy.hpp:75-94)."""
 
@@ -245,11 +261,16 @@ class TriangleHierarchy:
         self._dirty = False
         self.maxt = 0
 
-    def allocate(self, count):
+    def allocate(self, count, arena=None, slot=0):
+        """arena / slot: keep the traversal records in a slot of an Arena (count must be the arena's max_tris)"""
         if self._h:
             lib().psm_bvh_destroy(self._h)
             self._h = C.c_void_p()
-        self.ctx.check(lib().psm_bvh_create(self.ctx._h, C.c_size_t(count), C.byref(self._h)), "psm_bvh_create")
+        if arena is not None:
+            assert count == arena.max_tris, "a hierarchy in an arena has the arena's capacity"
+            self.ctx.check(lib().psm_bvh_create_in_arena(self.ctx._h, arena._h, C.c_uint32(slot), C.byref(self._h)), "psm_bvh_create_in_arena")
+        else:
+            self.ctx.check(lib().psm_bvh_create(self.ctx._h, C.c_size_t(count), C.byref(self._h)), "psm_bvh_create")
         self.maxt = count
         self.clearTribuffer()
 
@@ -695,6 +716,18 @@ def read_pfm(path):
     return data[::-1].copy()
 
 
+def traverse_group(pipelines, hierarchies, on=None):
+    """psm_rt_traverse_group: ONE traversal launch over the current queues of several Pipelines, each against its own
+    hierarchy (slots of one Arena), on `on`'s stream (default: the first Pipeline's context). The caller orders the streams."""
+    n = len(pipelines)
+    rts = (C.c_void_p * n)(*[r._h for r in pipelines])
+    bvhs = (C.c_void_p * n)(*[t._h for t in hierarchies])
+    ctx = on or pipelines[0].ctx
+    ctx.check(lib().psm_rt_traverse_group(rts, bvhs, C.c_uint32(n), ctx._h), "psm_rt_traverse_group")
+    for r, t in zip(pipelines, hierarchies):
+        r._obj = t
+
+
 def sharded_rounds(rays, intersector, materials, depth=16):
     """The bounce loop of Viewer.cpp:304-310 for one tile of a sharded frame, as a generator: yields
     the local ray count and is sent the GLOBAL count (sum over tiles), so the reference's
@@ -728,12 +761,17 @@ class FrameBatch:
         def __init__(self, ctx, th, rays):
             self.ctx, self.th, self.rays = ctx, th, rays
 
-    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None, split=1):
-        """split > 1: every frame is traced by `split` Pipelines ("parts") that own the frame's 8-row bands round-robin,
+    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None, split=1, group=1):
+        """group > 1: the lanes form lanes / group groups whose frames advance in lock step and trace every bounce round in
+        ONE launch over all their queues (psm_lanes_render_grouped); the hierarchies then live in one Arena.
+        split > 1: every frame is traced by `split` Pipelines ("parts") that own the frame's 8-row bands round-robin,
         share one hierarchy and one set of texel arrays and run their rounds independently (psm_lanes_render_split), so
         that a part's traversal tail overlaps the other parts' rounds INSIDE the frame; lanes = frames in flight."""
         self.n = lanes
         self.split = split
+        self.group = group
+        assert group >= 1 and lanes % group == 0 and (group == 1 or split == 1)
+        self.arena = None
         self.lanes = []
         self.parts = []          # parts 1..split-1 of every frame slot: (ctx, Pipeline)
         for s in range(lanes):
@@ -773,6 +811,17 @@ class FrameBatch:
 
     # -- scene: every lane holds the same scene ------------------------------------------------------
     def allocate(self, n):
+        if self.group > 1:   # traversal records of all lanes' hierarchies in one allocation (one launch walks them all)
+            if self.arena is not None:
+                for ln in self.lanes:
+                    if ln.th._h:
+                        lib().psm_bvh_destroy(ln.th._h)
+                        ln.th._h = C.c_void_p()
+                self.arena.close()
+            self.arena = Arena(self.lanes[0].ctx, len(self.lanes), n)
+            for s, ln in enumerate(self.lanes):
+                ln.th.allocate(n, self.arena, s)
+            return
         for ln in self.lanes:
             ln.th.allocate(n)
 
@@ -813,6 +862,24 @@ class FrameBatch:
             return []
         if self.split > 1:
             return self._trace_split(cam_inv, proj_inv, seeds, depth, rebuild, optimization, fold)
+        if self.group > 1:
+            assert fold, "grouped frames always fold into the accumulating Pipeline"
+            n = self.n
+            rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes])
+            bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes])
+            sd = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
+            res = (LaneResult * k)()
+            ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
+            pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
+            opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
+            rc = lib().psm_lanes_render_grouped(rts, bvhs, C.c_uint32(n), C.c_uint32(self.group), _p(ci), _p(pi), sd, C.c_uint32(k),
+                                                C.c_uint32(depth), C.c_int(int(rebuild)), _p(opt) if opt is not None else None,
+                                                self.master._h, res)
+            self.lanes[0].ctx.check(rc, "psm_lanes_render_grouped")
+            for ln in self.lanes:
+                ln.th._dirty = False
+                ln.rays._obj = ln.th
+            return [(res[f].rounds, res[f].rays) for f in range(k)]
         n = min(self.n, k)
         rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes[:n]])
         bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
@@ -956,6 +1023,10 @@ class FrameBatch:
         for ln in self.lanes:
             ln.rays.close()
             ln.th.close()
+        if self.arena is not None:      # after the hierarchies that live in it, before the context that allocated it
+            self.arena.close()
+            self.arena = None
+        for ln in self.lanes:
             ln.ctx.close()
         self.lanes = []
         self.master.close()

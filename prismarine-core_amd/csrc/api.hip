@@ -260,6 +260,7 @@ int psm_bvh_destroy(psm_bvh* b) {
     if (!b) return PSM_ERR_INVALID;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->arena) { b->d_tri48 = nullptr; b->d_node32 = nullptr; }   // slices of the arena
     dev_free(b->d_pos); dev_free(b->d_nrm); dev_free(b->d_mats); dev_free(b->d_tri48); dev_free(b->d_tex);
     dev_free(b->d_keys); dev_free(b->d_idx); dev_free(b->d_leafbox); dev_free(b->d_leaftri);
     dev_free(b->d_block); dev_free(b->d_small); dev_free(b->d_opt); dev_free(b->d_seg);
@@ -269,7 +270,37 @@ int psm_bvh_destroy(psm_bvh* b) {
     return PSM_OK;
 }
 
-int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
+int psm_arena_destroy(psm_arena* a) {
+    if (!a) return PSM_ERR_INVALID;
+    (void)hipSetDevice(a->ctx->device);
+    dev_free(a->d_node32); dev_free(a->d_tri48);
+    delete a;
+    return PSM_OK;
+}
+int psm_arena_create(psm_ctx* c, uint32_t slots, size_t max_tris, psm_arena** out) {
+    if (!c || !out || slots == 0 || max_tris == 0) return PSM_ERR_INVALID;
+    *out = nullptr;
+    // links and triangle ids count from the start of the arena: the same 2^27 limits as one hierarchy's, over all slots
+    if ((uint64_t)slots * max_tris > (1ull << 27)) return set_err(c, PSM_ERR_CAPACITY, "psm_arena_create: slots x max_tris exceeds 2^27");
+    (void)hipSetDevice(c->device);
+    psm_arena* a = new (std::nothrow) psm_arena();
+    if (!a) return PSM_ERR_INVALID;
+    a->ctx = c; a->slots = slots; a->max_tris = max_tris;
+    int rc = dev_alloc(c, &a->d_node32, (size_t)slots * 2 * max_tris);
+    if (rc == PSM_OK) rc = dev_alloc(c, &a->d_tri48, (size_t)slots * 3 * max_tris);
+    if (rc != PSM_OK) { psm_arena_destroy(a); return rc; }
+    *out = a;
+    return PSM_OK;
+}
+
+static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t slot, psm_bvh** out);
+int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) { return bvh_create(c, max_tris, nullptr, 0, out); }
+int psm_bvh_create_in_arena(psm_ctx* c, psm_arena* arena, uint32_t slot, psm_bvh** out) {
+    if (!c || !arena || !out || slot >= arena->slots || c->device != arena->ctx->device) return PSM_ERR_INVALID;
+    return bvh_create(c, arena->max_tris, arena, slot, out);
+}
+
+static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t slot, psm_bvh** out) {
     if (!c || !out || max_tris == 0) return PSM_ERR_INVALID;
     // 2^27 triangles (the reference: ~4.19 M, TriangleHierarchy.inl:80): the traversal kernel addresses its 32-byte node
     // records with a 32-bit byte offset, and 9 floats per triangle stay below 2^31 elements
@@ -291,12 +322,22 @@ int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
     int rc = PSM_OK;
     auto A = [&](int r) { if (rc == PSM_OK) rc = r; };
     A(dev_alloc(c, &b->d_pos, 9 * n)); A(dev_alloc(c, &b->d_nrm, 9 * n)); A(dev_alloc(c, &b->d_mats, n));
-    A(dev_alloc(c, &b->d_tri48, 3 * n)); A(dev_alloc(c, &b->d_tex, 6 * n)); A(dev_alloc(c, &b->d_keys, n)); A(dev_alloc(c, &b->d_idx, n));
+    if (arena) {
+        b->arena = arena;
+        b->node_off = (uint32_t)((size_t)slot * n);   // in nodes (2 uint4 each)
+        b->tri_off = (uint32_t)((size_t)slot * n);
+        b->d_tri48 = arena->d_tri48 + (size_t)3 * b->tri_off;
+        b->d_node32 = arena->d_node32 + (size_t)2 * b->node_off;
+    } else {
+        A(dev_alloc(c, &b->d_tri48, 3 * n));
+    }
+    A(dev_alloc(c, &b->d_tex, 6 * n)); A(dev_alloc(c, &b->d_keys, n)); A(dev_alloc(c, &b->d_idx, n));
     A(dev_alloc(c, &b->d_leafbox, n)); A(dev_alloc(c, &b->d_leaftri, n));
     A(dev_alloc(c, &b->d_block, (n + 255) / 256 + 1)); A(dev_alloc(c, &b->d_small, (size_t)SM_WORDS));
     A(dev_alloc(c, &b->d_opt, (size_t)16)); A(dev_alloc(c, &b->d_seg, off));
     A(dev_alloc(c, &b->d_sorted_tri, n)); A(dev_alloc(c, &b->d_pairbox, 2 * n)); A(dev_alloc(c, &b->d_link, n));
-    A(dev_alloc(c, &b->d_range, n)); A(dev_alloc(c, &b->d_node32, 2 * n));
+    A(dev_alloc(c, &b->d_range, n));
+    if (!arena) A(dev_alloc(c, &b->d_node32, 2 * n));
     if (rc != PSM_OK) { psm_bvh_destroy(b); return rc; }
     if (hipMemsetAsync(b->d_small, 0, SM_WORDS * 4, c->stream) != hipSuccess ||
         hipMemsetAsync(b->d_tex, 0, 6 * n * sizeof(float), c->stream) != hipSuccess) { psm_bvh_destroy(b); return PSM_ERR_HIP; }
@@ -519,6 +560,7 @@ int psm_bvh_get_info(psm_bvh* b, psm_bvh_info* info) {
     info->triangle_count = b->tri_count;
     info->leaf_count = sm[SM_COUNT];
     info->root = (int32_t)sm[SM_ROOT];
+    if (info->root >= 0) info->root -= (int32_t)b->node_off;   // (the traversal records of an arena slot count from the arena's start)
     std::memcpy(info->transform, sm, 16 * sizeof(float));
     std::memcpy(info->bounds_min, sm + SM_BFLOAT, 4 * sizeof(float));
     std::memcpy(info->bounds_max, sm + SM_BFLOAT + 4, 4 * sizeof(float));
@@ -852,6 +894,25 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
     return launch_rt_traverse(r, b);
 }
 
+// One traversal launch over the current queues of n Pipelines, on `on`'s stream (NULL: rts[0]'s context). The caller orders
+// that stream after the queues' writers and the hits' readers after it (the grouped scheduler does it with events).
+static int traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
+int psm_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on) { return traverse_group(rts, bvhs, n, on, nullptr); }
+// (owner: the Pipeline whose schedule settings and continuation queues the launch uses; the grouped scheduler's lead lane)
+int psm_rt_traverse_group_owned(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner) { return traverse_group(rts, bvhs, n, on, owner); }
+static int traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner) {
+    if (!rts || !bvhs || n == 0) return PSM_ERR_INVALID;
+    for (uint32_t k = 0; k < n; k++) {
+        if (!rts[k] || !bvhs[k]) return PSM_ERR_INVALID;
+        int32_t cnt;
+        int rc = psm_rt_ray_count(rts[k], &cnt);   // synchronises only where the host does not know the count yet
+        if (rc != PSM_OK) return rc;
+    }
+    psm_ctx* c = on ? on : rts[0]->ctx;
+    (void)hipSetDevice(c->device);
+    return launch_rt_traverse_group(rts, bvhs, n, c, owner);
+}
+
 int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
     if (!r) return PSM_ERR_INVALID;
     r->enable360 = enable360 ? 1 : 0;
@@ -1037,6 +1098,12 @@ int psm_rt_download_hits(psm_rt* r, psm_hit* hits, int32_t* counts, uint32_t max
             if (k < n) {
                 v = (k == 0) ? h0[i] : pool[off + k - 1];
                 std::memcpy(&tri, &v.w, 4);
+                // a hierarchy in an arena slot records arena-wide triangle ids: hand out the hierarchy's own
+                if (tri >= 0) {
+                    const int obj = (tri >> OBJ_SHIFT) & (MAX_TRAV_OBJECTS - 1);
+                    const psm_bvh* hb = obj < MAX_TRAV_OBJECTS ? r->last_objs[obj] : nullptr;
+                    if (hb && hb->tri_off) tri = (((tri & ((1 << OBJ_SHIFT) - 1)) - (int)hb->tri_off) | (obj << OBJ_SHIFT));
+                }
             }
             o.u = v.x; o.v = v.y; o.t = v.z; o.tri = tri;
         }

@@ -442,10 +442,13 @@ template <bool RECORDS>
 __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ keys, const int32_t* __restrict__ sorted_tri,
                                                 SegTree st, uint32_t* __restrict__ sm, uint4* __restrict__ pairbox,
                                                 int2* __restrict__ link, int2* __restrict__ range,
-                                                uint4* __restrict__ node32) {
+                                                uint4* __restrict__ node32, int node_off, int tri_off) {
+    // node_off / tri_off: the hierarchy's slot in an arena (psm_arena): the links and triangle ids of the TRAVERSAL records
+    // count from the start of the arena, so that one launch can walk several hierarchies from one base pointer; the
+    // reference-shaped records (RECORDS) and everything the parity tests download stay relative to the hierarchy
     int count = (int)sm[SM_COUNT];
     int s = blockIdx.x * 256 + threadIdx.x;
-    if (s == 0) sm[SM_ROOT] = (uint32_t)(count >= 2 ? find_split(keys, 0, count - 1) : -1);
+    if (s == 0) sm[SM_ROOT] = (uint32_t)(count >= 2 ? find_split(keys, 0, count - 1) + node_off : -1);
     if (s >= count - 1) return;
     uint64_t ks = keys[s], ks1 = keys[s + 1];
     int f, l;
@@ -517,7 +520,8 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     // traversal record (trace.hip): xyz of both child boxes (the w halves are never read by the
     // slab test) + both links = 32 bytes, one aligned pair of 16-byte loads per visit
     node32[2 * (size_t)s + 0] = make_uint4(lb.x, (lb.y & 0xffffu) | (lb.z << 16), (lb.z >> 16) | (lb.w << 16), rb.x);
-    node32[2 * (size_t)s + 1] = make_uint4((rb.y & 0xffffu) | (rb.z << 16), (rb.z >> 16) | (rb.w << 16), (uint32_t)lk.x, (uint32_t)lk.y);
+    const int ax = lk.x >= 0 ? lk.x + node_off : ~(~lk.x + tri_off), ay = lk.y >= 0 ? lk.y + node_off : ~(~lk.y + tri_off);
+    node32[2 * (size_t)s + 1] = make_uint4((rb.y & 0xffffu) | (rb.z << 16), (rb.z >> 16) | (rb.w << 16), (uint32_t)ax, (uint32_t)ay);
 }
 
 // ---- launch wrappers ----------------------------------------------------------------------------
@@ -578,7 +582,7 @@ int launch_bvh_emit(psm_bvh* b) {
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
     uint32_t grid = (n + 255u) / 256u;
     bvh_emit<false><<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
-                                                 b->d_range, b->d_node32);
+                                                 b->d_range, b->d_node32, (int)b->node_off, (int)b->tri_off);
     b->records_valid = false;
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
@@ -594,7 +598,7 @@ int launch_bvh_emit_records(psm_bvh* b) {
     st.seg = b->d_seg;
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
     bvh_emit<true><<<(n + 255u) / 256u, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
-                                                             b->d_range, b->d_node32);
+                                                             b->d_range, b->d_node32, (int)b->node_off, (int)b->tri_off);
     PSM_HIP(c, hipGetLastError());
     b->records_valid = true;
     return PSM_OK;

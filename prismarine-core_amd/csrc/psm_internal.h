@@ -142,8 +142,22 @@ struct psm_ctx {
     uint32_t* sort_error_word = nullptr; // device word the look-back raises on a spin timeout
 };
 
+// Traversal records of several hierarchies in ONE allocation (psm_arena_create): slot k holds the node records and the
+// triangle records of one hierarchy, and the links / triangle ids inside the node records count from the start of the
+// arena. One traversal launch can then walk rays of several hierarchies -- several frames in flight, each with its own
+// rebuilt hierarchy -- from two scalar base pointers (psm_rt_traverse_group, trace.hip).
+struct psm_arena {
+    psm_ctx* ctx = nullptr;
+    uint32_t slots = 0;
+    size_t max_tris = 0;
+    uint4* d_node32 = nullptr;   // slots x 2 * max_tris
+    float4* d_tri48 = nullptr;   // slots x 3 * max_tris
+};
+
 struct psm_bvh {
     psm_ctx* ctx = nullptr;
+    psm_arena* arena = nullptr;   // d_node32 / d_tri48 are slices of this arena (not freed with the hierarchy)
+    uint32_t node_off = 0, tri_off = 0;  // what the slot adds to child links / triangle ids in the node records
     size_t cap = 0;
     uint32_t tri_count = 0;
     bool built = false, bounds_done = false, morton_done = false, sort_done = false;
@@ -216,6 +230,7 @@ struct psm_rt {
     psm::TexDesc* d_tex_table = nullptr;
     bool tex_dirty = false;
     psm_bvh* trav_objs[psm::MAX_TRAV_OBJECTS] = {};  // hierarchies traversed since the queue last changed
+    psm_bvh* last_objs[psm::MAX_TRAV_OBJECTS] = {};  // ... of the last traversal(s), kept for psm_rt_download_hits after shade() reset trav_n
     int trav_n = 0;
     psm::ObjGeom* d_geoms = nullptr;
     int enable360 = 0;            // cameraUniform.enable360 (switchMode)
@@ -285,6 +300,7 @@ int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
 int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views);
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
+int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
 int launch_rt_sample(psm_rt* r, psm_rt* src);
 // pack / unpack the dense tile of rows [a, b) (bands == NULL) or of rank a in the dealing `bands`

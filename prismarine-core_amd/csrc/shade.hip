@@ -603,51 +603,64 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
             const float coef = pclamp((g.next() < spca) ? 1.0f : 0.0f, 0.0f, 1.0f);   // :267
             const float u10 = g.next(), u11 = g.next();
 
-            // ---- diffuse ray: diffuse(), shadinglib.glsl:106-119
-            WRay dr;
-            dr.color = incol * mk3(c_albedo[0], c_albedo[1], c_albedo[2]);
-            dr.color = dr.color * om;                       // :219
-            dr.color = dr.color * (1.0f - coef);            // :268
-            dr.direct = normalize3(randomCosineU(u2, u3, normal));
-            dr.origin = fma3(dr.direct, GAP, hitp);
-            dr.fin = mk3(0.f, 0.f, 0.f);
-            dr.bf = inbf;
-            S_ACTIVE(dr.bf, R_TYPE(dr.bf) == 2 ? 0 : R_ACTIVE(dr.bf));
-            S_BOUNCE(dr.bf, R_BOUNCE(dr.bf) < 2 ? R_BOUNCE(dr.bf) : 2);
-            S_TYPE(dr.bf, 1);
-            S_DL(dr.bf, 0);
-            // ---- shadow ray = directLight(0, diffuseRay, 1, normal), shadinglib.glsl:75-93, then applyLight :181-189
+            // Of the diffuse and the reflection ray exactly one survives the lobe pick (:267-268: coef is 0 or 1, the other
+            // ray's colour is multiplied by 0 and createRay drops it, and the shadow ray -- a copy of the diffuse one -- with
+            // it; none of them deposits: their `final` is 0). So the cosine-weighted direction both need is evaluated ONCE,
+            // from the draws of the ray that survives (#2, #3 for the diffuse ray, #4, #5 for the reflection), and only the
+            // surviving rays are built -- the same operations on the same values for everything that reaches the queue.
+            const bool refl_lobe = coef != 0.0f;
+            const v3 rc = randomCosineU(refl_lobe ? u4 : u2, refl_lobe ? u5 : u3, normal);
+            v3 sdir;   // the surviving secondary ray's direction
             {
-                WRay sr = dr;
-                S_ACTIVE(sr.bf, R_TYPE(sr.bf) == 2 ? 0 : R_ACTIVE(sr.bf));
-                S_DL(sr.bf, 1);
-                S_TYPE(sr.bf, 2);
-                S_TARGET(sr.bf, 0);
-                S_BOUNCE(sr.bf, R_BOUNCE(sr.bf) < 1 ? R_BOUNCE(sr.bf) : 1);
-                v3 ctr = lightCenter(a.lights[0]);
-                v3 sd = randomDirectionInSphereU(u10, u11);
-                v3 sl = fma3(sd, a.lights[0].lightColor[3] - 0.0001f, ctr);
-                v3 ldirect = normalize3(sl - sr.origin);
-                float dist = len3(ctr - sr.origin);
-                float q = a.lights[0].lightColor[3] / dist;
-                float weight = 1.0f - sqrtf(1.0f - pclamp(dot3(ldirect, normal) * 2.f * (q * q), 0.f, 1.f));
-                sr.origin = fma3(sr.direct, -GAP, sr.origin);
-                sr.direct = ldirect;
-                sr.color = sr.color * (1.0f * weight);
-                sr.origin = fma3(sr.direct, GAP, sr.origin);
-                bool off = (R_TYPE(dr.bf) == 2) || (dot3(c_normal, sr.direct) < 0.f);
-                S_ACTIVE(sr.bf, off ? 0 : R_ACTIVE(sr.bf));
-                have[3] = create_ray(sr, in_texel, child_key(in_pkey, 3u), outs[3], a.t_sum, a.t_flag);
-            }
-            have[1] = create_ray(dr, in_texel, child_key(in_pkey, 1u), outs[1], a.t_sum, a.t_flag);
-            // ---- reflection ray: reflection(), shadinglib.glsl:139-148
-            {
-                WRay rr;
+                // reflection(), shadinglib.glsl:139-148: mix(reflect(dir, n), randomCosine(n), clamp(roughness * random()))
                 float dn = dot3(normal, ray.direct);
                 v3 refl = mk3(ray.direct.x - 2.0f * dn * normal.x, ray.direct.y - 2.0f * dn * normal.y, ray.direct.z - 2.0f * dn * normal.z);
-                v3 rc = randomCosineU(u4, u5, normal);
                 float al = pclamp(refly * u6, 0.0f, 1.0f);
-                rr.direct = normalize3(mk3(mixf(refl.x, rc.x, al), mixf(refl.y, rc.y, al), mixf(refl.z, rc.z, al)));
+                v3 mixed = mk3(mixf(refl.x, rc.x, al), mixf(refl.y, rc.y, al), mixf(refl.z, rc.z, al));
+                sdir = normalize3(refl_lobe ? mixed : rc);   // diffuse(): normalize(randomCosine(n)), :106-119
+            }
+            if (!refl_lobe) {
+                // ---- diffuse ray: diffuse(), shadinglib.glsl:106-119
+                WRay dr;
+                dr.color = incol * mk3(c_albedo[0], c_albedo[1], c_albedo[2]);
+                dr.color = dr.color * om;                       // :219
+                dr.color = dr.color * (1.0f - coef);            // :268
+                dr.direct = sdir;
+                dr.origin = fma3(dr.direct, GAP, hitp);
+                dr.fin = mk3(0.f, 0.f, 0.f);
+                dr.bf = inbf;
+                S_ACTIVE(dr.bf, R_TYPE(dr.bf) == 2 ? 0 : R_ACTIVE(dr.bf));
+                S_BOUNCE(dr.bf, R_BOUNCE(dr.bf) < 2 ? R_BOUNCE(dr.bf) : 2);
+                S_TYPE(dr.bf, 1);
+                S_DL(dr.bf, 0);
+                // ---- shadow ray = directLight(0, diffuseRay, 1, normal), shadinglib.glsl:75-93, then applyLight :181-189
+                {
+                    WRay sr = dr;
+                    S_ACTIVE(sr.bf, R_TYPE(sr.bf) == 2 ? 0 : R_ACTIVE(sr.bf));
+                    S_DL(sr.bf, 1);
+                    S_TYPE(sr.bf, 2);
+                    S_TARGET(sr.bf, 0);
+                    S_BOUNCE(sr.bf, R_BOUNCE(sr.bf) < 1 ? R_BOUNCE(sr.bf) : 1);
+                    v3 ctr = lightCenter(a.lights[0]);
+                    v3 sd = randomDirectionInSphereU(u10, u11);
+                    v3 sl = fma3(sd, a.lights[0].lightColor[3] - 0.0001f, ctr);
+                    v3 ldirect = normalize3(sl - sr.origin);
+                    float dist = len3(ctr - sr.origin);
+                    float q = a.lights[0].lightColor[3] / dist;
+                    float weight = 1.0f - sqrtf(1.0f - pclamp(dot3(ldirect, normal) * 2.f * (q * q), 0.f, 1.f));
+                    sr.origin = fma3(sr.direct, -GAP, sr.origin);
+                    sr.direct = ldirect;
+                    sr.color = sr.color * (1.0f * weight);
+                    sr.origin = fma3(sr.direct, GAP, sr.origin);
+                    bool off = (R_TYPE(dr.bf) == 2) || (dot3(c_normal, sr.direct) < 0.f);
+                    S_ACTIVE(sr.bf, off ? 0 : R_ACTIVE(sr.bf));
+                    have[3] = create_ray(sr, in_texel, child_key(in_pkey, 3u), outs[3], a.t_sum, a.t_flag);
+                }
+                have[1] = create_ray(dr, in_texel, child_key(in_pkey, 1u), outs[1], a.t_sum, a.t_flag);
+            } else {
+                // ---- reflection ray: reflection(), shadinglib.glsl:139-148
+                WRay rr;
+                rr.direct = sdir;
                 v3 col = mk3(pclamp(sc.x / spca, 0.0f, 1.0f), pclamp(sc.y / spca, 0.0f, 1.0f), pclamp(sc.z / spca, 0.0f, 1.0f));
                 rr.color = incol * col;
                 rr.color = rr.color * om;                   // :220
@@ -883,7 +896,10 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     ShadeArgs a;
     a.q = current_queue(r);
     a.hit0 = r->hit0; a.hitN = r->hitN; a.pool = r->pool;
-    a.src.tri48 = b->d_tri48; a.src.nrm = b->d_nrm; a.src.tri_mats = b->d_mats; a.src.uv = b->d_tex;
+    // hits of a hierarchy in an arena slot carry arena-wide triangle ids: the arrays are handed over shifted back by the slot's
+    // first triangle, so that the kernel indexes them with the id as recorded
+    const size_t t0 = b->tri_off;
+    a.src.tri48 = b->d_tri48 - 3 * t0; a.src.nrm = b->d_nrm - 9 * t0; a.src.tri_mats = b->d_mats - t0; a.src.uv = b->d_tex - 6 * t0;
     a.src.mats = r->d_mats; a.src.tex = r->d_tex_table; a.lights = r->d_lights;
     const int nxt_q = r->cur ^ 1;
     a.sA = r->qA[nxt_q]; a.sB = r->qB[nxt_q]; a.sC = r->qC[nxt_q];  // every workgroup writes its own segment of the next queue
@@ -899,7 +915,11 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     if (multi) {  // hits carry an object tag: hand the kernel every traversed hierarchy's mosaics
         ObjGeom g[MAX_TRAV_OBJECTS] = {};
         for (int i = 0; i < r->trav_n; i++)
-            g[i] = ObjGeom{r->trav_objs[i]->d_tri48, r->trav_objs[i]->d_nrm, r->trav_objs[i]->d_mats, r->trav_objs[i]->d_tex};
+        {
+            const psm_bvh* o = r->trav_objs[i];
+            const size_t o0 = o->tri_off;
+            g[i] = ObjGeom{o->d_tri48 - 3 * o0, o->d_nrm - 9 * o0, o->d_mats - o0, o->d_tex - 6 * o0};
+        }
         PSM_HIP(c, hipMemcpyAsync(r->d_geoms, g, sizeof(g), hipMemcpyHostToDevice, c->stream));
         PSM_HIP(c, hipStreamSynchronize(c->stream));
     }

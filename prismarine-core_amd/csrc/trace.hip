@@ -103,6 +103,23 @@ PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(
 // the rest -- result arrays, counters, the hand-over state -- are read where they are used, through the kernarg
 // segment, behind an opaque move (cold_args): held in scalar registers from the kernel's entry they would cost the
 // loop ~30 SGPRs, whose spills take two VGPRs from a kernel that is allowed 64 (8 waves per SIMD).
+// GROUP: one launch over the current ray queues of several Pipelines (several frames in flight, each with its own rebuilt
+// hierarchy in a slot of one psm_arena, so that the node and triangle records of all of them hang off the same two base
+// pointers and their links are arena-wide). The rays of queue k are the launch's rays first[k] .. first[k] + nrays[k] - 1;
+// a ray finds its queue, its hierarchy's small block (transform, root) and its result arrays through this table -- in the
+// set-up and in the result write only; the node steps and triangle tests do not know about it.
+constexpr int MAX_GROUP = 8;
+struct GroupQueue {
+    const float4 *qA, *qB;
+    const uint32_t* qbases;
+    const uint32_t* sm;
+    float4* hit0;
+    uint32_t* hitN;
+    float4* pool;
+    uint32_t* cnt;
+    uint32_t qnb, nrays, first, pool_cap;
+};
+
 struct TravArgs {
     const float4 *qA, *qB;        // hot
     const uint32_t* qbases;
@@ -120,6 +137,8 @@ struct TravArgs {
     uint32_t pool_cap, obj_tag;
     TravState in, out;
     uint32_t* out_count;
+    uint32_t gn;                  // GROUP: queues in the table
+    GroupQueue gq[MAX_GROUP];
 };
 
 PSM_D const TravArgs* cold_args() {
@@ -128,7 +147,7 @@ PSM_D const TravArgs* cold_args() {
     return (const TravArgs*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + zero);
 }
 
-template <bool COUNT, bool CHAIN, bool PHASED>
+template <bool COUNT, bool CHAIN, bool PHASED, bool GROUP = false>
 __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const float4* __restrict__ qA = ka.qA;
     const float4* __restrict__ qB = ka.qB;
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const uint32_t qnb = ka.qnb;
     // never past what the queue holds: a host-supplied count (psm_rt_set_ray_count) larger than the queue's total would
     // resolve to slots beyond its last segment
-    const uint32_t nrays = min(ka.nrays, qbases[qnb]);
+    const uint32_t nrays = GROUP ? ka.nrays : min(ka.nrays, qbases[qnb]);   // (GROUP: clamped per queue below)
     const uint4* __restrict__ node32 = ka.node32;
     const float4* __restrict__ tri48 = ka.tri48;
     const uint32_t* __restrict__ sm = ka.sm;
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
-    const int root = (int)sm[SM_ROOT];
+    int root = GROUP ? -1 : (int)sm[SM_ROOT];
     // fresh rays: one ray per thread of the grid. Workgroups b and b + 8 of a grid share an XCD (round-robin dispatch,
     // observed, a speed matter only) and each XCD has its own 4 MB L2: the grid is dealt so that an XCD walks runs of
     // 32 consecutive workgroups' rays (4096 rays: two rows of texels, neighbouring parts of the tree), the runs
@@ -168,15 +187,35 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     uint32_t i = slot;
     if (resume) i = alive ? cold_args()->in.idx()[slot] : 0u;
 
-    const uint32_t loc = alive ? queue_loc(qbases, qnb, nrays, i) : 0u;  // the queue is segmented (psm_common.h)
-    float4 A = alive ? qA[loc] : make_float4(0, 0, 0, 0);
-    float4 B = alive ? qB[loc] : make_float4(1, 0, 0, 0);
+    float4 A = make_float4(0, 0, 0, 0), B = make_float4(1, 0, 0, 0);
+    float M[16];
+    if (GROUP) {
+        // the ray's queue: the last k with first[k] <= i (the table is in the kernarg segment; per-lane reads of it). `i`
+        // stays the ray's index in the LAUNCH (what a hand-over records); the result write looks the queue up again, so
+        // that nothing but `i` lives across the loop
+        const TravArgs* K = cold_args();
+        uint32_t gq_k = 0;
+        for (uint32_t k = 1; k < K->gn; k++) gq_k += (i >= K->gq[k].first) ? 1u : 0u;
+        const GroupQueue* Q = &K->gq[gq_k];
+        const uint32_t* __restrict__ qsm = Q->sm;
+        if (alive && (i - Q->first) >= Q->qbases[Q->qnb]) alive = false;   // never past what the ray's queue holds
+        if (alive) {
+            const uint32_t loc = queue_loc(Q->qbases, Q->qnb, min(Q->nrays, Q->qbases[Q->qnb]), i - Q->first);
+            A = Q->qA[loc];
+            B = Q->qB[loc];
+            root = (int)qsm[SM_ROOT];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) M[k] = alive ? u2f(qsm[SM_M + k]) : 0.f;
+    } else {
+        const uint32_t loc = alive ? queue_loc(qbases, qnb, nrays, i) : 0u;  // the queue is segmented (psm_common.h)
+        if (alive) { A = qA[loc]; B = qB[loc]; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
+    }
     v3 origin = mk3(A.x, A.y, A.z);
     v3 direct = normalize3(mk3(B.x, B.y, B.z));  // :350
 
-    float M[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
     float to4[4], td4[4];
     mat_vec(M, origin.x, origin.y, origin.z, 1.0f, to4);   // :353
     matT_vec(M, direct.x, direct.y, direct.z, 1.0f, td4);  // :354
@@ -365,12 +404,17 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     }
     if (PHASED && suspended) alive = false;  // its result is written by the launch that finishes it
     const TravArgs* K = cold_args();
-    float4* __restrict__ hit0 = K->hit0;
-    uint32_t* __restrict__ hitN = K->hitN;
-    float4* __restrict__ pool = K->pool;
-    uint32_t* __restrict__ cnt = K->cnt;
+    uint32_t gq_k = 0;
+    if (GROUP) {   // the ray's own Pipeline again, and its index there
+        for (uint32_t k = 1; k < K->gn; k++) gq_k += (i >= K->gq[k].first) ? 1u : 0u;
+        i -= alive ? K->gq[gq_k].first : 0u;
+    }
+    float4* __restrict__ hit0 = GROUP ? K->gq[gq_k].hit0 : K->hit0;
+    uint32_t* __restrict__ hitN = GROUP ? K->gq[gq_k].hitN : K->hitN;
+    float4* __restrict__ pool = GROUP ? K->gq[gq_k].pool : K->pool;
+    uint32_t* __restrict__ cnt = GROUP ? K->gq[gq_k].cnt : K->cnt;
     DevCounters* __restrict__ ctr = K->ctr;
-    const uint32_t pool_cap = K->pool_cap, obj_tag = K->obj_tag;
+    const uint32_t pool_cap = GROUP ? K->gq[gq_k].pool_cap : K->pool_cap, obj_tag = K->obj_tag;
 
     if (CHAIN) {
         if (alive && bakedCount > 0) {
@@ -736,11 +780,15 @@ __global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka)
 constexpr size_t MAX_PHASES = 16;
 constexpr uint32_t RESUME_GRID_CAP = 256 * 16;  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
-static int ensure_phase_buffers(psm_rt* r) {
+// continuation queues of the hand-over schedules: `need` entries at least (a launch over several Pipelines' queues can hold
+// more rays than one Pipeline's currentRayLimit)
+static int ensure_phase_buffers(psm_rt* r, size_t need = 0) {
     psm_ctx* c = r->ctx;
-    if (r->d_phase_mem && r->phase_cap == r->limit) return PSM_OK;
-    if (r->d_phase_mem) { (void)hipStreamSynchronize(c->stream); (void)hipFree(r->d_phase_mem); r->d_phase_mem = nullptr; }
-    const size_t L = r->limit;
+    const size_t want = std::max<size_t>(r->limit, need);
+    if (r->d_phase_mem && r->phase_cap >= want && (need || r->phase_cap == r->limit)) return PSM_OK;
+    // (a group launch runs on another context's stream than r's: nothing on the device may still use the old queues)
+    if (r->d_phase_mem) { (void)(need ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream)); (void)hipFree(r->d_phase_mem); r->d_phase_mem = nullptr; }
+    const size_t L = want;
     const size_t per = L * (4 * 5 + 16 + 4 * STACK_CAP);  // idx, cur, misc, predist, lastTri, head, stack
     PSM_HIP(c, hipMalloc(&r->d_phase_mem, 2 * per + sizeof(uint32_t) * MAX_PHASES));
     char* base = (char*)r->d_phase_mem;
@@ -749,7 +797,7 @@ static int ensure_phase_buffers(psm_rt* r) {
         r->phase_state[k].capacity = (uint32_t)L;
     }
     r->d_phase_cnt = (uint32_t*)(base + 2 * per);
-    r->phase_cap = r->limit;
+    r->phase_cap = (uint32_t)L;
     return PSM_OK;
 }
 
@@ -794,6 +842,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     if (r->trav_n >= MAX_TRAV_OBJECTS) return set_err(c, PSM_ERR_CAPACITY, "more than 16 hierarchies traversed for one ray queue");
     if (b->tri_count > (1u << OBJ_SHIFT)) return set_err(c, PSM_ERR_CAPACITY, "hierarchy too large for the object tag (2^27 triangles)");
     const uint32_t tag = (uint32_t)r->trav_n << OBJ_SHIFT;
+    r->last_objs[r->trav_n] = b;
     r->trav_objs[r->trav_n++] = b;
     std::vector<PhasePlan> plan;
     const int mode = plan_traverse(r, n, chain, plan);
@@ -801,7 +850,8 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         uint32_t grid = ((n + TRAV_BLOCK - 1) / TRAV_BLOCK + 255u) & ~255u;  // a multiple of 8 XCDs x 32 (rt_traverse: vblock)
         TravArgs ta = {};
         ta.qA = r->qA[r->cur]; ta.qB = r->qB[r->cur]; ta.qbases = r->q_bases[r->cur]; ta.qnb = r->q_nb[r->cur]; ta.nrays = n;
-        ta.node32 = b->d_node32; ta.tri48 = b->d_tri48; ta.sm = b->d_small;
+        // (a hierarchy in an arena slot: links and triangle ids in its records count from the arena's start)
+        ta.node32 = b->d_node32 - (size_t)2 * b->node_off; ta.tri48 = b->d_tri48 - (size_t)3 * b->tri_off; ta.sm = b->d_small;
         ta.hit0 = r->hit0; ta.hitN = r->hitN; ta.pool = r->pool; ta.cnt = r->d_cnt; ta.ctr = c->d_counters;
         ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
         ta.cap = 0xFFFFFFFFu;
@@ -860,6 +910,88 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     }
     PSM_HIP(c, hipGetLastError());
     c->rays_traced += n;
+    return PSM_OK;
+}
+
+// One traversal launch over the current queues of n Pipelines (psm_rt_traverse_group). Every Pipeline's hierarchy must sit in
+// a slot of the same psm_arena (or n == 1); the launch goes to `on`'s stream, and the caller has ordered that stream
+// after whatever wrote the queues and before whatever reads the hits. Schedule as launch_rt_traverse chooses it for rts[0]
+// and the launch's total ray count.
+int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner) {
+    psm_ctx* c = on;
+    if (n == 0 || n > (uint32_t)MAX_GROUP) return set_err(c, PSM_ERR_INVALID, "psm_rt_traverse_group: 1..8 Pipelines");
+    TravArgs ta = {};
+    uint64_t total = 0;
+    const uint4* nbase = bvhs[0]->d_node32 - (size_t)2 * bvhs[0]->node_off;
+    const float4* tbase = bvhs[0]->d_tri48 - (size_t)3 * bvhs[0]->tri_off;
+    for (uint32_t k = 0; k < n; k++) {
+        psm_rt* r = rts[k];
+        psm_bvh* b = bvhs[k];
+        if (r->ctx->device != c->device) return set_err(c, PSM_ERR_INVALID, "psm_rt_traverse_group: Pipelines of another device");
+        if (!b->built) return set_err(c, PSM_ERR_STATE, "traverse before build");
+        if (r->trav_n != 0) return set_err(c, PSM_ERR_STATE, "psm_rt_traverse_group: a queue that has been traversed already (multi-BVH chains go through psm_rt_traverse)");
+        if (!r->count_valid) return set_err(c, PSM_ERR_STATE, "psm_rt_traverse_group: a Pipeline's ray count is not known to the host yet");
+        if (b->d_node32 - (size_t)2 * b->node_off != nbase || b->d_tri48 - (size_t)3 * b->tri_off != tbase)
+            return set_err(c, PSM_ERR_INVALID, "psm_rt_traverse_group: the hierarchies must be slots of one psm_arena");
+        GroupQueue& q = ta.gq[k];
+        q.qA = r->qA[r->cur]; q.qB = r->qB[r->cur]; q.qbases = r->q_bases[r->cur]; q.qnb = r->q_nb[r->cur];
+        q.nrays = r->ray_count; q.first = (uint32_t)total; q.sm = b->d_small;
+        q.hit0 = r->hit0; q.hitN = r->hitN; q.pool = r->pool; q.cnt = r->d_cnt; q.pool_cap = r->pool_cap;
+        total += r->ray_count;
+    }
+    if (total == 0) return PSM_OK;
+    if (total > 0xFFFFFF00ull) return set_err(c, PSM_ERR_CAPACITY, "psm_rt_traverse_group: more than 2^32 rays in one launch");
+    const uint32_t N = (uint32_t)total;
+    psm_rt* r0 = owner ? owner : rts[0];   // whose schedule settings and continuation queues the launch uses
+    ta.gn = n;
+    ta.nrays = N;
+    ta.node32 = nbase; ta.tri48 = tbase;
+    ta.ctr = c->d_counters;
+    ta.cap = 0xFFFFFFFFu;
+    std::vector<PhasePlan> plan;
+    const int mode = plan_traverse(r0, N, false, plan);
+    const uint32_t grid = ((N + TRAV_BLOCK - 1) / TRAV_BLOCK + 255u) & ~255u;
+    if (mode == PSM_TRAVERSE_WHOLE || mode == PSM_TRAVERSE_REFILL) {
+        TimedScope ts(c, CAT_TRAVERSE);
+        if (c->counting) rt_traverse<true, false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
+        else rt_traverse<false, false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
+    } else {
+        int rc = ensure_phase_buffers(r0, N + N / 4);   // (headroom: the next round of the same frames may be a little larger)
+        if (rc != PSM_OK) return rc;
+        const size_t np = plan.size() + 1;
+        PSM_HIP(c, hipMemsetAsync(r0->d_phase_cnt, 0, sizeof(uint32_t) * MAX_PHASES, c->stream));
+        uint64_t bound = N;
+        for (size_t p = 0; p < np; p++) {
+            TravArgs ph = ta;
+            ph.cap = p < plan.size() ? plan[p].cap : 0xFFFFFFFFu;
+            ph.min_live = p < plan.size() ? plan[p].min_live : 0u;
+            ph.min_steps = r0->adapt_min_steps;
+            ph.final_rays = mode == PSM_TRAVERSE_ADAPTIVE ? r0->adapt_final_rays : 0u;
+            ph.in_count = p == 0 ? nullptr : r0->d_phase_cnt + (p - 1);
+            ph.in = r0->phase_state[(p + 1) & 1];
+            ph.out = r0->phase_state[p & 1];
+            ph.out_count = r0->d_phase_cnt + p;
+            uint32_t g = grid;
+            if (p > 0) {
+                uint64_t need = (bound + TRAV_BLOCK - 1) / TRAV_BLOCK;
+                g = (uint32_t)(need < RESUME_GRID_CAP ? need : RESUME_GRID_CAP);
+                if (g == 0) g = 1;
+            }
+            TimedScope ts(c, CAT_TRAVERSE_HANDOVER);
+            if (c->counting) rt_traverse<true, false, true, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
+            else rt_traverse<false, false, true, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
+            if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);
+        }
+    }
+    PSM_HIP(c, hipGetLastError());
+    for (uint32_t k = 0; k < n; k++) {
+        psm_rt* r = rts[k];
+        if (r->ray_count == 0) continue;
+        r->last_objs[0] = bvhs[k];
+        r->trav_objs[0] = bvhs[k];
+        r->trav_n = 1;
+        r->ctx->rays_traced += r->ray_count;
+    }
     return PSM_OK;
 }
 

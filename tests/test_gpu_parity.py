@@ -1082,6 +1082,88 @@ def test_frame_split_over_parts_equals_unsplit_frames(psm, oracle, scenes, name,
         np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode,kw", [("whole", {}), ("adaptive", {"min_live": 16, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
+                                     ("phased", {"caps": [3, 9]})], ids=["whole", "adaptive", "phased"])
+def test_one_traversal_launch_over_several_pipelines_is_bit_exact(psm, ctx, oracle, scenes, mode, kw):
+    """psm_rt_traverse_group: three Pipelines with different ray sets, each against ITS OWN hierarchy -- three different
+    scenes in the slots of one Arena, whose traversal records carry arena-wide links and triangle ids -- traced by ONE launch
+    (every schedule: the hand-over mixes rays of all three in its resume waves). Per Pipeline the hits, chains, V and T are
+    the oracle's for its scene; what the hierarchies hand out (topology, boxes, root) is unchanged by the arena."""
+    rng = np.random.RandomState(11)
+    sc = [scenes.sponza_like(n_tris=6007), scenes.cornell(open_top=True), scenes.sponza_like(n_tris=20011)]
+    cap = max(s_["tris"].shape[0] for s_ in sc)
+    arena = psm.Arena(ctx, 3, cap)
+    ths, rts, rays_l, built = [], [], [], []
+    for k, s_ in enumerate(sc):
+        th = psm.TriangleHierarchy(ctx)
+        th.allocate(cap, arena, k)
+        th.loadTriangles(s_["tris"], s_["normals"], s_["mats"])
+        th.build()
+        ob = oracle.build_scene(s_["tris"])
+        _built_equals_oracle(psm, oracle, th, ob)          # arena slot 1, 2: links offset inside, relative outside
+        n = [30000, 777, 50001][k]
+        tri = s_["tris"]
+        tid = rng.randint(0, tri.shape[0], n)
+        wgt = rng.dirichlet((1, 1, 1), n).astype(np.float32)
+        target = (tri[tid] * wgt[:, :, None]).sum(1)
+        origin = (target + rng.normal(0, 1, (n, 3)) * 2.0 + np.array([0, 2, 0])).astype(np.float32)
+        rays = np.zeros(n, psm.RAY_DT)
+        rays["origin"], rays["direct"], rays["color"] = origin, (target - origin).astype(np.float32), 1.0
+        rays["bitfield"] = 1 | (3 << 8)
+        rays["texel"] = np.arange(n) % 100
+        rays["pkey"] = np.arange(n)
+        rt = psm.Pipeline(ctx)
+        rt.resizeBuffers(128, 128)
+        _select_schedule(rt, mode, kw)
+        rt.upload_rays(rays)
+        ths.append(th); rts.append(rt); rays_l.append(rays); built.append(ob)
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    psm.traverse_group(rts, ths)
+    st = ctx.stats()
+    ctx.stats_enable(False, False)
+    V = T = 0
+    for k, s_ in enumerate(sc):
+        oh, oc, ostat = oracle.traverse(built[k]["nodes"], s_["tris"], built[k]["M"], rays_l[k]["origin"], rays_l[k]["direct"], 8)
+        gh, gc = rts[k].download_hits(rays_l[k].shape[0])
+        _hits_equal(gh, gc, oh, oc)
+        V += int(ostat.node_visits); T += int(ostat.tri_tests)
+    assert (st.node_visits, st.tri_tests) == (V, T)
+    for rt in rts:
+        rt.close()
+    for th in ths:
+        th.close()
+    arena.close()
+
+
+@pytest.mark.parametrize("name,w,h,lanes,group,frames", [("cornell_open", 64, 48, 2, 2, 5), ("sponza_small", 160, 90, 4, 2, 7),
+                                                         ("sponza_small", 128, 72, 4, 4, 6), ("sponza_small", 96, 54, 3, 3, 4)])
+def test_grouped_frames_equal_ungrouped_frames(psm, oracle, scenes, name, w, h, lanes, group, frames):
+    """psm_lanes_render_grouped: the lanes form groups whose frames trace every bounce round in one launch over all their
+    queues (each frame against its own rebuilt hierarchy in the batch's arena) -- image, rounds and rays per frame equal
+    psm_lanes_render's for the same seeds; a short last batch (7 frames on groups of 2), one group of all lanes, groups of 3."""
+    scene = _scene(scenes, name)
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+
+    def run(gr):
+        b = psm.FrameBatch(lanes, w, h, seed=19, group=gr)
+        b.allocate(scene["tris"].shape[0])
+        b.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+        b.applyMaterials(ms)
+        res = b.render(frames, scene["eye"], scene["view"])
+        img = b.snapHdr()
+        b.close()
+        return img, res
+    want, wres = run(1)
+    got, gres = run(group)
+    assert gres == wres, (gres, wres)
+    assert np.array_equal(got[..., 3], want[..., 3])
+    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+    assert want[..., :3].max() > 0.05
+
+
 def _three_lights(oracle):
     L = oracle.default_lights(3)
     L[1]["lightVector"] = (-0.5, 0.8, 0.6, 30.0)
