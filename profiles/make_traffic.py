@@ -24,13 +24,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def norm(k):
+    """rt_traverse<COUNT, CHAIN, PHASED, GROUP>: the single-Pipeline instantiations (GROUP = false) keep their three-argument
+    names of rounds 1-2"""
+    k = k.replace("void ", "").split("(")[0]
+    return k.replace(", false>", ">") if k.count(",") == 3 and k.endswith(", false>") else k
+
+
 def per_kernel(tag, sub, want):
     files = glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True)
     out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     if not files:
         return out
     for r in csv.DictReader(open(files[0])):
-        k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+        k = norm(r["Kernel_Name"])
         if want not in k:
             continue
         a = out[k][r["Counter_Name"]]
@@ -44,7 +51,7 @@ def kernel_avg_us(tag, want, sub="kt1"):
     res = {}
     if files:
         for r in csv.DictReader(open(files[0])):
-            k = r["Name"].replace("void ", "").split("(")[0]
+            k = norm(r["Name"])
             if want in k:
                 res[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
     return res

@@ -7,8 +7,9 @@ import sys
 
 
 def short(name):
-    name = name.replace("void ", "")
-    return name.split("(")[0]
+    name = name.replace("void ", "").split("(")[0]
+    # rt_traverse<COUNT, CHAIN, PHASED, GROUP>: GROUP = false keeps the three-argument name of rounds 1-2
+    return name.replace(", false>", ">") if name.count(",") == 3 and name.endswith(", false>") else name
 
 
 def stats(path):
