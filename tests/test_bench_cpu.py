@@ -1,0 +1,61 @@
+"""bench.py's roofline object without a GPU: the arithmetic of price() / roofline() on synthetic launch records.
+
+The contract (task statement (4)): `achieved` = algorithmic bytes per launch / average launch duration of
+the kernel the timed region launches; `peak` 8000 GB/s; `frac` = achieved / peak; the counters' physical figures lead the
+object; a note whenever SURVEY 8(d)'s bytes per step over ms_per_step pass the peak; PMC figures only where a committed
+pass exists for the workload (profiles/traffic_r03.json)."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_roofline_object_arithmetic_and_key_order():
+    bench = importlib.import_module("bench")
+    R, V, T = 6_000_000, 300_000_000, 36_000_000
+    launches, total_ms, steps = 9, 5.0, 1
+    t = bench.price("rt_traverse<false, false, true>", launches, total_ms, R, V, T, 3, steps, "sponza_like", 1920, 1080, "synthetic")
+    alg = R * 44 + V * 64 + T * 36
+    assert abs(t["achieved"] - alg / (total_ms * 1e-3) / 1e9) < 1e-6
+    assert abs(t["algorithmic_bytes_per_launch"] - alg / launches) < 1e-3
+    assert abs(t["avg_launch_ms"] - total_ms / launches) < 1e-12 and t["launches_per_round"] == 3.0
+    assert abs(t["own_record_bytes_per_launch"] - (R * 44 + V * 32 + T * 48) / launches) < 1e-3
+    # the committed counters of the C3 workload are found for this kernel and give an HBM-side rate
+    assert t["traffic"] and t["hbm_frac"] == t["hbm_gbs_of_one_launch"] / 8000.0 and 0.5 < t["l2_hit"] < 1.0
+    whole = bench.price("rt_traverse<false, false, false>", 4, 3.0, R, V, T, 4, steps, "sponza_like", 1920, 1080, "synthetic")
+    roof = bench.roofline(t, whole, alg / steps, 2.5, 5200.0)
+    keys = list(roof)
+    assert keys[:4] == ["bound", "hbm_frac", "valu_issue_utilisation", "timed_schedule_valu_lane_utilisation"]   # physical figures first
+    assert keys[4:10] == ["achieved", "peak", "unit", "frac", "traffic", "frac_note"]
+    assert roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-12
+    assert "not an HBM utilisation" in roof["frac_note"]              # 21.9 GB per 2.5 ms step > 8 TB/s
+    assert roof["bound"].startswith("cache/VALU") and roof["kernel"] == "rt_traverse<false, false, true>"
+    assert roof["single_launch_kernel_alone"]["kernel"] == "rt_traverse<false, false, false>"
+    json.dumps(roof)
+    # no committed pass for a workload -> no counters quoted, and none for tiles / split frames at all
+    other = bench.price("rt_traverse<false, false, true>", launches, total_ms, R, V, T, 3, steps, "cornell", 640, 480, "synthetic")
+    tile = bench.price("rt_traverse<false, false, true>", launches, total_ms, R, V, T, 3, steps, "sponza_like", 1920, 1080, "synthetic", use_pmc=False)
+    for o in (other, tile):
+        assert "traffic" not in o and "hbm_frac" not in o
+    r2 = bench.roofline(other, whole, 1e9, 2.5, 5200.0)
+    assert r2["bound"].startswith("unknown") and r2["hbm_frac"] is None and "frac_note" not in r2 and r2["traffic"] is None
+
+
+def test_committed_traffic_file_matches_its_profiles():
+    """profiles/traffic_r03.json (what bench.py quotes) holds the three traversal kernels of C3 and C5 with the fields the
+    roofline uses, and its in-flight launch average agrees with the committed kernel-trace summary of the same run."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
+    ents = {(e["scene"], e["kernel"]): e for e in d["entries"]}
+    for scene in ("sponza_like", "stress"):
+        for k in ("psm::rt_traverse<false, false, true>", "psm::rt_traverse<false, false, false>"):
+            e = ents[(scene, k)]
+            assert e["traffic_bytes_per_launch"] == 2.0 * e["fetch_bytes_per_launch_raw"] + e["write_bytes_per_launch"]
+            assert 0.3 < e["valu_lane_utilisation"] < 0.7 and e["alone_avg_us"] > 0 and e["sq_per_launch"]["SQ_INSTS_VALU"] > 0
+    tag = {"sponza_like": "c3", "stress": "c5"}
+    for scene, c in tag.items():
+        rows = [l.split() for l in open(os.path.join(ROOT, "profiles", "r03_%s_kt_stats.txt" % c)) if "false, false, tru" in l]
+        avg_us = float(rows[0][-2])
+        assert abs(avg_us - ents[(scene, "psm::rt_traverse<false, false, true>")]["in_flight_avg_us"]) < 0.01 * avg_us
