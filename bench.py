@@ -446,7 +446,8 @@ def roofline(timed, whole, bytes_per_step, ms_per_step, copy_gbs):
         bound = "cache/VALU: records served by L2 + Infinity Cache, VALU issue under divergence"
     else:
         bound = "unknown: no committed PMC pass for this kernel and workload"
-    out = {"bound": bound, "hbm_frac": t.get("hbm_frac"), "valu_issue_utilisation": t.get("valu_issue_utilisation"),
+    out = {"bound": bound, "hbm_frac": t.get("hbm_frac"), "valu_issue_frac_of_step": t.get("valu_issue_frac_of_step"),
+           "valu_issue_utilisation": t.get("valu_issue_utilisation"),
            "timed_schedule_valu_lane_utilisation": t.get("valu_lane_utilisation"),
            "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t["achieved"] / HBM_PEAK_GBS,
            "traffic": traffic}
@@ -718,6 +719,22 @@ def main():
             timed_k["hbm_frac"] = timed_k["hbm_gbs"] / HBM_PEAK_GBS
             timed_k["hbm_frac_note"] = ("HBM-side bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, committed passes) of all traversal "
                                         "launches of a step over traversal_busy_ms_per_step, the time at least one of them is on the chip")
+        if whole_frame and timed_k.get("valu_insts_per_launch"):
+            # How much of the chip's VALU issue capacity the timed step uses: wave-instructions of the traversal and shading
+            # launches of a step (PMC: SQ_INSTS_VALU per launch of the committed passes; the small rounds' single launches scaled by
+            # their rays) x 4 cycles per wave64 instruction per SIMD (the step's mix issues at 3.9-4.3, tools/ubench/valu_rate)
+            # over 1024 SIMDs x 2.4 GHz x ms_per_step. This -- not HBM -- is the roof the path runs under.
+            insts = timed_k["valu_insts_per_launch"] * timed_k["launches"]
+            small = timed_k.get("rounds_below_min_rays_run_single_launch")
+            if small and whole_k.get("valu_insts_per_launch") and whole_k["R"]:
+                insts += whole_k["valu_insts_per_launch"] * whole_k["launches"] * (small["R"] / whole_k["R"])
+            e_sh, _ = pmc_entry(args.scene, args.width, args.height, "rt_shade<false, false>")
+            sh = (e_sh or {}).get("sq_per_launch", {}).get("SQ_INSTS_VALU")
+            if sh:
+                insts += sh * len(round_log)
+            timed_k["valu_wave_insts_per_step"] = insts / args.steps
+            timed_k["valu_issue_frac_of_step"] = insts / args.steps * VALU_QUAD_CYCLES / (SIMDS * 2.4e9 * ms_step * 1e-3)
+            timed_k["valu_issue_frac_of_step_covers"] = "traversal + shading launches" if sh else "traversal launches"
         roof = roofline(timed_k, whole_k, (Rr * 44 + V * 64 + T * 36) / args.steps, ms_step, copy_gbs)  # rank 0's launches
         out = {
             "metric": "Mrays/sec + ms/frame, Sponza 1920x1080 4spp",

@@ -99,6 +99,13 @@ def main():
                            "alone_avg_us from the --lanes 1 kernel traces, in_flight_avg_us from the trace of the bench as timed" % (
                                tag, scene, w, h))
             entries.append(e)
+        # the shading kernel's VALU instruction count per launch (SQ pass as timed): with the traversal kernels' it says how much
+        # of the chip's VALU issue capacity a timed step uses (bench.py: valu_issue_frac_of_step)
+        for k, c in sorted(per_kernel(tag, "sq", "rt_shade").items()):
+            if "SQ_INSTS_VALU" in c:
+                entries.append({"scene": scene, "width": w, "height": h, "kernel": k, "launches_sampled": c["SQ_INSTS_VALU"][0],
+                                "sq_per_launch": {n: a[1] / a[0] for n, a in c.items()},
+                                "source": "rocprofv3 --pmc SQ_* pass of profiles/collect.sh %s (bench as timed)" % tag})
     json.dump({"entries": entries}, open(out_path, "w"), indent=1)
     print("wrote %d entries to %s" % (len(entries), out_path))
 

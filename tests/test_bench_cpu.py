@@ -28,8 +28,8 @@ def test_roofline_object_arithmetic_and_key_order():
     whole = bench.price("rt_traverse<false, false, false>", 4, 3.0, R, V, T, 4, steps, "sponza_like", 1920, 1080, "synthetic")
     roof = bench.roofline(t, whole, alg / steps, 2.5, 5200.0)
     keys = list(roof)
-    assert keys[:4] == ["bound", "hbm_frac", "valu_issue_utilisation", "timed_schedule_valu_lane_utilisation"]   # physical figures first
-    assert keys[4:10] == ["achieved", "peak", "unit", "frac", "traffic", "frac_note"]
+    assert keys[:5] == ["bound", "hbm_frac", "valu_issue_frac_of_step", "valu_issue_utilisation", "timed_schedule_valu_lane_utilisation"]   # physical figures first
+    assert keys[5:11] == ["achieved", "peak", "unit", "frac", "traffic", "frac_note"]
     assert roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-12
     assert "not an HBM utilisation" in roof["frac_note"]              # 21.9 GB per 2.5 ms step > 8 TB/s
     assert roof["bound"].startswith("cache/VALU") and roof["kernel"] == "rt_traverse<false, false, true>"
