@@ -166,7 +166,10 @@ enum {
     PSM_BVH_POSITIONS = 8, /* float[9][triangle_count] world-space triangle soup as loaded */
     PSM_BVH_NORMALS = 9,   /* float[9][triangle_count] per-vertex normals as loaded */
     PSM_BVH_MATERIALS = 10,/* int32[triangle_count] */
-    PSM_BVH_TEXCOORDS = 11 /* float[6][triangle_count] u,v per vertex */
+    PSM_BVH_TEXCOORDS = 11,/* float[6][triangle_count] u,v per vertex */
+    PSM_BVH_NODE32 = 12    /* uint32[8][leaf_count-1] the traversal record of internal node s as the build wrote it: 12 fp16 box
+                              coordinates (left mn.xyz mx.xyz, right mn.xyz mx.xyz) + the two child links, which a node writes
+                              into its PARENT's record (for a hierarchy in an arena slot they count from the arena's start) */
 };
 int psm_bvh_download(psm_bvh* bvh, int what, void* dst, size_t bytes);
 

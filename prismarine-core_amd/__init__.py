@@ -43,7 +43,7 @@ TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAV
                   "refill": TRAVERSE_REFILL}
 
 (BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
- BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS, BVH_TEXCOORDS) = range(12)
+ BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS, BVH_TEXCOORDS, BVH_NODE32) = range(13)
 
 RAY_DT = np.dtype([("origin", "<f4", 3), ("direct", "<f4", 3), ("color", "<f4", 3),
                    ("bitfield", "<i4"), ("texel", "<i4"), ("pkey", "<u4")])
@@ -269,6 +269,7 @@ class TriangleHierarchy:
         if arena is not None:
             assert count == arena.max_tris, "a hierarchy in an arena has the arena's capacity"
             self.ctx.check(lib().psm_bvh_create_in_arena(self.ctx._h, arena._h, C.c_uint32(slot), C.byref(self._h)), "psm_bvh_create_in_arena")
+            self._node_off = self._tri_off = slot * count     # what the slot adds to the links / triangle ids of its traversal records
         else:
             self.ctx.check(lib().psm_bvh_create(self.ctx._h, C.c_size_t(count), C.byref(self._h)), "psm_bvh_create")
         self.maxt = count

@@ -586,6 +586,7 @@ int psm_bvh_download(psm_bvh* b, int what, void* dst, size_t bytes) {
         case PSM_BVH_NORMALS: src = b->d_nrm; elem = 36; break;
         case PSM_BVH_MATERIALS: src = b->d_mats; elem = 4; break;
         case PSM_BVH_TEXCOORDS: src = b->d_tex; elem = 24; break;
+        case PSM_BVH_NODE32: src = b->d_node32; elem = 32; break;
         default: return set_err(c, PSM_ERR_INVALID, "psm_bvh_download: unknown item");
     }
     if (bytes > b->cap * elem) return set_err(c, PSM_ERR_CAPACITY, "psm_bvh_download: too many bytes");

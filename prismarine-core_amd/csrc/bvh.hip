@@ -438,6 +438,17 @@ PSM_D int find_split(const uint64_t* __restrict__ keys, int first, int last) {
 // RECORDS: also write the per-node records in the reference's terms (child boxes as 2 x uvec4, links, ranges) that
 // psm_bvh_download hands out for parity checks. Traversal reads node32 only, so a build writes 32 of the 80 bytes per
 // node; the records are produced on demand by running the kernel again on the build's (still resident) inputs.
+// RECORDS = false (the build): the traversal records. A node does not search for its children's splits -- two more binary
+// searches per node, and a wave waits for the longest of its 64 -- : every node finds its PARENT, which costs two key
+// reads, and writes its own id into the parent's record; a parent writes its child boxes and the links of its LEAF children.
+// The parent of the node over [f, l] splits at gap l (the node is its left child) or at gap f - 1 (right child): inside a
+// run of equal codes it is the range of the median recursion one level up; otherwise it is the side whose neighbour shares
+// the longer prefix with the node (nlz(key[l] ^ key[l+1]) against nlz(key[f-1] ^ key[f]); they cannot be equal: the two
+// neighbours would have to differ from the node in the same bit, one above and one below it). The node over [0, count-1]
+// is the root. Every dword of a record has exactly one writer.
+// RECORDS = true: the per-node records in the reference's terms (child boxes as 2 x uvec4, links found by findSplit as
+// build-new.comp does, ranges) that psm_bvh_download hands out for parity checks, produced on demand from the build's
+// (still resident) inputs; it does not touch the traversal records, so the tests can hold one against the other.
 template <bool RECORDS>
 __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ keys, const int32_t* __restrict__ sorted_tri,
                                                 SegTree st, uint32_t* __restrict__ sm, uint4* __restrict__ pairbox,
@@ -448,10 +459,12 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     // reference-shaped records (RECORDS) and everything the parity tests download stay relative to the hierarchy
     int count = (int)sm[SM_COUNT];
     int s = blockIdx.x * 256 + threadIdx.x;
-    if (s == 0) sm[SM_ROOT] = (uint32_t)(count >= 2 ? find_split(keys, 0, count - 1) + node_off : -1);
+    if (!RECORDS && s == 0 && count < 2) sm[SM_ROOT] = (uint32_t)-1;
     if (s >= count - 1) return;
     uint64_t ks = keys[s], ks1 = keys[s + 1];
     int f, l;
+    int parent = -1;       // the gap the parent splits at; -1: not known yet
+    bool is_left = false;  // this node is its parent's left child
     if (ks != ks1) {
         int delta = nlz64(ks ^ ks1);
         // leftmost f with nlz(key[f]^ks) >= delta (monotone towards s)
@@ -502,26 +515,43 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
         for (;;) {
             int m = (f + l) >> 1;
             if (s == m) break;
+            parent = m;                 // the range one level up splits at m; s lies on ...
+            is_left = s < m;            // ... its left side [f, m] or its right side [m + 1, l]
             if (s < m) l = m; else f = m + 1;
         }
     }
-    // children [f,s] and [s+1,l] (splitNode, build-new.comp:70-117; leaf link child-link.comp:34-53)
-    int2 lk;
-    lk.x = (f == s) ? ~sorted_tri[s] : find_split(keys, f, s);
-    lk.y = (s + 1 == l) ? ~sorted_tri[l] : find_split(keys, s + 1, l);
     uint4 lb = key_to_box(seg_query(st, (uint32_t)f, (uint32_t)s));          // refit.comp:91-98
     uint4 rb = key_to_box(seg_query(st, (uint32_t)(s + 1), (uint32_t)l));
     if (RECORDS) {
+        // children [f,s] and [s+1,l] (splitNode, build-new.comp:70-117; leaf link child-link.comp:34-53)
+        int2 lk;
+        lk.x = (f == s) ? ~sorted_tri[s] : find_split(keys, f, s);
+        lk.y = (s + 1 == l) ? ~sorted_tri[l] : find_split(keys, s + 1, l);
         pairbox[2 * (size_t)s + 0] = lb;
         pairbox[2 * (size_t)s + 1] = rb;
         link[s] = lk;
         range[s] = make_int2(f, l);
+        return;
     }
     // traversal record (trace.hip): xyz of both child boxes (the w halves are never read by the
     // slab test) + both links = 32 bytes, one aligned pair of 16-byte loads per visit
+    uint32_t* rec = (uint32_t*)(node32 + 2 * (size_t)s);
     node32[2 * (size_t)s + 0] = make_uint4(lb.x, (lb.y & 0xffffu) | (lb.z << 16), (lb.z >> 16) | (lb.w << 16), rb.x);
-    const int ax = lk.x >= 0 ? lk.x + node_off : ~(~lk.x + tri_off), ay = lk.y >= 0 ? lk.y + node_off : ~(~lk.y + tri_off);
-    node32[2 * (size_t)s + 1] = make_uint4((rb.y & 0xffffu) | (rb.z << 16), (rb.z >> 16) | (rb.w << 16), (uint32_t)ax, (uint32_t)ay);
+    *(uint2*)(rec + 4) = make_uint2((rb.y & 0xffffu) | (rb.z << 16), (rb.z >> 16) | (rb.w << 16));
+    if (f == s) rec[6] = (uint32_t)~(sorted_tri[s] + tri_off);        // leaf children: the parent's to write
+    if (s + 1 == l) rec[7] = (uint32_t)~(sorted_tri[l] + tri_off);
+    // this node's own link, into its parent's record
+    if (f == 0 && l == count - 1) {
+        sm[SM_ROOT] = (uint32_t)(s + node_off);
+        return;
+    }
+    if (parent < 0) {
+        const int dL = f > 0 ? nlz64(keys[f - 1] ^ keys[f]) : -1;
+        const int dR = l < count - 1 ? nlz64(keys[l] ^ keys[l + 1]) : -1;
+        is_left = dR > dL;
+        parent = is_left ? l : f - 1;
+    }
+    ((uint32_t*)(node32 + 2 * (size_t)parent))[is_left ? 6 : 7] = (uint32_t)(s + node_off);
 }
 
 // ---- launch wrappers ----------------------------------------------------------------------------

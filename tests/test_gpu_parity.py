@@ -143,6 +143,17 @@ def _built_equals_oracle(psm, oracle, th, ob):
     pb = th.download(psm.BVH_PAIR_BOX, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
     rg = th.download(psm.BVH_RANGE, np.int32, 2 * (n - 1)).reshape(n - 1, 2)
     assert info.root == oracle.find_split(ob["keys"], 0, n - 1)
+    # the traversal records (written by the build: every node puts its own id into its parent's record) against the
+    # reference-shaped records (links found by findSplit, produced on demand): same links, same twelve box coordinates
+    n32 = th.download(psm.BVH_NODE32, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
+    off_n, off_t = getattr(th, "_node_off", 0), getattr(th, "_tri_off", 0)
+    want_link = np.where(link >= 0, link + off_n, ~(~link + off_t))
+    assert np.array_equal(n32[:, 6:8].view(np.int32), want_link.astype(np.int32))
+    def half(a, k):   # k-th fp16 of a row of packed words
+        return (a[:, k // 2] >> (16 * (k % 2))) & 0xFFFF
+    for side, first in ((0, 0), (4, 6)):      # left box: halves 0..5 of the record, right box: 6..11
+        for j, src in enumerate((0, 1, 2, 4, 5, 6)):   # mn.x mn.y mn.z | mx.x mx.y mx.z of the uvec4 pair (mn.xy mn.zw mx.xy mx.zw)
+            assert np.array_equal(half(n32, first + j), half(pb[:, side:side + 4], src))
     nodes = canonical_nodes(info.root, link, pb, rg, oracle.NODE_DT)
     assert np.array_equal(nodes["pdata"], ob["nodes"]["pdata"])
     assert np.array_equal(nodes["box"], ob["nodes"]["box"])
