@@ -277,20 +277,11 @@ __global__ __launch_bounds__(256) void bvh_morton_count(const float* __restrict_
 
 // exclusive scan of nb block counts in place; total -> *total_out
 __global__ __launch_bounds__(1024) void scan_blocks(uint32_t* __restrict__ g, uint32_t nb, uint32_t* total_out) {
-    __shared__ uint32_t tmp[32];
-    uint32_t tid = threadIdx.x;
-    uint32_t chunk = (nb + 1023u) / 1024u;
-    uint32_t s = min(tid * chunk, nb), e = min(s + chunk, nb);
-    uint32_t sum = 0;
-    for (uint32_t i = s; i < e; i++) sum += g[i];
-    uint32_t total;
-    uint32_t run = block_scan_excl<1024>(sum, tmp, &total);
-    for (uint32_t i = s; i < e; i++) {
-        uint32_t v = g[i];
-        g[i] = run;
-        run += v;
-    }
-    if (tid == 0 && total_out) *total_out = total;
+    // (one workgroup; a thread that walks its own contiguous chunk instead reads and writes one cache line per lane and
+    // instruction: 55 us for C5's 39 k counts, 17 us this way)
+    __shared__ uint32_t tmp[33];
+    const uint32_t total = block_scan_array_1024(g, g, nb, tmp);
+    if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
 // canonical leaf slot `to` = rank among kept triangles in ascending t (SURVEY a-8)

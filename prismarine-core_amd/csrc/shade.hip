@@ -707,18 +707,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
 __global__ __launch_bounds__(1024) void rt_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t limit,
                                                        uint32_t* __restrict__ bases, uint32_t* __restrict__ cnt,
                                                        DevCounters* __restrict__ ctr, uint32_t* __restrict__ host_cnt) {
-    __shared__ uint32_t tmp[32];
-    uint32_t tid = threadIdx.x;
-    uint32_t chunk = (nb + 1023u) / 1024u;
-    uint32_t s = min(tid * chunk, nb), e = min(s + chunk, nb);
-    uint32_t sum = 0;
-    for (uint32_t i = s; i < e; i++) sum += counts[i];
-    uint32_t total;
-    uint32_t run = block_scan_excl<1024>(sum, tmp, &total);
-    for (uint32_t i = s; i < e; i++) {
-        bases[i] = run;
-        run += counts[i];
-    }
+    __shared__ uint32_t tmp[33];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total = block_scan_array_1024(counts, bases, nb, tmp);
     if (tid == 0) {
         bases[nb] = total;
         uint32_t next = total < limit ? total : limit;  // canonical overflow rule: rays past currentRayLimit are dropped
