@@ -752,11 +752,12 @@ __global__ __launch_bounds__(256) void rt_sample(uint32_t w, uint32_t h, uint32_
             int cx = bx + x, cy = by + y;
             if (cx >= 0 && cx < (int)w && cy >= 0 && cy < (int)h) {
                 int ts = cy * (int)w + cx;
-                if (!t_flag[ts]) continue;
+                // (the position test first, the flag only for a texel whose sample lands in this pixel: of the nine
+                // candidates of a 1:1 grid one does, and the other eight no longer cost a flag read -- same condition)
                 float2 co = t_coord[ts];
                 float sx = co.x * (float)dw, sy = co.y * (float)dh;
                 float dx = (sx - (float)px) + 0.00001f, dy = (sy - (float)py) + 0.00001f;
-                if (dx >= 0.0f && dx < 1.0f && dy >= 0.0f && dy < 1.0f) {
+                if (dx >= 0.0f && dx < 1.0f && dy >= 0.0f && dy < 1.0f && t_flag[ts]) {
                     samplecount++;
                     float4 s = t_sum[ts];
                     n0 += s.x; n1 += s.y; n2 += s.z;
