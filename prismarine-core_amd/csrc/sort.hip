@@ -12,8 +12,8 @@
 //                    order and written out as coalesced runs: 12 B/key read + 12 B/key written per pass
 // = 200 B/key and 10 launches, against 256 B/key and 24 launches for the three-kernel passes
 // (radix_hist / radix_scan / radix_scatter below). Measured on MI355X (tools/sort_bench.py) the
-// three-kernel passes are FASTER at every size -- 0.120 vs 0.146 ms for 262 267 keys, 0.32 vs 0.53 ms for 2 M,
-// 0.87 vs 0.96 ms for 10 M: a look-back hop is a ~1 us round trip through L2 across XCDs and the tiles of a pass
+// three-kernel passes are FASTER at every size -- 0.113 vs 0.146 ms for 262 267 keys, 0.21 vs 0.53 ms for 2 M,
+// 0.77 vs 0.93 ms for 10 M (round 3's tile shapes, pass_tile below): a look-back hop is a ~1 us round trip through L2 across XCDs and the tiles of a pass
 // all start together (the chip holds as many tiles as a pass has), so the look-back chain costs more than the
 // two extra launches and the 8 B/key it saves. The three-kernel pass is therefore the default;
 // psm_sort_set_algorithm(ctx, 1) selects the one-sweep sort, and the parity tests run both.
@@ -220,16 +220,17 @@ __global__ __launch_bounds__(THREADS) void radix_hist(const uint64_t* __restrict
 // (row-major ghist[digit][tile]); the row total goes to totals[digit]. The cross-digit base is a
 // 256-wide scan that every scatter workgroup redoes from `totals` (pfx-work.comp:34-70 did both
 // scans in ONE workgroup for the whole grid).
-__global__ __launch_bounds__(256) void radix_scan(uint32_t* __restrict__ g, uint32_t numTiles,
-                                                  uint32_t* __restrict__ totals) {
-    __shared__ uint32_t tmp[8];
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_scan(uint32_t* __restrict__ g, uint32_t numTiles,
+                                                      uint32_t* __restrict__ totals) {
+    __shared__ uint32_t tmp[THREADS / 64 + 1];
     uint32_t* row = g + (size_t)blockIdx.x * numTiles;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < numTiles; base += 256) {
+    for (uint32_t base = 0; base < numTiles; base += THREADS) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < numTiles ? row[i] : 0u;
         uint32_t total;
-        uint32_t ex = block_scan_excl<256>(v, tmp, &total);
+        uint32_t ex = block_scan_excl<THREADS>(v, tmp, &total);
         if (i < numTiles) row[i] = carry + ex;
         carry += total;
     }
@@ -390,7 +391,8 @@ static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
         int shift = pass * 8;
         radix_hist<ITEMS, THREADS><<<numTiles, THREADS, 0, c->stream>>>(kin, c->sort_hist, numTiles, (uint32_t)n_max, d_n, shift);
         uint32_t* totals = c->sort_hist + (size_t)256 * numTiles;
-        radix_scan<<<256, 256, 0, c->stream>>>(c->sort_hist, numTiles, totals);
+        if (numTiles > 512u) radix_scan<1024><<<256, 1024, 0, c->stream>>>(c->sort_hist, numTiles, totals);   // (10 M keys: 2442 tiles, 3 strips instead of 10)
+        else radix_scan<256><<<256, 256, 0, c->stream>>>(c->sort_hist, numTiles, totals);
         radix_scatter<ITEMS, THREADS><<<numTiles, THREADS, 0, c->stream>>>(kin, vin, kout, vout, c->sort_hist, totals, numTiles,
                                                               (uint32_t)n_max, d_n, shift);
         uint64_t* tk = kin; kin = kout; kout = tk;
