@@ -41,6 +41,7 @@ def main():
     rec = []
     O.render_frames(sc, W, H, frames=1, seed=1000, nthreads=8, built=ob, record=rec, frame_streams=True)
     prev_n = None
+    prev_steps_by_texel = None
     for r in rec:
         rays = r["rays"]
         v, _ = O.traverse_visits(ob["nodes"], sc["tris"], ob["M"], rays["origin"], rays["direct"], 8)
@@ -52,6 +53,18 @@ def main():
         # a shading workgroup turns 256 input rays into one segment: its mean size is 256 * n / (rays of the round before)
         G = 256 if prev_n is None else max(64, int(round(256.0 * n / prev_n)))
         prev_n = n
+        # the step count of the ray(s) of the round before at the same texel: what a shading workgroup could know
+        texel = rays["texel"].astype(np.int64) if "texel" in rays.dtype.names else rays["origin"][:, 3].view(np.int32).astype(np.int64)
+        if prev_steps_by_texel is not None:
+            parent = prev_steps_by_texel[texel]
+            print("   correlation of a ray's steps with its texel's steps in the round before: %.3f" % float(np.corrcoef(parent, steps)[0, 1]))
+        else:
+            parent = np.zeros(n, dtype=np.int64)
+        acc = np.zeros(W * H, dtype=np.float64)
+        cnt = np.zeros(W * H, dtype=np.float64)
+        np.add.at(acc, texel, steps)
+        np.add.at(cnt, texel, 1.0)
+        prev_steps_by_texel = acc / np.maximum(cnt, 1.0)
         ideal = steps.sum() / 64.0
         print("round %d: %d rays, segment ~%d rays; types spec/diffuse/shadow = %s; mean steps by type %s" % (
             r["round"], n, G, np.bincount(typ, minlength=3)[:3].tolist(),
@@ -61,6 +74,8 @@ def main():
             ("by type", reorder(steps, lambda i, g: typ[i], G)),
             ("by type alt", reorder(steps, lambda i, g: typ[i] if g % 2 == 0 else -typ[i], G)),
             ("type+octant alt", reorder(steps, lambda i, g: (typ[i] * 8 + octant[i]) * (1 if g % 2 == 0 else -1), G)),
+            ("by parent steps", reorder(steps, lambda i, g: parent[i] * (1 if g % 2 == 0 else -1), G)),
+            ("parent, 4 G", reorder(steps, lambda i, g: parent[i] * (1 if g % 2 == 0 else -1), 4 * G)),
             ("by steps (bound)", reorder(steps, lambda i, g: steps[i] * (1 if g % 2 == 0 else -1), G)),
         ]
         for name, st in orders:
