@@ -43,7 +43,9 @@ PSM_D Slab slab_child(v3 dr, v3 norig, float mnx, float mny, float mnz, float mx
     s.cube = (tfp >= tNear) & (tfp >= 0.0f);
     s.near = sminf(tNear, tFar);
     float far = smaxf(tNear, tFar);
-    s.hit = ((s.near + PZERO) <= 0.0f) ? far : s.near;
+    // the reference's `near + PZERO <= 0` (:192): a sum of two floats rounds to zero only when it is zero, and its sign is
+    // the exact sum's, so the test is `near <= -PZERO` for every near (NaN: false either way) -- one add less per box
+    s.hit = (s.near <= -PZERO) ? far : s.near;
     return s;
 }
 
@@ -51,11 +53,29 @@ PSM_D Slab slab_child(v3 dr, v3 norig, float mnx, float mny, float mnz, float mx
 // input: near <= hit (hit is near or far), so `near <= INF - PZERO` follows from `hit <= INF - PZERO`; and dirlenInv is
 // in [0, 1e6] or NaN, so where `hit * dirlenInv <= INF - PZERO` holds, `near * dirlenInv <= INF - PZERO` can only fail
 // for near = -inf with dirlenInv = 0, where the predist test is NaN <= predist = false as well.
+// The two tests on hit that remain, `hit <= IP` and `hit * dirlenInv <= IP` (IP = INF - PZERO), are one compare against a
+// per-ray constant (hit_limit below): next to `hit > -PZERO` only hits in (-PZERO, +inf] matter; a rounded product with a
+// factor >= 0 is monotone in hit, so the hits that pass both tests are exactly those up to the largest one that does.
 // (bitwise & on purpose: the operands are computations, && would branch around them -- measured: +7 VALU, +2 branches)
-PSM_D bool child_ok(const Slab& c, float dirlenInv, float toffset, float predist) {
+PSM_D bool child_ok(const Slab& c, float hitMax, float dirlenInv, float toffset, float predist) {
+    return c.cube & (c.hit <= hitMax) & (c.hit > -PZERO) & (((c.near + toffset) * dirlenInv - PZERO) <= predist);
+}
+
+// The largest h with `h <= IP && h * dirlenInv <= IP` (float arithmetic, as directTraverse.comp:425-426 evaluates them).
+// dirlenInv <= 1: the product of a hit >= 0 is at most the hit, so IP itself (a hit in (-PZERO, 0) passes both tests and
+// the limit alike). dirlenInv > 1: the quotient, moved by the ulp or two that the two roundings can be off -- the loops
+// establish the definition, the quotient only makes them short. NaN: NaN, every compare fails as `hit * NaN <= IP` does.
+PSM_D float hit_limit(float dirlenInv) {
     const float IP = INF - PZERO;
-    return c.cube & (c.hit <= IP) & (c.hit * dirlenInv <= IP) & (c.hit > -PZERO) &
-           (((c.near + toffset) * dirlenInv - PZERO) <= predist);
+    if (!(dirlenInv > 1.0f)) return dirlenInv == dirlenInv ? IP : dirlenInv;
+    float t = IP / dirlenInv;   // in (IP * 1e-6, IP): positive and normal, its neighbours are its bit pattern +- 1
+    while (t * dirlenInv > IP) t = __uint_as_float(__float_as_uint(t) - 1u);
+    for (;;) {
+        const float up = __uint_as_float(__float_as_uint(t) + 1u);
+        if (!(up * dirlenInv <= IP)) break;
+        t = up;
+    }
+    return t;
 }
 
 // intersectTriangle, include/vertex.glsl:140-189 (e1, e2 precomputed by bvh_prepare_tris)
@@ -223,6 +243,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     v3 tdir = mk3(td4[0], td4[1], td4[2]);
     float dirlen = len3(tdir) / pmax(len3(direct), 0.000001f);
     float dirlenInv = 1.f / pmax(dirlen, 0.000001f);
+    const float hitMax = hit_limit(dirlenInv);
     v3 dirproj = normalize3(tdir);
 
     // root slab test, intersectCubeSingle (mathlib.glsl:107-126) against [-1e-5, 1+1e-5]^3, :365
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 Slab R = slab_child(divident, norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
                 // straight-line selects from here on (bitwise & on the flags: no short-circuit branches)
                 const bool leftNear = lessEqualF(L.near, R.near);  // :414 (only read when both children are accepted)
-                const bool ogL = child_ok(L, dirlenInv, toffset, predist), ogR = child_ok(R, dirlenInv, toffset, predist);
+                const bool ogL = child_ok(L, hitMax, dirlenInv, toffset, predist), ogR = child_ok(R, hitMax, dirlenInv, toffset, predist);
                 const bool lfL = lk.x < 0, lfR = lk.y < 0;
                 // the flags are lane masks: && / || on values already computed are mask ANDs / ORs (bitwise & | would
                 // promote them to integers and materialise them in VGPRs)
@@ -542,7 +563,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
 struct RayLane {          // one lane's ray in flight
     v3 origin, direct;    // world space (triangle tests)
     v3 divident, norig;   // slab test constants
-    float dirlenInv, toffset, predist;
+    float dirlenInv, hitMax, toffset, predist;
     Baked head;
     int lastTri, bakedCount, cur, sp, it;
 };
@@ -561,6 +582,7 @@ PSM_D bool ray_setup(RayLane& s, const float4 A, const float4 B, const uint32_t*
     v3 tdir = mk3(td4[0], td4[1], td4[2]);
     float dirlen = len3(tdir) / pmax(len3(s.direct), 0.000001f);
     s.dirlenInv = 1.f / pmax(dirlen, 0.000001f);
+    s.hitMax = hit_limit(s.dirlenInv);
     v3 dirproj = normalize3(tdir);
     float rootNear, rootD;
     {   // root slab test, intersectCubeSingle (mathlib.glsl:107-126) against [-1e-5, 1+1e-5]^3, :365
@@ -698,7 +720,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka)
             Slab L = slab_child(s.divident, s.norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
             Slab R = slab_child(s.divident, s.norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
             const bool leftNear = lessEqualF(L.near, R.near);  // :414
-            const bool ogL = child_ok(L, s.dirlenInv, s.toffset, s.predist), ogR = child_ok(R, s.dirlenInv, s.toffset, s.predist);
+            const bool ogL = child_ok(L, s.hitMax, s.dirlenInv, s.toffset, s.predist), ogR = child_ok(R, s.hitMax, s.dirlenInv, s.toffset, s.predist);
             const bool lfL = lk.x < 0, lfR = lk.y < 0;
             const bool leafL = ogL && lfL, leafR = ogR && lfR;
             pl = leafL ? lk.x : 0;   // accepted leaves, :441-448
