@@ -90,6 +90,20 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
 // densely (camera, upload) is one segment: nb = 1.
 constexpr uint32_t QUEUE_SEG = 1024;  // 256 input rays x at most 4 output rays
 
+// Accesses to data that is read or written once per launch (ray queues, hit records): with PSM_STREAM they carry the
+// non-temporal hint, so that these streams do not push the node and triangle records out of L2.
+typedef float psm_f4v __attribute__((ext_vector_type(4)));
+PSM_D float4 ld_stream(const float4* p) {
+    psm_f4v v = __builtin_nontemporal_load((const psm_f4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PSM_D void st_stream(float4* p, float4 v) {
+    psm_f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (psm_f4v*)p);
+}
+PSM_D uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+PSM_D void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 struct RayQueue {
     const float4 *A, *B, *C;   // origin|texel, direct|bitfield, color|pkey
     const uint32_t* bases;     // nb + 1 entries

@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256) void rt_camera(Mat16 camInv, Mat16 projInv, ui
     uint32_t tx = x >> 3;
     uint32_t tw = min(8u, w - tx * 8);
     uint32_t q = tr.local_base * w + tx * 8 * tr.bh + (y - tr.by) * tw + (x - tx * 8);
-    qA[q] = make_float4(orig[0], orig[1], orig[2], __int_as_float((int)idx));
-    qB[q] = make_float4(dir.x, dir.y, dir.z, __int_as_float(bf));
-    qC[q] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(idx));
+    st_stream(&qA[q], make_float4(orig[0], orig[1], orig[2], __int_as_float((int)idx)));
+    st_stream(&qB[q], make_float4(dir.x, dir.y, dir.z, __int_as_float(bf)));
+    st_stream(&qC[q], make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(idx)));
 }
 
 // The gathering rank of a sharded frame samples the whole image (sampler.comp reads every texel's jitter position and
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     const uint32_t nrays = min(a.nrays, a.q.bases[a.q.nb]);  // never past what the queue holds (psm_rt_set_ray_count)
     if (it < nrays) {
         const uint32_t loc = queue_loc(a.q.bases, a.q.nb, nrays, it);
-        float4 A = a.q.A[loc], B = a.q.B[loc], C = a.q.C[loc];
+        float4 A = ld_stream(&a.q.A[loc]), B = ld_stream(&a.q.B[loc]), C = ld_stream(&a.q.C[loc]);
         int in_texel = __float_as_int(A.w);
         uint32_t in_pkey = __float_as_uint(C.w);
         Rng g{in_pkey, 0u, a.time << 5};
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
         ray.fin = mk3(0.f, 0.f, 0.f);
         ray.bf = __float_as_int(B.w);
         bool skipping = false;
-        uint32_t hn = a.hitN[it];
+        uint32_t hn = ld_stream(&a.hitN[it]);
         int n = (int)(hn & 15u);
         uint32_t poff = hn >> 4;
 
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
         // distance behind it are blended in (:88-116)
         bool found = false;
         for (int k = 0; k < n; k++) {
-            Surf h = surface_eval<TEX, MULTI>(k == 0 ? a.hit0[it] : a.pool[poff + k - 1], a.src);
+            Surf h = surface_eval<TEX, MULTI>(k == 0 ? ld_stream(&a.hit0[it]) : a.pool[poff + k - 1], a.src);
             if (!found) {
                 uvt_t = h.t;
                 if (!h.active) { c_normal = h.normal_trav; continue; }
@@ -693,9 +693,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (have[k]) {
-            a.sA[at] = outs[k].A;
-            a.sB[at] = outs[k].B;
-            a.sC[at] = outs[k].C;
+            st_stream(&a.sA[at], outs[k].A);
+            st_stream(&a.sB[at], outs[k].B);
+            st_stream(&a.sC[at], outs[k].C);
             at++;
         }
     }
@@ -759,13 +759,13 @@ __global__ __launch_bounds__(256) void rt_sample(uint32_t w, uint32_t h, uint32_
                 float dx = (sx - (float)px) + 0.00001f, dy = (sy - (float)py) + 0.00001f;
                 if (dx >= 0.0f && dx < 1.0f && dy >= 0.0f && dy < 1.0f && t_flag[ts]) {
                     samplecount++;
-                    float4 s = t_sum[ts];
+                    float4 s = ld_stream(&t_sum[ts]);
                     n0 += s.x; n1 += s.y; n2 += s.z;
                 }
             }
         }
     }
-    float4 xs = presampled[it];
+    float4 xs = ld_stream(&presampled[it]);
     if (samplecount > 0) {
         float sc = (float)samplecount;
         n0 = n0 / sc; n1 = n1 / sc; n2 = n2 / sc;
@@ -776,9 +776,9 @@ __global__ __launch_bounds__(256) void rt_sample(uint32_t w, uint32_t h, uint32_
         xs.y = fmaf(xs.y, divisor, n1 * (1.0f - divisor));
         xs.z = fmaf(xs.z, divisor, n2 * (1.0f - divisor));
         xs.w = (samples_lock > 0) ? pmin(next, (float)(samples_lock - 1)) : next;
-        presampled[it] = xs;
+        st_stream(&presampled[it], xs);
     }
-    filtered[it] = xs;
+    st_stream(&filtered[it], xs);
 }
 
 // dense <-> full-image copy of a tile's per-texel radiance (tile gather): one thread per texel OF THE TILE

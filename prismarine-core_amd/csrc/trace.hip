@@ -24,6 +24,12 @@ constexpr int SM_ROOT = 25;
 
 constexpr int TRAV_BLOCK = 128;
 
+// leaf tests run once PSM_PARK_NUM / PSM_PARK_DEN of a wave's lanes with work wait for one (experiment builds vary it)
+#ifndef PSM_PARK_NUM
+#define PSM_PARK_NUM 1u
+#define PSM_PARK_DEN 2u
+#endif
+
 struct Slab {
     float hit, near;
     bool cube;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         for (int k = 0; k < 16; k++) M[k] = alive ? u2f(qsm[SM_M + k]) : 0.f;
     } else {
         const uint32_t loc = alive ? queue_loc(qbases, qnb, nrays, i) : 0u;  // the queue is segmented (psm_common.h)
-        if (alive) { A = qA[loc]; B = qB[loc]; }
+        if (alive) { A = ld_stream(&qA[loc]); B = ld_stream(&qB[loc]); }
 #pragma unroll
         for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
     }
@@ -286,16 +292,16 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     int it = 0;
     if (resume && alive) {  // pick the ray up where the previous launch left it
         const TravState in = cold_args()->in;
-        uint32_t m = in.misc()[slot];
-        cur = in.cur()[slot];
+        uint32_t m = ld_stream(&in.misc()[slot]);
+        cur = (int)ld_stream((const uint32_t*)&in.cur()[slot]);
         sp = (int)(m & 255u);
         it = (int)((m >> 8) & 0xFFFFu);
         bakedCount = (int)(m >> 24);
-        predist = in.predist()[slot];
-        lastTri = in.lastTri()[slot];
-        float4 hd = in.head()[slot];
+        predist = __uint_as_float(ld_stream((const uint32_t*)&in.predist()[slot]));
+        lastTri = (int)ld_stream((const uint32_t*)&in.lastTri()[slot]);
+        float4 hd = ld_stream(&in.head()[slot]);
         head.u = hd.x; head.v = hd.y; head.t = hd.z; head.tri = __float_as_int(hd.w);
-        for (int k = 0; k < sp; k++) stack[k][tid] = in.stack()[(size_t)k * in.capacity + slot];
+        for (int k = 0; k < sp; k++) stack[k][tid] = (int)ld_stream((const uint32_t*)&in.stack()[(size_t)k * in.capacity + slot]);
         validBox = true;
     }
     uint32_t wsteps = 0;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && nl < min_live));
         // keep stepping the others while fewer than half of the lanes with work wait for a leaf test (with nobody able
         // to step, np == nl: the tests run; with nobody left at all, nl == 0, the wave is done)
-        if (!capHit && 2u * np < nl) continue;
+        if (!capHit && PSM_PARK_DEN * np < PSM_PARK_NUM * nl) continue;
         if (nl == 0u) break;
         if (parkedNow) {  // testIntersectionPacked, :261-309
             // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
@@ -409,13 +415,13 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 base = __shfl(base, leader);
                 if (susp) {
                     const uint32_t o = base + (uint32_t)__popcll(sb & ((1ull << lane_id()) - 1ull));
-                    out.idx()[o] = i;
-                    out.cur()[o] = cur;
-                    out.misc()[o] = (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24);
-                    out.predist()[o] = predist;
-                    out.lastTri()[o] = lastTri;
-                    out.head()[o] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
-                    for (int k = 0; k < sp; k++) out.stack()[(size_t)k * out.capacity + o] = stack[k][tid];
+                    st_stream(&out.idx()[o], i);
+                    st_stream((uint32_t*)&out.cur()[o], (uint32_t)cur);
+                    st_stream(&out.misc()[o], (uint32_t)sp | ((uint32_t)it << 8) | ((uint32_t)bakedCount << 24));
+                    st_stream((uint32_t*)&out.predist()[o], __float_as_uint(predist));
+                    st_stream((uint32_t*)&out.lastTri()[o], (uint32_t)lastTri);
+                    st_stream(&out.head()[o], make_float4(head.u, head.v, head.t, __int_as_float(head.tri)));
+                    for (int k = 0; k < sp; k++) st_stream((uint32_t*)&out.stack()[(size_t)k * out.capacity + o], (uint32_t)stack[k][tid]);
                     validBox = false;
                     suspended = true;
                 }
@@ -515,9 +521,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 }
             }
         }
-        if (count == 0) hit0[i] = make_float4(0.f, 0.f, INF, __int_as_float(-1));
-        else hit0[i] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
-        hitN[i] = count | (off << 4);
+        if (count == 0) st_stream(&hit0[i], make_float4(0.f, 0.f, INF, __int_as_float(-1)));
+        else st_stream(&hit0[i], make_float4(head.u, head.v, head.t, __int_as_float(head.tri)));
+        st_stream(&hitN[i], count | (off << 4));
     }
     if (!resume) break;
     }  // batches
