@@ -233,7 +233,7 @@ PSM_D Surf surface_eval(float4 hit, const SurfSrc& src) {
     s.t = hit.z;
     float4 b = g.tri48[(size_t)3 * tri + 1], c = g.tri48[(size_t)3 * tri + 2];
     v3 d1 = mk3(b.x, b.y, b.z), d2 = mk3(c.x, c.y, c.z);
-    const float* n = g.nrm + (size_t)9 * tri;
+    const float* n = g.nrm + (size_t)9 * tri;   // (cached on purpose, like the triangle records: with the hint 2.40 -> 2.47 ms per frame)
     float vs0 = (1.0f - u) - v, vs1 = u, vs2 = v;
     v3 nor = normalize3(cross3(d1, d2));
     v3 nn = mk3((vs0 * n[0] + vs1 * n[3]) + vs2 * n[6], (vs0 * n[1] + vs1 * n[4]) + vs2 * n[7],

@@ -24,6 +24,12 @@ constexpr int SM_ROOT = 25;
 
 constexpr int TRAV_BLOCK = 128;
 
+// workgroups are dealt to the XCDs in runs of XCD_RUN (a power of two; the grid is a multiple of 8 runs), rt_traverse
+#ifndef PSM_XCD_GROUP
+#define PSM_XCD_GROUP 32
+#endif
+constexpr uint32_t XCD_RUN = PSM_XCD_GROUP;
+
 // leaf tests run once PSM_PARK_NUM / PSM_PARK_DEN of a wave's lanes with work wait for one (experiment builds vary it)
 #ifndef PSM_PARK_NUM
 #define PSM_PARK_NUM 1u
@@ -86,6 +92,7 @@ PSM_D float hit_limit(float dirlenInv) {
 
 // intersectTriangle, include/vertex.glsl:140-189 (e1, e2 precomputed by bvh_prepare_tris)
 PSM_D float tri_test(const float4* __restrict__ tri48, int tri, v3 orig, v3 dir, float& U, float& V) {
+    // (cached: with the non-temporal hint the frame takes 3.03 ms instead of 2.40 -- the 12.6 MB of C3's triangle records live in L2)
     float4 a = tri48[(size_t)3 * tri + 0], b = tri48[(size_t)3 * tri + 1], c = tri48[(size_t)3 * tri + 2];
     v3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
     v3 pvec = cross3(dir, e2);
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     // themselves round-robin. One contiguous eighth of the queue per XCD was 6 % slower (C5: 28 %): the expensive
     // part of the image lands on one XCD. Runs of 32 or 128: 1-2 % faster than plain round-robin serial, equal in
     // flight (tools/run_r02_y.sh). Resume: every wave strides over the continuation queue.
-    constexpr uint32_t XCD_GROUP = 32;
+    constexpr uint32_t XCD_GROUP = XCD_RUN;
     const uint32_t bq = blockIdx.x >> 3;   // position within the XCD's sequence
     const uint32_t vb_ = ((bq / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + (bq % XCD_GROUP);
     const uint32_t vblock = resume ? blockIdx.x : vb_;
@@ -875,7 +882,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     std::vector<PhasePlan> plan;
     const int mode = plan_traverse(r, n, chain, plan);
     {
-        uint32_t grid = ((n + TRAV_BLOCK - 1) / TRAV_BLOCK + 255u) & ~255u;  // a multiple of 8 XCDs x 32 (rt_traverse: vblock)
+        uint32_t grid = ((n + TRAV_BLOCK - 1) / TRAV_BLOCK + (8u * XCD_RUN - 1u)) & ~(8u * XCD_RUN - 1u);  // a multiple of 8 XCDs x XCD_RUN (rt_traverse: vblock)
         TravArgs ta = {};
         ta.qA = r->qA[r->cur]; ta.qB = r->qB[r->cur]; ta.qbases = r->q_bases[r->cur]; ta.qnb = r->q_nb[r->cur]; ta.nrays = n;
         // (a hierarchy in an arena slot: links and triangle ids in its records count from the arena's start)
@@ -978,7 +985,7 @@ int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t 
     ta.cap = 0xFFFFFFFFu;
     std::vector<PhasePlan> plan;
     const int mode = plan_traverse(r0, N, false, plan);
-    const uint32_t grid = ((N + TRAV_BLOCK - 1) / TRAV_BLOCK + 255u) & ~255u;
+    const uint32_t grid = ((N + TRAV_BLOCK - 1) / TRAV_BLOCK + (8u * XCD_RUN - 1u)) & ~(8u * XCD_RUN - 1u);
     if (mode == PSM_TRAVERSE_WHOLE || mode == PSM_TRAVERSE_REFILL) {
         TimedScope ts(c, CAT_TRAVERSE);
         if (c->counting) rt_traverse<true, false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
