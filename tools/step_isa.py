@@ -18,7 +18,7 @@ def main():
         path = "/tmp/psm_trace_step.s"
         src = os.path.join(ROOT, "prismarine-core_amd", "csrc", "trace.hip")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                               "-fno-fast-math", "-S", "--cuda-device-only", "-o", path, src], stderr=subprocess.DEVNULL)
+                               "-fno-fast-math", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", path, src], stderr=subprocess.DEVNULL)
     L = open(path).read().split("\n")
     starts = [(i, l.split(":")[0]) for i, l in enumerate(L) if re.match(r"^_ZN3psm\w+:", l)]
     ends = [i for i, l in enumerate(L) if l.startswith(".Lfunc_end")]
