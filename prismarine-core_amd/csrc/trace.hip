@@ -30,11 +30,8 @@ constexpr int TRAV_BLOCK = 128;
 #endif
 constexpr uint32_t XCD_RUN = PSM_XCD_GROUP;
 
-// leaf tests run once PSM_PARK_NUM / PSM_PARK_DEN of a wave's lanes with work wait for one (experiment builds vary it)
-#ifndef PSM_PARK_NUM
-#define PSM_PARK_NUM 1u
-#define PSM_PARK_DEN 2u
-#endif
+// (leaf tests run once half of a wave's lanes with work wait for one: a third is equal, two thirds and more lose 2-18 %,
+// profiles/r03_park_trigger.txt)
 
 struct Slab {
     float hit, near;
@@ -200,6 +197,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     // with few rays left there is nothing to pack them with: the launch finishes them
     const uint32_t min_live = (PHASED && !(resume && total <= ph.final_rays)) ? ph.min_live : 0u;
     const uint32_t cap = (PHASED && !(resume && total <= ph.final_rays)) ? ph.cap : 0xFFFFFFFFu;
+    const int capI = (int)min(cap, 0x7FFFFFFFu), minLive1 = (int)min_live - 1, minSteps = (int)min(ph.min_steps, 0x7FFFFFFFu);
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     v3 divident = mk3(1.f / dirproj.x, 1.f / dirproj.y, 1.f / dirproj.z);
     v3 norig = mk3(-origined.x * divident.x, -origined.y * divident.y, -origined.z * divident.z);
 
-    bool validBox = alive && root >= 0 && lessF(rootD, INF) && lessF(rootD * dirlenInv, INF) && greaterEqualF(rootD, 0.0f);
+    const bool validRay = alive && root >= 0 && lessF(rootD, INF) && lessF(rootD * dirlenInv, INF) && greaterEqualF(rootD, 0.0f);
 
     // hit state (TResult + bakedStack, :27-45)
     float predist = INF;
@@ -294,8 +292,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     Baked head = {0.f, 0.f, INF, -1};
     Baked extra[BAKED_CAP - 1];
 
+    // sp: entries on the ray's stack, -1 once the ray has no node step left (the flag lives in the register the step
+    // updates anyway: carried as a lane mask of its own it cost the scalar unit a three-instruction merge per step)
     int cur = root;
-    int sp = 0;
+    int sp = validRay ? 0 : -1;
     int it = 0;
     if (resume && alive) {  // pick the ray up where the previous launch left it
         const TravState in = cold_args()->in;
@@ -309,10 +309,11 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         float4 hd = ld_stream(&in.head()[slot]);
         head.u = hd.x; head.v = hd.y; head.t = hd.z; head.tri = __float_as_int(hd.w);
         for (int k = 0; k < sp; k++) stack[k][tid] = (int)ld_stream((const uint32_t*)&in.stack()[(size_t)k * in.capacity + slot]);
-        validBox = true;
     }
-    uint32_t wsteps = 0;
-    bool suspended = false;
+    int wsteps = 0;
+    // handed over (a lane mask of its own on purpose: with the mark kept in a register the hand-over sets -- bakedCount or it
+    // = -1 -- the counting instantiation of the GROUP kernel lost rays, test_one_traversal_launch_over_several_pipelines_is_bit_exact[adaptive-counting]; the two forms are the same program)
+    bool suspendedFlag = false;
     // Leaf tests are deferred, not reordered: a lane that reaches a leaf parks its triangle pair (pl, pr) and
     // sits out the node steps of the others until enough lanes of the wave are parked (or nobody can step),
     // then all of them run the triangle block together. Per ray the sequence of node steps and triangle
@@ -321,11 +322,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     int pl = 0, pr = 0;  // parked leaf links as stored in the node record (~triangle id: negative), 0 = none
     bool pLeftNear = false;
     bool parkedNow = false;  // pl < 0 || pr < 0; false again once the tests have run
+    bool stepping = sp >= 0; // a node step is due: sp >= 0 && !parkedNow (assigned for the whole wave at once, no merge)
     for (;;) {
-        if (validBox && !parkedNow) {
+        if (stepping) {
             {
-                const bool lastIter = it >= MAX_ITERS - 1;  // :383, see below
                 it++;
+                const bool lastIter = it >= MAX_ITERS;  // :383, see below
                 // 32-bit byte offset (the node array is < 4 GiB: 2^27 nodes): one shift, the load adds it to the scalar base
                 const uint4* np = (const uint4*)((const char*)node32 + ((uint32_t)cur << 5));
                 uint4 n0 = np[0], n1 = np[1];
@@ -353,28 +355,35 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 }
                 cur = first;              // the nearer accepted internal child (a dead value when there is none)
                 if (!(intL || intR)) {    // :467-476
-                    sp--;
+                    sp--;        // -1: the stack is empty, the ray has no node step left
                     if (sp >= 0) cur = stack[sp][tid];
-                    else validBox = false;
                 }
                 // :383: the loop runs MAX_ITERS iterations at most; a ray that still has work after its last one stops here
                 // (flagged with the step itself instead of in a branch of its own before the next one: its parked leaves,
                 // if any, are still tested below, exactly as when the flag was raised one wave-step later)
-                const bool capped = validBox && lastIter;
-                validBox = validBox && !capped;
-                if (COUNT) nCap += capped ? 1u : 0u;
+                if (COUNT) nCap += (sp >= 0 && lastIter) ? 1u : 0u;
+                sp = lastIter ? -1 : sp;
             }
         }
         // wave-uniform bookkeeping, in scalar registers: np lanes wait for a leaf test, nl lanes have work of any kind
-        const uint32_t np = (uint32_t)__popcll(lane_mask(parkedNow));
-        const uint32_t nl = np + (uint32_t)__popcll(lane_mask(validBox && !parkedNow));
+        stepping = sp >= 0 && !parkedNow;
+        const int np = __popcll(lane_mask(parkedNow));
+        const int nl = np + __popcll(lane_mask(stepping));
         if (COUNT) dg_steps++;
-        // the cap, or too few lanes with work left to be worth a wave
-        const bool capHit = PHASED && (++wsteps >= cap || (wsteps >= ph.min_steps && nl < min_live));
-        // keep stepping the others while fewer than half of the lanes with work wait for a leaf test (with nobody able
-        // to step, np == nl: the tests run; with nobody left at all, nl == 0, the wave is done)
-        if (!capHit && PSM_PARK_DEN * np < PSM_PARK_NUM * nl) continue;
-        if (nl == 0u) break;
+        // Keep stepping the others while fewer than half of the lanes with work wait for a leaf test (with nobody able to
+        // step, np == nl: the tests run; with nobody left at all, nl == 0, the wave is done) -- unless the launch's cap is
+        // reached or too few lanes have work left to be worth a wave (PHASED). Three differences whose signs are the three
+        // conditions, so that the decision is one AND and one compare in the scalar unit instead of a chain of selects
+        // (the step is bound by scalar issue as much as by vector issue: ~75 instructions of each).
+        int handover = 0;   // >= 0 (PHASED): hand over after the parked tests
+        if (PHASED) {
+            wsteps++;
+            const int thr1 = wsteps >= minSteps ? minLive1 : -1;   // nl > thr1  <=>  nl >= min_live once min_steps have run
+            handover = (thr1 - nl) & (wsteps - capI);              // < 0: enough lanes live and below the cap
+            if ((((np << 1) - nl) & handover) < 0) continue;
+        } else if ((np << 1) < nl) continue;
+        const bool capHit = PHASED && handover >= 0;
+        if (nl == 0) break;
         if (parkedNow) {  // testIntersectionPacked, :261-309
             // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
             const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         if (capHit) {
             // every parked test has just run. Rays with work left and a chain of at most one hit hand their state
             // to the next launch (a longer chain lives in registers / scratch: such a ray, < 0.1 %, finishes here)
-            const bool susp = validBox && bakedCount <= 1;
+            const bool susp = sp >= 0 && bakedCount <= 1;
             const unsigned long long sb = lane_mask(susp);
             if (sb != 0ull) {
                 const TravArgs* K = cold_args();
@@ -429,14 +438,15 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                     st_stream((uint32_t*)&out.lastTri()[o], (uint32_t)lastTri);
                     st_stream(&out.head()[o], make_float4(head.u, head.v, head.t, __int_as_float(head.tri)));
                     for (int k = 0; k < sp; k++) st_stream((uint32_t*)&out.stack()[(size_t)k * out.capacity + o], (uint32_t)stack[k][tid]);
-                    validBox = false;
-                    suspended = true;
+                    sp = -1;
+                    suspendedFlag = true;
                 }
             }
-            if (lane_mask(validBox) == 0ull) break;
+            if (lane_mask(sp >= 0) == 0ull) break;
         }
+        stepping = sp >= 0;   // nobody is parked now
     }
-    if (PHASED && suspended) alive = false;  // its result is written by the launch that finishes it
+    if (PHASED && suspendedFlag) alive = false;  // handed over
     const TravArgs* K = cold_args();
     uint32_t gq_k = 0;
     if (GROUP) {   // the ray's own Pipeline again, and its index there

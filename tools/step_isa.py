@@ -11,6 +11,46 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def walk(body, start):
+    """Follow the hot path of one wave-step: from the block that loads the node record, through the divergent regions
+    (s_cbranch_execz falls through: somebody is in them), taking the wave-level `continue` (the first scalar conditional
+    branch after the lane counts) and every execnz / unconditional branch, until the walk is back at the start."""
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if l.startswith(".LBB")}
+    i, valu, salu, br, mem, seen_counts, steps = start, 0, 0, 0, 0, False, 0
+    while steps < 2000:
+        steps += 1
+        l = body[i]
+        if l.startswith("\tv_"):
+            valu += 1
+        elif l.startswith("\ts_") and not l.startswith("\ts_waitcnt") and not l.startswith("\ts_nop"):
+            salu += 1
+        elif re.match(r"\t(ds_|global_|scratch_|buffer_)", l):
+            mem += 1
+        if "s_bcnt1" in l:
+            seen_counts = True
+        m = re.match(r"\ts_(cbranch_\w+|branch) (\.LBB\w+)", l)
+        if m:
+            br += 1
+            kind, tgt = m.group(1), m.group(2)
+            take = kind == "branch" or kind == "cbranch_execnz" or (seen_counts and kind in ("cbranch_scc1", "cbranch_vccnz", "cbranch_scc0", "cbranch_vccz") and labels.get(tgt, -1) != -1 and not globals().get("_took"))
+            if kind.startswith("cbranch_scc") or kind.startswith("cbranch_vcc"):
+                if seen_counts and not globals().get("_took"):
+                    globals()["_took"] = True
+                    take = True
+                else:
+                    take = False
+            if take:
+                i = labels[tgt]
+                if i <= start <= i + 3 or i == start:
+                    break
+                continue
+        i += 1
+        if i == start:
+            break
+    globals()["_took"] = False
+    return valu, salu, br, mem
+
+
 def main():
     if len(sys.argv) > 1:
         path = sys.argv[1]
@@ -39,6 +79,8 @@ def main():
         br = sum(1 for l in seg if l.startswith("\ts_cbranch"))
         mem = sum(1 for l in seg if re.match(r"\t(ds_|global_|scratch_|buffer_)", l))
         scr = sum(1 for l in seg if "scratch_" in l)
+        hv, hs, hb, hm = walk(body, a)
+        print("%-62s hot path of one wave-step: VALU %3d  SALU %3d (of them %d branches)  memory %d" % (name.replace("_ZN3psm", "")[:62], hv, hs, hb, hm))
         print("%-62s step lines %5d-%5d: VALU %3d  SALU %3d  branches %2d  memory %d (scratch %d); kernel scratch ops %d" % (
             name.replace("_ZN3psm", "")[:62], st + a + 1, st + b + 1, len(valu), salu, br, mem, scr, sum(1 for l in body if "scratch_" in l)))
 
