@@ -22,11 +22,16 @@ namespace psm {
 constexpr int SM_M = 0;
 constexpr int SM_ROOT = 25;
 
-constexpr int TRAV_BLOCK = 128;
+#ifndef PSM_TRAV_BLOCK
+#define PSM_TRAV_BLOCK 64
+#endif
+// one wave per workgroup: its slot (registers, 4 KB of stack) is free the moment the wave ends instead of when its partner
+// does -- equal with frames in flight, 1.7 % faster for a frame alone (3.41 -> 3.35 ms); 256: 2 % slower (round 2)
+constexpr int TRAV_BLOCK = PSM_TRAV_BLOCK;
 
 // workgroups are dealt to the XCDs in runs of XCD_RUN (a power of two; the grid is a multiple of 8 runs), rt_traverse
 #ifndef PSM_XCD_GROUP
-#define PSM_XCD_GROUP 32
+#define PSM_XCD_GROUP 64
 #endif
 constexpr uint32_t XCD_RUN = PSM_XCD_GROUP;
 
@@ -204,10 +209,11 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     int root = GROUP ? -1 : (int)sm[SM_ROOT];
     // fresh rays: one ray per thread of the grid. Workgroups b and b + 8 of a grid share an XCD (round-robin dispatch,
     // observed, a speed matter only) and each XCD has its own 4 MB L2: the grid is dealt so that an XCD walks runs of
-    // 32 consecutive workgroups' rays (4096 rays: two rows of texels, neighbouring parts of the tree), the runs
+    // XCD_RUN consecutive workgroups' rays (4096 rays: two rows of texels, neighbouring parts of the tree), the runs
     // themselves round-robin. One contiguous eighth of the queue per XCD was 6 % slower (C5: 28 %): the expensive
-    // part of the image lands on one XCD. Runs of 32 or 128: 1-2 % faster than plain round-robin serial, equal in
-    // flight (tools/run_r02_y.sh). Resume: every wave strides over the continuation queue.
+    // part of the image lands on one XCD. Runs of 4096 rays are 1-2 % faster than plain round-robin serial, equal in
+    // flight; 1024 rays: 4 % slower in flight, 16 k: 1 %, 64 k: 5 % (profiles/r03_cache_policy_ab.txt: x8, x128, x512
+    // of 128-thread workgroups). Resume: every wave strides over the continuation queue.
     constexpr uint32_t XCD_GROUP = XCD_RUN;
     const uint32_t bq = blockIdx.x >> 3;   // position within the XCD's sequence
     const uint32_t vb_ = ((bq / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + (bq % XCD_GROUP);
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka)
 }
 
 constexpr size_t MAX_PHASES = 16;
-constexpr uint32_t RESUME_GRID_CAP = 256 * 16;  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
+constexpr uint32_t RESUME_GRID_CAP = 256 * 32 / (TRAV_BLOCK / 64);  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
 // continuation queues of the hand-over schedules: `need` entries at least (a launch over several Pipelines' queues can hold
 // more rays than one Pipeline's currentRayLimit)
