@@ -54,7 +54,10 @@ PSM_D Slab slab_child(v3 dr, v3 norig, float mnx, float mny, float mnz, float mx
     float tFar = sminf(sminf(smaxf(tminx, tmaxx), smaxf(tminy, tmaxy)), smaxf(tminz, tmaxz));
     float tfp = tFar + PZERO;
     Slab s;
-    s.cube = (tfp >= tNear) & (tfp >= 0.0f);
+    // the reference's two tests, tfp >= tNear and tfp >= 0 (:189), as one against the larger of the two: maxNum drops a NaN
+    // tNear, but tNear is NaN only when all six plane distances are, and then tFar and tfp are NaN too and the test fails
+    // either way (one compare and one mask AND less per box)
+    s.cube = tfp >= smaxf(tNear, 0.0f);
     s.near = sminf(tNear, tFar);
     float far = smaxf(tNear, tFar);
     // the reference's `near + PZERO <= 0` (:192): a sum of two floats rounds to zero only when it is zero, and its sign is
