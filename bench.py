@@ -168,8 +168,9 @@ class Renderer:
             dist.initial_total = self.rt.tile_texels()
         self.cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
         if use_native:
+            tile_world = w_ if (args.emulate_tile and dist.world == 1) else dist.world   # (an emulated tile is dealt for W ranks)
             self.native = dist.attach_native(  # collective: every rank creates its communicator here (RCCL unless a rehearsal asked otherwise)
-                self.ctx, self.pdist.largest_tile_texels(dist.world, w, h, self.weights) * 16)
+                self.ctx, self.pdist.largest_tile_texels(tile_world, w, h, self.weights) * 16)
             if args.emulate_tile and dist.world == 1:
                 self.native.emulate_tile(r_, w_)
             self.native.set_band_weights(self.weights)
