@@ -16,9 +16,9 @@ def walk(body, start):
     (s_cbranch_execz falls through: somebody is in them), taking the wave-level `continue` (the first scalar conditional
     branch after the lane counts) and every execnz / unconditional branch, until the walk is back at the start."""
     labels = {l.split(":")[0]: i for i, l in enumerate(body) if l.startswith(".LBB")}
-    i, valu, salu, br, mem, seen_counts, steps = start, 0, 0, 0, 0, False, 0
-    while steps < 2000:
-        steps += 1
+    i, valu, salu, br, mem = start, 0, 0, 0, 0
+    seen_counts = took_continue = False
+    for _ in range(2000):
         l = body[i]
         if l.startswith("\tv_"):
             valu += 1
@@ -32,22 +32,18 @@ def walk(body, start):
         if m:
             br += 1
             kind, tgt = m.group(1), m.group(2)
-            take = kind == "branch" or kind == "cbranch_execnz" or (seen_counts and kind in ("cbranch_scc1", "cbranch_vccnz", "cbranch_scc0", "cbranch_vccz") and labels.get(tgt, -1) != -1 and not globals().get("_took"))
+            take = kind in ("branch", "cbranch_execnz")
             if kind.startswith("cbranch_scc") or kind.startswith("cbranch_vcc"):
-                if seen_counts and not globals().get("_took"):
-                    globals()["_took"] = True
-                    take = True
-                else:
-                    take = False
+                take = seen_counts and not took_continue
+                took_continue = took_continue or take
             if take:
                 i = labels[tgt]
-                if i <= start <= i + 3 or i == start:
+                if i <= start <= i + 3:
                     break
                 continue
         i += 1
         if i == start:
             break
-    globals()["_took"] = False
     return valu, salu, br, mem
 
 

@@ -5,9 +5,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8
 rm -rf $REPO/gpurun_out/tile_kt
-rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/tile_kt -- python3 $REPO/bench.py --no-cpu-baseline --no-obj-roundtrip --force-dist --emulate-tile ${TILE:-1/8} --band-weights none --lanes ${LANES:-8} --steps 96 --warmup 8 > $REPO/gpurun_out/tile_kt_bench.json 2> $REPO/gpurun_out/tile_kt.err
+rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/tile_kt -- python3 $REPO/bench.py --no-cpu-baseline --no-obj-roundtrip ${DIST---force-dist} --emulate-tile ${TILE:-1/8} --band-weights none --lanes ${LANES:-8} --steps 96 --warmup 8 > $REPO/gpurun_out/tile_kt_bench.json 2> $REPO/gpurun_out/tile_kt.err
 f=$(find $REPO/gpurun_out/tile_kt -name '*kernel_trace.csv' | head -1)
-python3 $REPO/tools/trace_bins.py $f 5 > $REPO/gpurun_out/tile_bins.txt
+python3 $REPO/tools/trace_bins.py $f 5 6 > $REPO/gpurun_out/tile_bins.txt
 python3 $REPO/tools/trace_concurrency.py $f 20 > $REPO/gpurun_out/tile_concurrency.txt
 q=$(python3 - <<PY
 import csv,collections
@@ -17,5 +17,5 @@ print(c.most_common(1)[0][0])
 PY
 )
 python3 $REPO/tools/trace_concurrency.py $f 6 $q > $REPO/gpurun_out/tile_queue.txt
-awk '$2>=8' $REPO/gpurun_out/tile_bins.txt | head -40
+grep -A200 '^queue' $REPO/gpurun_out/tile_bins.txt | head -150
 find $REPO/gpurun_out/tile_kt -name '*kernel_trace.csv' -delete

@@ -44,3 +44,19 @@ for s, e, k, qq in ev:
 print("bin start ms  queues  kernels  idle  traversal-resident  mean-resident")
 for i in range(nb):
     print("%10.1f  %6d  %7d  %5.2f  %8.2f  %8.2f" % (i * binw / 1e6, len(q[i]), n[i], 1 - busy[i] / binw, trav[i] / binw, occ[i] / binw))
+
+# the timeline of one queue in the densest part of the trace: kernel, start, gap to the queue's previous kernel, duration
+if len(sys.argv) > 3:
+    span = float(sys.argv[3]) * 1e6
+    best = max(range(nb), key=lambda i: n[i])
+    a = t0 + best * binw
+    qs = collections.Counter(qq for s, e, k, qq in ev if a <= s < a + span and "rt_shade" in k)
+    qid = qs.most_common(1)[0][0]
+    print("queue %s from %.1f ms on:" % (qid, best * binw / 1e6))
+    prev = None
+    for s, e, k, qq in ev:
+        if qq != qid or s < a or s >= a + span:
+            continue
+        name = k.split("(")[0].replace("void ", "").replace("psm::", "")[:44]
+        print("%9.1f us  +gap %7.1f  dur %8.1f  %s" % ((s - a) / 1e3, (s - prev) / 1e3 if prev else 0, (e - s) / 1e3, name))
+        prev = e
