@@ -48,10 +48,13 @@ struct Lane {
     uint32_t rand = 0;
     uint32_t round = 0;
     uint64_t rays = 0;
+    bool fold_wait = false;   // the lane's stream has yet to wait for the fold of its last frame (see fold)
 };
 
-// sample() of `r` fed with src's frame; stream-ordered against both contexts
-static int fold(psm_rt* r, psm_rt* src) {
+// sample() of `r` fed with src's frame; stream-ordered against both contexts. With `defer` the caller takes over the last
+// step -- src's stream waiting for the sample before anything touches src's texels again -- and may put work that does not
+// touch them (the next frame's rebuild) in front of the wait: hipStreamWaitEvent(src stream, src->ev_fold).
+static int fold(psm_rt* r, psm_rt* src, bool* defer = nullptr) {
     psm_ctx* c = r->ctx;
     if (r == src || c->stream == src->ctx->stream) return launch_rt_sample(r, src);
     int rc = lane_resources(src);
@@ -61,7 +64,8 @@ static int fold(psm_rt* r, psm_rt* src) {
     rc = launch_rt_sample(r, src);
     if (rc != PSM_OK) return rc;
     PSM_HIP(c, hipEventRecord(src->ev_fold, c->stream));
-    PSM_HIP(c, hipStreamWaitEvent(src->ctx->stream, src->ev_fold, 0));  // src's next camera() waits for the fold
+    if (defer) *defer = true;
+    else PSM_HIP(c, hipStreamWaitEvent(src->ctx->stream, src->ev_fold, 0));  // src's next camera() waits for the fold
     return PSM_OK;
 }
 
@@ -122,9 +126,13 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         ln.rand = frame_seeds[f];
         ln.round = 0;
         ln.rays = 0;
-        if (rebuild) {
+        if (rebuild) {   // in front of the wait for the last frame's fold: the rebuild does not touch the texels sample() reads
             int e = psm_bvh_build(ln.bvh, opt);
             if (e != PSM_OK) return e;
+        }
+        if (ln.fold_wait) {
+            PSM_HIP(ln.rt->ctx, hipStreamWaitEvent(ln.rt->ctx->stream, ln.rt->ev_fold, 0));
+            ln.fold_wait = false;
         }
         int e = psm_rt_camera(ln.rt, cam_inv, proj_inv, lcg_next(ln.rand));
         if (e != PSM_OK) return e;
@@ -176,7 +184,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
             for (uint32_t s = 0; s < lanes; s++) {
                 Lane& ln = L[s];
                 if (ln.state == FINISHED && (uint32_t)ln.frame == next_fold) {
-                    if (fold_into) rc = fold(fold_into, ln.rt);
+                    if (fold_into) rc = fold(fold_into, ln.rt, &ln.fold_wait);
                     ln.state = fold_into ? IDLE : FINISHED;
                     ln.frame = fold_into ? -1 : -2;  // without fold_into the lane keeps its frame (frames <= lanes)
                     next_fold++;
