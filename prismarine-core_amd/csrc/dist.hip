@@ -203,7 +203,7 @@ int psm_dist_set_band_weights(psm_dist* d, const uint32_t* weights) {
 namespace psm {
 // psm_dist_gather_tiles; *collective = INT_MIN while the transport's gather has not been called, its result afterwards
 // (a caller that must keep the collective sequence makes the call itself in the first case: dist_gather_placeholder)
-int dist_gather_tiles(psm_dist* d, psm_rt* rt, int* collective) {
+int dist_gather_tiles(psm_dist* d, psm_rt* rt, int* collective, bool* defer_wait = nullptr) {
     *collective = INT_MIN;
     if (!d || !rt || !rt->t_sum) return PSM_ERR_INVALID;
     psm_ctx* c = rt->ctx;
@@ -229,23 +229,40 @@ int dist_gather_tiles(psm_dist* d, psm_rt* rt, int* collective) {
     if (rc != PSM_OK) return rc;
     // ... and hands back: whatever the Pipeline's stream does next (sample(), the next camera()) sees the gathered image
     PSM_HIP(c, hipEventRecord(d->ev_out, d->stream));
-    PSM_HIP(c, hipStreamWaitEvent(c->stream, d->ev_out, 0));
+    if (defer_wait) *defer_wait = true;   // the caller enqueues the wait (a later record of ev_out covers this one: one stream)
+    else PSM_HIP(c, hipStreamWaitEvent(c->stream, d->ev_out, 0));
     return PSM_OK;
 }
 
 // one frame's gather (+ fold on rank 0) inside a sharded batch; `local` is this rank's own status so far. Returns
 // false when the transport itself failed (the sequence cannot be kept: the caller returns `local` at once).
-bool dist_frame_gather(psm_dist* d, psm_rt* rt, psm_rt* fold_into, int& local) {
+bool dist_frame_gather(psm_dist* d, psm_rt* rt, psm_rt* fold_into, int& local, uint32_t* defer) {
     int coll = INT_MIN;
     if (local == PSM_OK) {
-        local = dist_gather_tiles(d, rt, &coll);
-        if (local == PSM_OK && d->rank == 0) local = psm_rt_sample_from(fold_into, rt);
+        bool wait_gather = false, wait_fold = false;
+        local = dist_gather_tiles(d, rt, &coll, defer ? &wait_gather : nullptr);
+        if (local == PSM_OK && d->rank == 0) {
+            // (the Pipeline's stream has not waited for the gather: the accumulating Pipeline's stream does, before it samples)
+            if (wait_gather && hipStreamWaitEvent(fold_into->ctx->stream, d->ev_out, 0) != hipSuccess)
+                local = set_err(rt->ctx, PSM_ERR_HIP, "hipStreamWaitEvent (fold after gather)", hipGetLastError());
+            if (local == PSM_OK) local = defer ? rt_fold(fold_into, rt, &wait_fold) : psm_rt_sample_from(fold_into, rt);
+        }
+        if (defer) *defer |= (wait_gather ? LANE_WAIT_GATHER : 0u) | (wait_fold ? LANE_WAIT_FOLD : 0u);
     }
     if (coll == INT_MIN) {  // this rank did not get as far as the collective call: make it, the others are in it
         if (dist_gather_placeholder(d) != PSM_OK) return false;
         coll = PSM_OK;
     }
     return coll == PSM_OK;
+}
+
+// the waits a deferred gather / fold left to the caller, on the Pipeline's stream
+int lane_flush_waits(psm_dist* d, psm_rt* rt, uint32_t* pending) {
+    psm_ctx* c = rt->ctx;
+    if (*pending & LANE_WAIT_GATHER) PSM_HIP(c, hipStreamWaitEvent(c->stream, d->ev_out, 0));
+    if (*pending & LANE_WAIT_FOLD) PSM_HIP(c, hipStreamWaitEvent(c->stream, rt->ev_fold, 0));
+    *pending = 0;
+    return PSM_OK;
 }
 }  // namespace psm
 

@@ -69,6 +69,8 @@ static int fold(psm_rt* r, psm_rt* src, bool* defer = nullptr) {
     return PSM_OK;
 }
 
+int rt_fold(psm_rt* r, psm_rt* src, bool* defer) { return fold(r, src, defer); }
+
 }  // namespace psm
 
 using namespace psm;
@@ -238,10 +240,12 @@ struct ShardedLanes {
     std::vector<uint32_t> force_until;
     std::vector<LaneState> st;
     std::vector<uint64_t> traced;  // rays handed to traverse per lane since its frame began
+    std::vector<uint32_t> pending; // waits a deferred gather / fold left to this lane's stream (LANE_WAIT_*)
+    psm_dist* dist = nullptr;      // whose gather they wait for
     int rc = PSM_OK;
 
     ShardedLanes(psm_rt* const* r, psm_bvh* const* b, uint32_t n, uint32_t d, uint32_t* rs, uint32_t* rd)
-        : rts(r), bvhs(b), lanes(n), depth(d), rand_state(rs), rounds(rd), force_until(n, 0u), st(n, FINISHED), traced(n, 0ull) {}
+        : rts(r), bvhs(b), lanes(n), depth(d), rand_state(rs), rounds(rd), force_until(n, 0u), st(n, FINISHED), traced(n, 0ull), pending(n, 0u) {}
 
     int step(uint32_t s) {  // park, or queue one more round
         psm_rt* r = rts[s];
@@ -261,7 +265,8 @@ struct ShardedLanes {
     // begin a new frame on lane s: build (if rebuild) + camera, then rounds until it parks or a round is in flight
     void start(uint32_t s, uint32_t seed, const float* cam_inv, const float* proj_inv, int rebuild, const double* opt) {
         if (rc != PSM_OK) return;
-        if (rebuild) rc = psm_bvh_build(bvhs[s], opt);
+        if (rebuild) rc = psm_bvh_build(bvhs[s], opt);   // in front of the waits: the rebuild touches nothing a gather or a fold reads
+        if (rc == PSM_OK && pending[s]) rc = lane_flush_waits(dist, rts[s], &pending[s]);
         begin(s, seed, cam_inv, proj_inv);
     }
     // the same without the build (the hierarchy has been rebuilt by somebody else and this lane's stream waits for it)
@@ -382,6 +387,7 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
     const uint32_t gbeg[2] = {0u, h0}, gend[2] = {h0, lanes};
     std::vector<uint32_t> state(lanes, 0u), rounds(lanes, 0u);
     ShardedLanes L(rts, bvhs, lanes, depth, state.data(), rounds.data());
+    L.dist = d;
     // batches: consecutive runs of frames, alternating between the groups
     struct Batch { uint32_t f0, n, g; };
     std::vector<Batch> batches;
@@ -435,7 +441,7 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
         }
         if (rc != PSM_OK) break;
         for (uint32_t k = 0; k < n; k++) {  // frame order; a rank that fails here still takes part in the gathers that are due
-            if (!dist_frame_gather(d, rts[g0 + k], fold_into, local)) { transport_dead = true; break; }
+            if (!dist_frame_gather(d, rts[g0 + k], fold_into, local, &L.pending[g0 + k])) { transport_dead = true; break; }
             if (rounds_out) rounds_out[B.f0 + k] = rounds[g0 + k];
         }
         if (!transport_dead && local == PSM_OK && b + groups < batches.size()) {  // this group's next frames (their camera() waits for the gather: stream order)
@@ -446,6 +452,7 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
     if (!transport_dead && rc == PSM_OK) rc = psm_dist_agree(d, local);  // a failure after the last decision reaches everybody here
     if (local != PSM_OK) rc = local;
     for (uint32_t s = 0; s < lanes; s++) {
+        if (L.pending[s]) (void)lane_flush_waits(d, rts[s], &L.pending[s]);   // the last frames' gathers: nobody rebuilt in front of them
         (void)hipStreamSynchronize(rts[s]->ctx->stream);
         rts[s]->in_flight = 1;
     }

@@ -309,7 +309,12 @@ int launch_rt_unpack_all(psm_rt* r, hipStream_t stream, const float* d_all, cons
 // dist.hip: pieces of the sharded batch that lanes.hip's pipelined scheduler shares
 int dist_reserve(psm_dist* d, uint32_t w, uint32_t h);
 int dist_gather_placeholder(psm_dist* d);
-bool dist_frame_gather(psm_dist* d, psm_rt* rt, psm_rt* fold_into, int& local);
+// `defer` (may be null): the caller takes over the Pipeline's stream waiting for the gather (and, on rank 0, for the fold) --
+// one bit each, LANE_WAIT_GATHER / LANE_WAIT_FOLD -- and may put its next rebuild in front of the waits (lane_flush_waits)
+bool dist_frame_gather(psm_dist* d, psm_rt* rt, psm_rt* fold_into, int& local, uint32_t* defer = nullptr);
+enum { LANE_WAIT_GATHER = 1u, LANE_WAIT_FOLD = 2u };
+int lane_flush_waits(psm_dist* d, psm_rt* rt, uint32_t* pending);
+int rt_fold(psm_rt* r, psm_rt* src, bool* defer);   // lanes.hip: sample() of r fed with src's frame
 int launch_rt_gather_queue(psm_rt* r, float4* d_dense, uint32_t m);  // current queue in queue order: A | B | C, m rays each
 uint32_t tile_texel_count(const psm_rt* r);
 }  // namespace psm
