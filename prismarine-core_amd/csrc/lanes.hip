@@ -49,17 +49,21 @@ struct Lane {
     uint32_t round = 0;
     uint64_t rays = 0;
     bool fold_wait = false;   // the lane's stream has yet to wait for the fold of its last frame (see fold)
+    int next = -1;            // the frame the lane claimed when its last one ended, -1: none
+    bool marked = false;      // ... and its rebuild is queued behind a mark of the old frame's end (ev_fold)
 };
 
 // sample() of `r` fed with src's frame; stream-ordered against both contexts. With `defer` the caller takes over the last
 // step -- src's stream waiting for the sample before anything touches src's texels again -- and may put work that does not
 // touch them (the next frame's rebuild) in front of the wait: hipStreamWaitEvent(src stream, src->ev_fold).
-static int fold(psm_rt* r, psm_rt* src, bool* defer = nullptr) {
+// `recorded`: src->ev_fold already marks the end of src's frame on src's stream (the caller recorded it before it queued
+// further work there that the sample need not wait for).
+static int fold(psm_rt* r, psm_rt* src, bool* defer = nullptr, bool recorded = false) {
     psm_ctx* c = r->ctx;
     if (r == src || c->stream == src->ctx->stream) return launch_rt_sample(r, src);
     int rc = lane_resources(src);
     if (rc != PSM_OK) return rc;
-    PSM_HIP(c, hipEventRecord(src->ev_fold, src->ctx->stream));
+    if (!recorded) PSM_HIP(c, hipEventRecord(src->ev_fold, src->ctx->stream));
     PSM_HIP(c, hipStreamWaitEvent(c->stream, src->ev_fold, 0));
     rc = launch_rt_sample(r, src);
     if (rc != PSM_OK) return rc;
@@ -119,16 +123,32 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
         return PSM_OK;
     };
-    auto finish = [&](Lane& ln) {
+    uint32_t next_frame = 0;
+    // A frame has ended: its lane waits for its turn to fold (frame order). The lane's NEXT frame is claimed here and its
+    // rebuild queued at once -- it touches nothing the fold reads -- so a lane that ends out of turn does not sit idle.
+    auto finish = [&](Lane& ln) -> int {
         ln.state = FINISHED;
         if (results) { results[ln.frame].rounds = ln.round; results[ln.frame].rays = ln.rays; }
+        ln.next = -1;
+        ln.marked = false;
+        if (fold_into && next_frame < frames) {
+            ln.next = (int)next_frame++;
+            if (rebuild && fold_into->ctx->stream != ln.rt->ctx->stream) {
+                // the end of the frame, marked before the rebuild goes onto the stream: the sample waits for the mark only
+                PSM_HIP(ln.rt->ctx, hipEventRecord(ln.rt->ev_fold, ln.rt->ctx->stream));
+                ln.marked = true;
+                return psm_bvh_build(ln.bvh, opt);
+            }
+        }
+        return PSM_OK;
     };
-    auto start = [&](Lane& ln, uint32_t f) -> int {
+    // frame f on lane ln; `built`: its rebuild has been queued already (finish)
+    auto start = [&](Lane& ln, uint32_t f, bool built) -> int {
         ln.frame = (int)f;
         ln.rand = frame_seeds[f];
         ln.round = 0;
         ln.rays = 0;
-        if (rebuild) {   // in front of the wait for the last frame's fold: the rebuild does not touch the texels sample() reads
+        if (rebuild && !(built && ln.marked)) {   // in front of the wait for the last frame's fold: the rebuild does not touch the texels sample() reads
             int e = psm_bvh_build(ln.bvh, opt);
             if (e != PSM_OK) return e;
         }
@@ -138,7 +158,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
         }
         int e = psm_rt_camera(ln.rt, cam_inv, proj_inv, lcg_next(ln.rand));
         if (e != PSM_OK) return e;
-        if (depth == 0 || ln.rt->ray_count < 32) { finish(ln); return PSM_OK; }  // Pipeline.inl:459-461
+        if (depth == 0 || ln.rt->ray_count < 32) return finish(ln);  // Pipeline.inl:459-461
         ln.state = RUNNING;
         return queue_round(ln);
     };
@@ -149,14 +169,14 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     double issue_s = 0.0, gpu_wait_s = 0.0, react_s = 0.0;  // profile: issue -> count seen, count seen -> next issue
     uint32_t waits = 0;
     std::vector<clk::time_point> t_issued(lanes), t_seen(lanes);
-    uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
+    uint32_t next_fold = 0, idle_spins = 0;
     while (rc == PSM_OK && next_fold < frames) {
         bool progressed = false;
         for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
             Lane& ln = L[s];
             if (ln.state == IDLE && next_frame < frames) {
                 const clk::time_point t0 = clk::now();
-                rc = start(ln, next_frame++);
+                rc = start(ln, next_frame++, false);
                 t_issued[s] = clk::now();
                 issue_s += std::chrono::duration<double>(t_issued[s] - t0).count();
                 progressed = true;
@@ -170,7 +190,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
                 waits++;
                 ln.rt->ray_count = *ln.rt->h_cnt;  // what reloadQueuedRays learns (Pipeline.inl:325-359)
                 ln.rt->count_valid = true;
-                if (ln.round >= depth || ln.rt->ray_count < 32) finish(ln);
+                if (ln.round >= depth || ln.rt->ray_count < 32) rc = finish(ln);
                 else {
                     const clk::time_point t0 = clk::now();
                     rc = queue_round(ln);
@@ -186,11 +206,17 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
             for (uint32_t s = 0; s < lanes; s++) {
                 Lane& ln = L[s];
                 if (ln.state == FINISHED && (uint32_t)ln.frame == next_fold) {
-                    if (fold_into) rc = fold(fold_into, ln.rt, &ln.fold_wait);
+                    if (fold_into) rc = fold(fold_into, ln.rt, &ln.fold_wait, ln.marked);
                     ln.state = fold_into ? IDLE : FINISHED;
                     ln.frame = fold_into ? -1 : -2;  // without fold_into the lane keeps its frame (frames <= lanes)
                     next_fold++;
                     again = progressed = true;
+                    if (rc == PSM_OK && fold_into && ln.next >= 0) {   // the frame it claimed when it ended (rebuild queued there)
+                        const clk::time_point t0 = clk::now();
+                        rc = start(ln, (uint32_t)ln.next, true);
+                        t_issued[s] = clk::now();
+                        issue_s += std::chrono::duration<double>(t_issued[s] - t0).count();
+                    }
                     break;
                 }
             }
