@@ -167,6 +167,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
     double issue_s = 0.0, gpu_wait_s = 0.0, react_s = 0.0;  // profile: issue -> count seen, count seen -> next issue
+    double turn_wait_s = 0.0;                                 // profile: frame ended -> its turn to fold
     uint32_t waits = 0;
     std::vector<clk::time_point> t_issued(lanes), t_seen(lanes);
     uint32_t next_fold = 0, idle_spins = 0;
@@ -190,7 +191,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
                 waits++;
                 ln.rt->ray_count = *ln.rt->h_cnt;  // what reloadQueuedRays learns (Pipeline.inl:325-359)
                 ln.rt->count_valid = true;
-                if (ln.round >= depth || ln.rt->ray_count < 32) rc = finish(ln);
+                if (ln.round >= depth || ln.rt->ray_count < 32) { rc = finish(ln); t_issued[s] = clk::now(); }
                 else {
                     const clk::time_point t0 = clk::now();
                     rc = queue_round(ln);
@@ -206,6 +207,7 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
             for (uint32_t s = 0; s < lanes; s++) {
                 Lane& ln = L[s];
                 if (ln.state == FINISHED && (uint32_t)ln.frame == next_fold) {
+                    turn_wait_s += std::chrono::duration<double>(clk::now() - t_issued[s]).count();
                     if (fold_into) rc = fold(fold_into, ln.rt, &ln.fold_wait, ln.marked);
                     ln.state = fold_into ? IDLE : FINISHED;
                     ln.frame = fold_into ? -1 : -2;  // without fold_into the lane keeps its frame (frames <= lanes)
@@ -235,8 +237,8 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     if (profile) {
         const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
         fprintf(stderr, "psm_lanes_render: %u frames on %u lanes, wall %.3f ms, issuing %.3f ms (%.0f %%); per round: issued -> count seen "
-                        "%.1f us\n", frames, lanes, wall * 1e3, issue_s * 1e3, 100.0 * issue_s / wall,
-                waits ? gpu_wait_s * 1e6 / waits : 0.0);
+                        "%.1f us; per frame: ended -> its turn to fold %.1f us\n", frames, lanes, wall * 1e3, issue_s * 1e3, 100.0 * issue_s / wall,
+                waits ? gpu_wait_s * 1e6 / waits : 0.0, frames ? turn_wait_s * 1e6 / frames : 0.0);
         (void)react_s;
     }
     return rc;
