@@ -14,7 +14,6 @@ constexpr int SM_COUNT = 24;
 constexpr int SM_ROOT = 25;
 constexpr int SM_BFLOAT = 26;
 constexpr int SM_WORDS = 64;
-constexpr int SHADE_BLOCK = 256;
 
 int set_err(psm_ctx* c, int code, const char* what, hipError_t e) {
     if (c) {
@@ -668,7 +667,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     size_t nb = (L + SHADE_BLOCK - 1) / SHADE_BLOCK;
     int rc = PSM_OK;
     auto A = [&](int x) { if (rc == PSM_OK) rc = x; };
-    for (int q = 0; q < 2; q++) {  // one segment of QUEUE_SEG slots per shading workgroup (256 rays in, at most 4 x 256 out)
+    for (int q = 0; q < 2; q++) {  // one segment of QUEUE_SEG slots per shading workgroup (SHADE_BLOCK rays in, at most 4 x as many out)
         A(dev_alloc(c, &r->qA[q], nb * QUEUE_SEG)); A(dev_alloc(c, &r->qB[q], nb * QUEUE_SEG)); A(dev_alloc(c, &r->qC[q], nb * QUEUE_SEG));
         A(dev_alloc(c, &r->q_bases[q], nb + 2));
         r->q_nb[q] = 1;

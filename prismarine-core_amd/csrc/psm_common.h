@@ -88,7 +88,11 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
 // the next round reads the rays THROUGH this map, so the compacting copy of reloadQueuedRays (Pipeline.inl:325-359:
 // three buffer copies per round there, one gather + scatter of every ray here in round 1) is gone. A queue written
 // densely (camera, upload) is one segment: nb = 1.
-constexpr uint32_t QUEUE_SEG = 1024;  // 256 input rays x at most 4 output rays
+#ifndef PSM_SHADE_BLOCK
+#define PSM_SHADE_BLOCK 128   // (256: 0.7 % slower with frames in flight -- a 4-wave workgroup waits longer for room next to one-wave traversal workgroups; 64: equal in flight, 1 % slower alone)
+#endif
+constexpr int SHADE_BLOCK = PSM_SHADE_BLOCK;           // rays a shading workgroup takes from the queue
+constexpr uint32_t QUEUE_SEG = 4u * SHADE_BLOCK;       // ... and the slots of its output segment: at most 4 rays out per ray in
 
 // Accesses to data that is read or written once per launch (ray queues, hit records): with PSM_STREAM they carry the
 // non-temporal hint, so that these streams do not push the node and triangle records out of L2.

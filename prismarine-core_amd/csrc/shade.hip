@@ -21,7 +21,6 @@ namespace psm {
 
 constexpr float TWO_PI_F = 6.2831853071795864769252867665590057683943f;
 constexpr float SQRT_OF_ONE_THIRD_F = 0.5773502691896257645091487805019574556476f;
-constexpr int SHADE_BLOCK = 256;
 static_assert(QUEUE_SEG == SHADE_BLOCK * 4, "one segment holds a shading workgroup's output rays");
 
 // ray bitfield, include/structs.glsl:73-78
