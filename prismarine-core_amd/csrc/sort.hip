@@ -361,8 +361,10 @@ static bool sort_uses_passes(const psm_ctx* c, size_t n_max) { return c->sort_al
 // keys: 0.79 against 0.88 ms at 10 M keys (16 waves per CU hide the scatter's latency where 54 KB of LDS per tile allowed
 // 8), 0.21 against 0.32 ms at 2 M (which ran 256 x 4); small sorts are launch-bound and want enough tiles to fill the chip
 static uint32_t pass_tile(size_t n_max) {
-    if (n_max <= (1u << 17)) return 1024u;   // 256 threads x 4 keys
-    if (n_max <= (1u << 19)) return 2048u;   // 1024 threads x 2 (C3: 262 267 keys, 0.113 against 0.122 ms)
+    // (C3's 262 267 keys: 1024 threads x 2 sort in 0.113 ms against 0.122 alone on the chip -- but next to other frames' one-wave
+    // traversal workgroups a 16-wave workgroup waits for room: the emulated 1/8 tile's frame is 3 % faster with 256 x 4, the
+    // full frame equal, profiles/r03_tile_emulation.txt)
+    if (n_max <= (1u << 19)) return 1024u;   // 256 threads x 4 keys
     return 4096u;                            // 1024 threads x 4
 }
 static size_t sort_words(const psm_ctx* c, size_t n_max) {
@@ -435,8 +437,7 @@ int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, co
     TimedScope ts(c, CAT_SORT);
     if (sort_uses_passes(c, n_max)) {  // (the one-sweep status words hold 30-bit counts)
         c->sort_error_word = nullptr;  // no look-back, nothing to time out (and the buffer it pointed into is reused)
-        if (n_max <= (1u << 17)) return sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n);
-        if (n_max <= (1u << 19)) return sort_passes<2, 1024>(c, d_keys, d_vals, n_max, d_n);
+        if (n_max <= (1u << 19)) return sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n);
         return sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n);
     }
     if (n_max <= (1u << 21)) return sort_onesweep<4>(c, d_keys, d_vals, n_max, d_n);
