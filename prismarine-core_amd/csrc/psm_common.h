@@ -52,13 +52,14 @@ PSM_D uint32_t block_scan_excl(uint32_t v, uint32_t* tmp, uint32_t* total) {
     return base + inc - v;
 }
 
-// exclusive scan of in[0 .. n) into out[0 .. n) by ONE workgroup of 1024 threads (in == out allowed); returns the total to
-// every thread. Strips of 4096 elements: a thread reads and writes four consecutive ones (16-byte accesses, coalesced over
+// exclusive scan of in[0 .. n) into out[0 .. n) by ONE workgroup of NT threads (in == out allowed); returns the total to
+// every thread. Strips of 4 NT elements: a thread reads and writes four consecutive ones (16-byte accesses, coalesced over
 // the wave), a running carry between the strips. `tmp`: 33 words of LDS.
-PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp) {
+template <int NT>
+PSM_D uint32_t block_scan_array(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp) {
     const uint32_t tid = threadIdx.x;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 4096u) {
+    for (uint32_t base = 0; base < n; base += 4u * NT) {
         const uint32_t i = base + 4u * tid;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (i + 3u < n) v = *(const uint4*)(in + i);
@@ -68,7 +69,7 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
             if (i + 2u < n) v.z = in[i + 2u];
         }
         uint32_t strip;
-        const uint32_t ex = carry + block_scan_excl<1024>(v.x + v.y + v.z + v.w, tmp, &strip);
+        const uint32_t ex = carry + block_scan_excl<NT>(v.x + v.y + v.z + v.w, tmp, &strip);
         const uint4 o = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
         if (i + 3u < n) *(uint4*)(out + i) = o;
         else {
@@ -80,6 +81,7 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
     }
     return carry;
 }
+PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp) { return block_scan_array<1024>(in, out, n, tmp); }
 
 // ---- segmented ray queue -------------------------------------------------------------------------------------------
 // A ray queue is a sequence of segments of QUEUE_SEG slots: segment b holds rays bases[b] .. bases[b+1]-1 of the queue

@@ -703,12 +703,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
 
 // reloadQueuedRays, Pipeline.inl:325-359: next count (clamped to currentRayLimit), pool cursor reset -- and the segment
 // bases of the next queue (exclusive scan of the workgroups' output counts; bases[nb] = total)
-__global__ __launch_bounds__(1024) void rt_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t limit,
+template <int NT>
+__global__ __launch_bounds__(NT) void rt_scan_blocks(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t limit,
                                                        uint32_t* __restrict__ bases, uint32_t* __restrict__ cnt,
                                                        DevCounters* __restrict__ ctr, uint32_t* __restrict__ host_cnt) {
     __shared__ uint32_t tmp[33];
     const uint32_t tid = threadIdx.x;
-    const uint32_t total = block_scan_array_1024(counts, bases, nb, tmp);
+    const uint32_t total = block_scan_array<NT>(counts, bases, nb, tmp);
     if (tid == 0) {
         bases[nb] = total;
         uint32_t next = total < limit ? total : limit;  // canonical overflow rule: rays past currentRayLimit are dropped
@@ -923,7 +924,8 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
         else if (any_tex) rt_shade<true, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         else if (multi) rt_shade<false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         else rt_shade<false, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        rt_scan_blocks<<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->q_bases[nxt], r->d_cnt, c->d_counters, r->h_cnt);
+        rt_scan_blocks<1024>   // (256 threads: the same with frames in flight, slower alone)
+           <<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->q_bases[nxt], r->d_cnt, c->d_counters, r->h_cnt);
     }
     r->q_nb[nxt] = nb;
     PSM_HIP(c, hipGetLastError());
