@@ -91,7 +91,7 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
 // three buffer copies per round there, one gather + scatter of every ray here in round 1) is gone. A queue written
 // densely (camera, upload) is one segment: nb = 1.
 #ifndef PSM_SHADE_BLOCK
-#define PSM_SHADE_BLOCK 128   // (256: 0.7 % slower with frames in flight -- a 4-wave workgroup waits longer for room next to one-wave traversal workgroups; 64: equal in flight, 1 % slower alone)
+#define PSM_SHADE_BLOCK 256   // (128: equal to 0.7 % faster with frames in flight, 4 % slower alone (0.332 -> 0.347 ms of shading per C3 frame); 64: equal in flight, slower alone)
 #endif
 constexpr int SHADE_BLOCK = PSM_SHADE_BLOCK;           // rays a shading workgroup takes from the queue
 constexpr uint32_t QUEUE_SEG = 4u * SHADE_BLOCK;       // ... and the slots of its output segment: at most 4 rays out per ray in
