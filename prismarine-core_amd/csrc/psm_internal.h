@@ -238,6 +238,8 @@ struct psm_rt {
     void* d_phase_mem = nullptr;
     psm::TravState phase_state[2] = {};
     uint32_t* d_phase_cnt = nullptr;
+    uint32_t phase_set = 0;        // which of the two sets of continuation counts the next hand-over round uses
+    bool phase_dirty = true;       // the sets are not known to be clear (first use; a round that failed half way)
     uint32_t phase_cap = 0;
     uint32_t phase_caps[7] = {96};  // PSM_TRAVERSE_PHASED: wave-step caps of the launches before the last one
     int phase_caps_n = 1;

@@ -146,6 +146,7 @@ PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(
 // pointers and their links are arena-wide). The rays of queue k are the launch's rays first[k] .. first[k] + nrays[k] - 1;
 // a ray finds its queue, its hierarchy's small block (transform, root) and its result arrays through this table -- in the
 // set-up and in the result write only; the node steps and triangle tests do not know about it.
+constexpr size_t MAX_PHASES = 16;   // launches of a hand-over round at most; two sets of continuation counts alternate between rounds
 constexpr int MAX_GROUP = 8;
 struct GroupQueue {
     const float4 *qA, *qB;
@@ -175,6 +176,7 @@ struct TravArgs {
     uint32_t pool_cap, obj_tag;
     TravState in, out;
     uint32_t* out_count;
+    uint32_t* zero_cnt;           // the last launch of a hand-over round clears the OTHER set of continuation counts (next round's)
     uint32_t gn;                  // GROUP: queues in the table
     GroupQueue gq[MAX_GROUP];
 };
@@ -209,6 +211,10 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (PHASED && blockIdx.x == 0 && tid < (int)MAX_PHASES) {   // (instead of a memset launch in front of every round: 40 us on a lane's critical path with frames in flight)
+        uint32_t* z = cold_args()->zero_cnt;
+        if (z) z[tid] = 0u;
+    }
     int root = GROUP ? -1 : (int)sm[SM_ROOT];
     // fresh rays: one ray per thread of the grid. Workgroups b and b + 8 of a grid share an XCD (round-robin dispatch,
     // observed, a speed matter only) and each XCD has its own 4 MB L2: the grid is dealt so that an XCD walks runs of
@@ -831,7 +837,6 @@ __global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka)
     }
 }
 
-constexpr size_t MAX_PHASES = 16;
 constexpr uint32_t RESUME_GRID_CAP = 256 * 32 / (TRAV_BLOCK / 64);  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
 // continuation queues of the hand-over schedules: `need` entries at least (a launch over several Pipelines' queues can hold
@@ -844,13 +849,14 @@ static int ensure_phase_buffers(psm_rt* r, size_t need = 0) {
     if (r->d_phase_mem) { (void)(need ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream)); (void)hipFree(r->d_phase_mem); r->d_phase_mem = nullptr; }
     const size_t L = want;
     const size_t per = L * (4 * 5 + 16 + 4 * STACK_CAP);  // idx, cur, misc, predist, lastTri, head, stack
-    PSM_HIP(c, hipMalloc(&r->d_phase_mem, 2 * per + sizeof(uint32_t) * MAX_PHASES));
+    PSM_HIP(c, hipMalloc(&r->d_phase_mem, 2 * per + 2 * sizeof(uint32_t) * MAX_PHASES));
     char* base = (char*)r->d_phase_mem;
     for (int k = 0; k < 2; k++) {
         r->phase_state[k].base = base + k * per;
         r->phase_state[k].capacity = (uint32_t)L;
     }
-    r->d_phase_cnt = (uint32_t*)(base + 2 * per);
+    r->d_phase_cnt = (uint32_t*)(base + 2 * per);   // two sets: a round counts in one and its last launch clears the other
+    r->phase_dirty = true;
     r->phase_cap = (uint32_t)L;
     return PSM_OK;
 }
@@ -937,18 +943,23 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
             int rc = ensure_phase_buffers(r);
             if (rc != PSM_OK) return rc;
             const size_t np = plan.size() + 1;
-            PSM_HIP(c, hipMemsetAsync(r->d_phase_cnt, 0, sizeof(uint32_t) * MAX_PHASES, c->stream));
+            if (r->phase_dirty) PSM_HIP(c, hipMemsetAsync(r->d_phase_cnt, 0, 2 * sizeof(uint32_t) * MAX_PHASES, c->stream));   // first use, or a round that failed half way
+            r->phase_dirty = true;
+            uint32_t* const pcnt = r->d_phase_cnt + r->phase_set * MAX_PHASES;
+            uint32_t* const pother = r->d_phase_cnt + (r->phase_set ^ 1u) * MAX_PHASES;
+            r->phase_set ^= 1u;
             uint64_t bound = n;
             for (size_t p = 0; p < np; p++) {
                 TravArgs ph = ta;
+                ph.zero_cnt = p + 1 == np ? pother : nullptr;
                 ph.cap = p < plan.size() ? plan[p].cap : 0xFFFFFFFFu;
                 ph.min_live = p < plan.size() ? plan[p].min_live : 0u;
                 ph.min_steps = r->adapt_min_steps;
                 ph.final_rays = mode == PSM_TRAVERSE_ADAPTIVE ? r->adapt_final_rays : 0u;
-                ph.in_count = p == 0 ? nullptr : r->d_phase_cnt + (p - 1);
+                ph.in_count = p == 0 ? nullptr : pcnt + (p - 1);
                 ph.in = r->phase_state[(p + 1) & 1];
                 ph.out = r->phase_state[p & 1];
-                ph.out_count = r->d_phase_cnt + p;
+                ph.out_count = pcnt + p;
                 uint32_t g = grid;
                 if (p > 0) {
                     uint64_t need = (bound + TRAV_BLOCK - 1) / TRAV_BLOCK;
@@ -960,6 +971,8 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
                 else rt_traverse<false, false, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
                 if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);
             }
+            PSM_HIP(c, hipGetLastError());
+            r->phase_dirty = false;
         }
     }
     PSM_HIP(c, hipGetLastError());
@@ -1013,18 +1026,23 @@ int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t 
         int rc = ensure_phase_buffers(r0, N + N / 4);   // (headroom: the next round of the same frames may be a little larger)
         if (rc != PSM_OK) return rc;
         const size_t np = plan.size() + 1;
-        PSM_HIP(c, hipMemsetAsync(r0->d_phase_cnt, 0, sizeof(uint32_t) * MAX_PHASES, c->stream));
+        if (r0->phase_dirty) PSM_HIP(c, hipMemsetAsync(r0->d_phase_cnt, 0, 2 * sizeof(uint32_t) * MAX_PHASES, c->stream));
+        r0->phase_dirty = true;
+        uint32_t* const pcnt = r0->d_phase_cnt + r0->phase_set * MAX_PHASES;
+        uint32_t* const pother = r0->d_phase_cnt + (r0->phase_set ^ 1u) * MAX_PHASES;
+        r0->phase_set ^= 1u;
         uint64_t bound = N;
         for (size_t p = 0; p < np; p++) {
             TravArgs ph = ta;
+            ph.zero_cnt = p + 1 == np ? pother : nullptr;
             ph.cap = p < plan.size() ? plan[p].cap : 0xFFFFFFFFu;
             ph.min_live = p < plan.size() ? plan[p].min_live : 0u;
             ph.min_steps = r0->adapt_min_steps;
             ph.final_rays = mode == PSM_TRAVERSE_ADAPTIVE ? r0->adapt_final_rays : 0u;
-            ph.in_count = p == 0 ? nullptr : r0->d_phase_cnt + (p - 1);
+            ph.in_count = p == 0 ? nullptr : pcnt + (p - 1);
             ph.in = r0->phase_state[(p + 1) & 1];
             ph.out = r0->phase_state[p & 1];
-            ph.out_count = r0->d_phase_cnt + p;
+            ph.out_count = pcnt + p;
             uint32_t g = grid;
             if (p > 0) {
                 uint64_t need = (bound + TRAV_BLOCK - 1) / TRAV_BLOCK;
@@ -1036,6 +1054,8 @@ int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t 
             else rt_traverse<false, false, true, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
             if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);
         }
+        PSM_HIP(c, hipGetLastError());
+        r0->phase_dirty = false;
     }
     PSM_HIP(c, hipGetLastError());
     for (uint32_t k = 0; k < n; k++) {
