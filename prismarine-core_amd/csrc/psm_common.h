@@ -96,18 +96,19 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
 constexpr int SHADE_BLOCK = PSM_SHADE_BLOCK;           // rays a shading workgroup takes from the queue
 constexpr uint32_t QUEUE_SEG = 4u * SHADE_BLOCK;       // ... and the slots of its output segment: at most 4 rays out per ray in
 
-// Accesses to data that is read or written once per launch (ray queues, hit records): with PSM_STREAM they carry the
+// Accesses to data that is written once per launch (ray queues, hit records, hand-over state, images): the STORES carry the
 // non-temporal hint, so that these streams do not push the node and triangle records out of L2.
+// The LOADS do not, although it would help as much: a non-temporal load of the hand-over state returned what the slot had
+// held two launches earlier (the two state buffers alternate, so a resume wave reads addresses it read then) -- lost and
+// mixed-up rays in tests/test_gpu_parity.py::test_one_traversal_launch_over_several_pipelines_is_bit_exact, depending on
+// code generation and timing; with plain loads (and non-temporal stores) never. DESIGN.md 5.4.
 typedef float psm_f4v __attribute__((ext_vector_type(4)));
-PSM_D float4 ld_stream(const float4* p) {
-    psm_f4v v = __builtin_nontemporal_load((const psm_f4v*)p);
-    return make_float4(v.x, v.y, v.z, v.w);
-}
+PSM_D float4 ld_stream(const float4* p) { return *p; }
 PSM_D void st_stream(float4* p, float4 v) {
     psm_f4v w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, (psm_f4v*)p);
 }
-PSM_D uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+PSM_D uint32_t ld_stream(const uint32_t* p) { return *p; }
 PSM_D void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
 struct RayQueue {
@@ -120,7 +121,9 @@ struct RayQueue {
 PSM_D uint32_t queue_loc(const uint32_t* __restrict__ bases, uint32_t nb, uint32_t total, uint32_t i) {
     if (nb <= 1u) return i;
     uint32_t lo = 0, hi = nb;  // bases[lo] <= i < bases[hi]
-    uint32_t g = (uint32_t)(((uint64_t)i * nb) / total);
+    // a first guess only (the search below is exact from any start): i * nb / total in floats -- the 64-bit integer quotient
+    // this used to be is ~100 scalar and vector instructions per wave in every prologue (hipcc expands it in software)
+    uint32_t g = (uint32_t)((float)i * ((float)nb / (float)total));
     g = g < nb ? g : nb - 1u;
     if (bases[g] <= i) {
         lo = g;

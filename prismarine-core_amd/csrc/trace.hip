@@ -326,8 +326,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         for (int k = 0; k < sp; k++) stack[k][tid] = (int)ld_stream((const uint32_t*)&in.stack()[(size_t)k * in.capacity + slot]);
     }
     int wsteps = 0;
-    // handed over (a lane mask of its own on purpose: with the mark kept in a register the hand-over sets -- bakedCount or it
-    // = -1 -- the counting instantiation of the GROUP kernel lost rays, test_one_traversal_launch_over_several_pipelines_is_bit_exact[adaptive-counting]; the two forms are the same program)
+    // handed over: its result is written by the launch that finishes the ray
     bool suspendedFlag = false;
     // Leaf tests are deferred, not reordered: a lane that reaches a leaf parks its triangle pair (pl, pr) and
     // sits out the node steps of the others until enough lanes of the wave are parked (or nobody can step),
