@@ -32,7 +32,7 @@ for k, s_ in enumerate(sc):
     oh, oc, ostat = oracle.traverse(built[k]["nodes"], s_["tris"], built[k]["M"], rays_l[k]["origin"], rays_l[k]["direct"], 8)
     v, _ = oracle.traverse_visits(built[k]["nodes"], s_["tris"], built[k]["M"], rays_l[k]["origin"], rays_l[k]["direct"], 8)
     orc.append((oh, oc, v))
-for rep in range(3):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
     for k in range(3): rts[k].upload_rays(rays_l[k])
     ctx.stats_enable(False, True); ctx.stats_reset()
     psm.traverse_group(rts, ths)
