@@ -583,7 +583,7 @@ class Pipeline:
         self.ctx.check(lib().psm_rt_set_traverse_phases(self._h, arr, C.c_uint32(len(caps)), C.c_uint32(min_rays)),
                        "psm_rt_set_traverse_phases")
 
-    def setTraverseAdaptive(self, min_live=12, min_steps=8, final_rays=65536, max_launches=3, min_rays=1 << 19):
+    def setTraverseAdaptive(self, min_live=12, min_steps=8, final_rays=65536, max_launches=4, min_rays=1 << 19):
         """psm_rt_set_traverse_adaptive: parameters of the "adaptive" schedule (does not select it)."""
         self.ctx.check(lib().psm_rt_set_traverse_adaptive(self._h, C.c_uint32(min_live), C.c_uint32(min_steps),
                                                           C.c_uint32(final_rays), C.c_uint32(max_launches),
