@@ -286,7 +286,7 @@ int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count,
 /* ADAPTIVE parameters (does not change the mode): hand over below min_live live lanes (2..64) but not before
  * min_steps wave-steps; a resume launch that finds at most final_rays rays waiting finishes them; at most
  * max_launches launches (2..15) per intersection; intersections under min_rays rays run WHOLE.
- * Defaults: 12, 8, 65536, 3, 2^19. */
+ * Defaults: 12, 8, 65536, 4, 2^19. */
 int psm_rt_set_traverse_adaptive(psm_rt* rt, uint32_t min_live, uint32_t min_steps, uint32_t final_rays,
                                  uint32_t max_launches, uint32_t min_rays);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
