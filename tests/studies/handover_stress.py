@@ -1,3 +1,6 @@
+"""GPU study (uses the oracle: lives under tests/): the hand-over schedules of the GROUP traversal launch, counting kernels,
+repeated in one process -- the script that bisected the stale non-temporal loads of DESIGN.md 5.4.
+usage: python tests/studies/handover_stress.py [adaptive|phased] [repetitions]   (on the GPU box, from the repo root)"""
 import sys, importlib, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 psm = importlib.import_module("prismarine-core_amd")
