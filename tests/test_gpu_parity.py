@@ -1093,6 +1093,40 @@ def test_frame_split_over_parts_equals_unsplit_frames(psm, oracle, scenes, name,
         np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("lanes,frames,w,h,depth,rebuild", [
+    (1, 3, 48, 32, 16, True),     # one frame at a time: every frame's rebuild is queued while the frame before folds
+    (2, 1, 48, 32, 16, True),     # fewer frames than lanes
+    (4, 2, 48, 32, 16, True),
+    (3, 7, 48, 32, 16, True),     # lanes end out of turn and claim their next frames
+    (4, 9, 48, 32, 16, False),    # no rebuild: only the waits
+    (3, 5, 48, 32, 1, True),      # one bounce round per frame
+    (3, 5, 5, 5, 16, True),       # 25 primary rays: a frame ends in camera() (fewer than 32 rays, Pipeline.inl:459-461)
+], ids=["1x3", "2x1", "4x2", "3x7", "4x9-norebuild", "depth1", "5x5px"])
+def test_lane_scheduler_edge_cases_equal_the_oracle(psm, oracle, scenes, lanes, frames, w, h, depth, rebuild):
+    """psm_lanes_render at the corners of its scheduler: the frames are claimed, rebuilt, folded and counted as the same
+    frames rendered one after another by the oracle (radiance <= 1e-4, deposit counts, rounds and rays per frame)."""
+    scene = scenes.cornell(open_top=True)
+    seed = 977
+    batch = psm.FrameBatch(lanes, w, h, seed=seed)
+    batch.allocate(scene["tris"].shape[0])
+    batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
+    ms = psm.MaterialSet()
+    for m in scene["materials"]:
+        ms.addSubmat(m)
+    batch.applyMaterials(ms)
+    if not rebuild:
+        for ln in batch.lanes:
+            ln.th.build()
+    per_frame = batch.render(frames, scene["eye"], scene["view"], depth=depth, rebuild=rebuild)
+    img = batch.snapHdr()
+    ref, st = oracle.render_frames(scene, w, h, frames=frames, seed=seed, depth=depth, frame_streams=True)
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    assert len(per_frame) == frames
+    assert sum(r for _, r in per_frame) == st["rays"] and sum(n for n, _ in per_frame) == len(st["rounds"])
+    batch.close()
+
+
 @pytest.mark.parametrize("mode,kw", [("whole", {}), ("adaptive", {"min_live": 16, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
                                      ("phased", {"caps": [3, 9]})], ids=["whole", "adaptive", "phased"])
 @pytest.mark.parametrize("counting", [True, False], ids=["counting", "plain"])
