@@ -1,0 +1,54 @@
+"""Code-generation guards that need no GPU: hipcc's gfx950 assembly of the traversal kernels (tools/step_isa.py).
+The node step's hot path is the frame's critical resource: a compiler flag lost from the Makefile
+(-fno-slp-vectorize), a flag that moves back into a lane mask or a spill that lands in the loop shows here first."""
+import importlib.util
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _asm(tmp_path):
+    flags = open(os.path.join(ROOT, "prismarine-core_amd", "csrc", "Makefile")).read()
+    cxx = re.search(r"^CXXFLAGS := (.*)$", flags, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    assert "-fno-slp-vectorize" in cxx and "-ffp-contract=off" in cxx
+    out = str(tmp_path / "trace.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + [f for f in cxx if not f.startswith("-W")] +
+                          ["-S", "--cuda-device-only", "-o", out, os.path.join(ROOT, "prismarine-core_amd", "csrc", "trace.hip")],
+                          stderr=subprocess.DEVNULL)
+    return out
+
+
+def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
+    path = _asm(tmp_path)
+    spec = importlib.util.spec_from_file_location("step_isa", os.path.join(ROOT, "tools", "step_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = open(path).read().split("\n")
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_ZN3psm\w+:", l)]
+    ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
+    seen = 0
+    for (st, name), en in zip(starts, ends):
+        if "rt_traverseILb0ELb0ELb1ELb0E" not in name and "rt_traverseILb0ELb0ELb0ELb0E" not in name:
+            continue   # the timed kernels: hand-over and single launch, plain
+        body = lines[st:en]
+        first = [i for i, l in enumerate(body) if "v_fma_mix_f32" in l][0]
+        a = first
+        while not body[a].startswith(".LBB"):
+            a -= 1
+        valu, salu, branches, mem = mod.walk(body, a)
+        assert 60 <= valu <= 84, (name, valu)        # 80 at the end of round 3 (94 at the end of round 2)
+        assert salu <= 68, (name, salu)              # 61 / 45 (86)
+        assert mem == 4, (name, mem)                 # two record loads, the stack's push and pop: no scratch in the step
+        assert not any("v_pk_" in l for l in body), name   # no packed-fp32 pairs (the SLP vectoriser's)
+        seen += 1
+    assert seen == 2
+    # occupancy: 64 VGPRs at most (8 waves per SIMD), nothing spilled
+    meta = open(path).read()
+    for kern in ("_ZN3psm11rt_traverseILb0ELb0ELb1ELb0EEEvNS_8TravArgsE", "_ZN3psm11rt_traverseILb0ELb0ELb0ELb0EEEvNS_8TravArgsE"):
+        blk = meta[meta.index(".name:           " + kern):]
+        blk = blk[:blk.index(".wavefront_size")]
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 64, kern
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, kern
+        assert int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, kern
