@@ -86,6 +86,8 @@ def parse():
                     help="tuning study: traversal kernel schedule (psm_rt_set_traverse_mode); results never depend on it")
     ap.add_argument("--trav-caps", default="96", help="phased: wave-step caps, comma separated")
     ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
+    ap.add_argument("--solo", type=int, default=-1, help="tuning study: rays a traversal wave takes into the solo gear at most "
+                                                          "(psm_rt_set_traverse_solo, 0..4; -1 = the library's default)")
     return ap.parse_args()
 
 
@@ -138,6 +140,9 @@ class Renderer:
             self.ms.setTextureSet(ts)
         for b in self.batches:
             b.applyMaterials(self.ms)
+        if args.solo >= 0:
+            for b in self.batches:
+                b.each(lambda r: r.setTraverseSolo(args.solo))
         if args.traverse != "auto" or args.trav_adaptive or args.trav_refill:
             def tune(r):
                 if args.trav_refill:

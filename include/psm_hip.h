@@ -289,6 +289,16 @@ int psm_rt_set_traverse_phases(psm_rt* rt, const uint32_t* caps, uint32_t count,
  * Defaults: 12, 8, 65536, 4, 2^19. */
 int psm_rt_set_traverse_adaptive(psm_rt* rt, uint32_t min_live, uint32_t min_steps, uint32_t final_rays,
                                  uint32_t max_launches, uint32_t min_rays);
+/* The solo gear of every schedule (round 4): a traversal wave that is left with at most solo_max rays (0..4; default 2) --
+ * and is not in a launch that hands rays over -- stops stepping them one lane each and walks them one after the other with
+ * ALL its lanes on one ray: the ray's state is wave-uniform, so the step's decisions are scalar arithmetic instead of lane
+ * masks, a lane evaluates one axis of one child box (the same v_fma_mix_f32 on the same operands; tNear / tFar by quad-permute
+ * DPP max / min in the order mathlib.glsl:129-193 combines them), the stack lives in the lanes of one register, a leaf's two
+ * triangles are tested side by side. A round's tail consists of such waves (a bounce round's longest ray takes 659-1099
+ * steps against a mean of 56) and a frame on its own, a tile's launches and every hand-over round's last launch end with
+ * them. Per ray nothing changes: the node steps and triangle tests of directTraverse.comp:333-484 in the same order, hits,
+ * chains and counters bit-exact. 0 switches the gear off. */
+int psm_rt_set_traverse_solo(psm_rt* rt, uint32_t solo_max);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
 int psm_rt_reset_hits(psm_rt* rt);
 /* applyMaterials + shade, Pipeline.inl:407-436 -> surface.comp + rayshading.comp, then the

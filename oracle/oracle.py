@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libpsm_oracle.so")
+# PSM_ORACLE_LIB: another build of the same sources (the sanitizer build, `make -C oracle asan`)
+_LIB = os.environ.get("PSM_ORACLE_LIB") or os.path.join(_HERE, "libpsm_oracle.so")
 
 PZERO = np.float32(0.0005)
 INFINITY = np.float32(10000.0)
@@ -42,6 +43,8 @@ class FrameCfg(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("PSM_ORACLE_LIB"):
+        return _LIB
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
             for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):

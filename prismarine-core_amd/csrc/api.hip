@@ -947,6 +947,12 @@ int psm_rt_set_traverse_adaptive(psm_rt* r, uint32_t min_live, uint32_t min_step
     return PSM_OK;
 }
 
+int psm_rt_set_traverse_solo(psm_rt* r, uint32_t solo_max) {
+    if (!r || solo_max > 4u) return PSM_ERR_INVALID;
+    r->solo_max = solo_max;
+    return PSM_OK;
+}
+
 int psm_rt_set_traverse_refill(psm_rt* r, uint32_t refill_min, uint32_t waves_per_cu, uint32_t min_rays) {
     if (!r || refill_min < 1 || refill_min > 64 || waves_per_cu < 2 || waves_per_cu > 32 || (waves_per_cu & 1u)) return PSM_ERR_INVALID;
     r->refill_min = refill_min;

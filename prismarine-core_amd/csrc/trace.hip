@@ -125,6 +125,155 @@ struct Baked {
 // The wave's lane mask of a flag (the flag stays a flag: __ballot(int) would first widen it to an integer).
 PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// ---- SOLO: the whole wave walks ONE ray ------------------------------------------------------------------------------
+//
+// A round's tail is made of waves in which a single ray is left (the per-ray step counts have a long thin tail: mean 56,
+// p99 124, maximum 659-1099 on C3's bounce rounds, and two such rays rarely share a wave): the wave then issues the ~140
+// instructions of a node step -- and every vector-compare -> scalar-AND -> vector-select hop of its lane-mask logic --
+// for one live lane, ~2450 cycles per step for a wave alone on its SIMD (profiles/r03_lone_wave.txt), and a frame on its
+// own, a tile's launches and every hand-over round's last launch wait for exactly these chains (4 x 0.68 ms of a 3.35 ms
+// frame). When at most `solo_max` lanes of a wave have work left (and the launch does not hand rays over), the wave
+// changes gear: it takes the rays one after the other, and for each one
+//   * the ray's constants and state are broadcast (v_readlane) -- wave-uniform from here on, so every decision of the
+//     step (accepted? leaf? nearer child? push, pop, done?) is SCALAR arithmetic and a scalar branch: no lane masks;
+//   * lane j of each group of eight loads ONE dword of the 32-byte node record (a single request): lanes 0,1,2 hold the
+//     left child's x,y,z slabs (min | max halves), lanes 4,5,6 the right child's, lanes 3 and 7 the two links; a lane
+//     evaluates its two plane distances (the same v_fma_mix_f32 on the same operands), tNear / tFar are two quad-permute
+//     DPP v_max / v_min each, IN THE ORDER slab_child combines them (lane 0: ((x, y), z)), the acceptance tests run in lanes
+//     0 and 4 at once and reach the scalar unit as two bits of one ballot;
+//   * the stack lives in the lanes of one VGPR (v_writelane / v_readlane at the scalar depth): no LDS round trip in a pop;
+//   * a leaf's two triangles are tested side by side in lanes 0 and 1, and accepted one after the other in the
+//     reference's order (directTraverse.comp:261-309) by scalar code; only the ray's own lane touches its hit chain.
+// Per ray the node steps and triangle tests, their operands and their order are those of the lane-per-ray step above
+// (hits, chains, V and T bit-exact: every traversal test runs through this body, test_every_traversal_schedule_is_bit_exact
+// with solo_max 0..4); the step is ~25 vector + ~30 scalar instructions and one memory round trip.
+PSM_D float rl_f(float x, int lane) { return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), lane)); }
+PSM_D int rl_i(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+template <int P0, int P1, int P2, int P3>
+PSM_D float quad_perm(float x) {   // lane i of every quad reads lane P_i of its quad
+    return u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(x), P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true));
+}
+
+struct SoloCounters {
+    uint32_t nV, nT, nDrop, nCap, nBakedDrop;
+};
+
+// Runs the ray of lane `L` (wave-uniform) to its end. Out, in lane L only: the hit chain (head, extra, bakedCount); the
+// caller marks the lane done.
+// The ray travels from its lane to the wave through 23 words of LDS (`xch`, written by solo_park): the floats come back as
+// vector registers that hold the same value in every lane (operands of the plane and triangle arithmetic), the integers as
+// scalars (v_readfirstlane) -- the kernel has 78 scalar registers, the ray's thirteen constants do not fit beside the loop's.
+constexpr int XCH_WORDS = 32;
+constexpr int SOLO_MAX = 4;     // rays a wave takes into the solo gear at most (LDS: SOLO_MAX blocks of XCH_WORDS words per wave)
+// the lane-per-ray loop's variables of one ray, parked in LDS for solo_ray
+PSM_D void solo_park(uint32_t* xch, const v3 origin, const v3 direct, const v3 divident, const v3 norig, const float dirlenInv, const float hitMax,
+                     const float toffset, const float predist, const int lastTri, const int cur, const int sp, const int it, const int pl,
+                     const int pr, const bool pLeftNear, const bool parked) {
+    xch[0] = f2u(origin.x); xch[1] = f2u(origin.y); xch[2] = f2u(origin.z); xch[3] = f2u(dirlenInv);
+    xch[4] = f2u(direct.x); xch[5] = f2u(direct.y); xch[6] = f2u(direct.z); xch[7] = f2u(hitMax);
+    xch[8] = f2u(divident.x); xch[9] = f2u(divident.y); xch[10] = f2u(divident.z); xch[11] = f2u(toffset);
+    xch[12] = f2u(norig.x); xch[13] = f2u(norig.y); xch[14] = f2u(norig.z); xch[15] = f2u(predist);
+    xch[16] = (uint32_t)lastTri; xch[17] = (uint32_t)cur; xch[18] = (uint32_t)sp; xch[19] = (uint32_t)it;
+    xch[20] = (uint32_t)pl; xch[21] = (uint32_t)pr; xch[22] = (pLeftNear ? 1u : 0u) | (parked ? 2u : 0u);
+}
+template <bool COUNT>
+PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const float4* __restrict__ tri48, const int* lds_stack_col, const uint32_t* xch,
+                    const int lj, int& bakedCount, Baked& head, Baked* extra, SoloCounters& ctr, unsigned long long& wave_steps) {
+    const bool mine = lj == L;
+    const int j8 = lj & 7, q = lj & 3;
+    const v3 O = mk3(u2f(xch[0]), u2f(xch[1]), u2f(xch[2]));
+    const v3 D = mk3(u2f(xch[4]), u2f(xch[5]), u2f(xch[6]));
+    const float dirlenInv = u2f(xch[3]), hitMax = u2f(xch[7]), toffset = u2f(xch[11]);
+    float predist = u2f(xch[15]);
+    // this lane's axis of the slab test (lanes 3 and 7 of a group of eight hold the links: any axis)
+    const int ax = q < 3 ? q : 2;
+    const float my_dr = u2f(xch[8 + ax]), my_no = u2f(xch[12 + ax]);
+    int lastTri = __builtin_amdgcn_readfirstlane((int)xch[16]), cur = __builtin_amdgcn_readfirstlane((int)xch[17]);
+    int sp = __builtin_amdgcn_readfirstlane((int)xch[18]), it = __builtin_amdgcn_readfirstlane((int)xch[19]);
+    int pl = __builtin_amdgcn_readfirstlane((int)xch[20]), pr = __builtin_amdgcn_readfirstlane((int)xch[21]);
+    const int fl = __builtin_amdgcn_readfirstlane((int)xch[22]);
+    bool pLeftNear = (fl & 1) != 0, parked = (fl & 2) != 0;
+    // this lane's part of a node record: dword 0,1,2 | 6 | 3,4,5 | 7 (left slabs, left link, right slabs, right link)
+    const uint32_t dwsel = q == 3 ? (uint32_t)(6 + (j8 >> 2)) : (uint32_t)(j8 - (j8 >> 2));
+    // the ray's stack: entry k in lane k
+    int stk = lj < sp ? lds_stack_col[(lj < STACK_CAP ? lj : 0) * TRAV_BLOCK + L] : 0;
+    for (;;) {
+        if (parked) {  // testIntersectionPacked, :261-309
+            const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
+            const int tx = ~(lo ? pl : pr), ty = ~(lo ? pr : pl);
+            const bool validx = (tx >= 0) && (tx != lastTri);
+            const bool validy = (ty >= 0) && (ty != lastTri) && (tx != ty);
+            const int triA = validx ? tx : ty;
+            const bool valid = validx || validy, again = validx && validy;
+            if (valid) {
+                float u = 0.f, v = 0.f, d = INF;
+                if (lj == 0 || (lj == 1 && again)) d = tri_test(tri48, lj == 0 ? triA : ty, O, D, u, v);
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1 && !again) break;
+                    const float sd = rl_f(d, pass), su = rl_f(u, pass), sv = rl_f(v, pass);
+                    const int stri = pass == 0 ? triA : ty;
+                    if (COUNT) ctr.nT += mine ? 1u : 0u;
+                    // (predist is a vector register with one value in all lanes: the decisions reach the scalar unit as lane masks)
+                    const bool near = lane_mask(lessF(sd, INF) && lessEqualF(sd, predist) && greaterEqualF(sd, 0.0f)) != 0ull;
+                    if (near) {
+                        const bool fresh = !equalF(sd, predist);
+                        predist = sd;
+                        lastTri = stri;
+                        if (mine) {
+                            if (fresh) bakedCount = 0;
+                            int at = bakedCount++;
+                            if (at == 0) { head.u = su; head.v = sv; head.t = sd; head.tri = stri; }
+                            else if (at < BAKED_CAP) { extra[at - 1].u = su; extra[at - 1].v = sv; extra[at - 1].t = sd; extra[at - 1].tri = stri; }
+                            else if (COUNT) ctr.nBakedDrop++;
+                        }
+                    }
+                }
+            }
+            parked = false;
+        }
+        if (sp < 0) break;
+        it++;
+        const bool lastIter = it >= MAX_ITERS;  // :383
+        const uint32_t wd = node_dw[((uint32_t)cur << 3) + dwsel];
+        if (COUNT) { ctr.nV += mine ? 1u : 0u; wave_steps++; }
+        // intersectCubeDual, mathlib.glsl:129-193: slab_child with one axis of one child per lane
+        const float tmin = fmaf(half_lo(wd), my_dr, my_no), tmax = fmaf(half_hi(wd), my_dr, my_no);
+        const float lo_ = sminf(tmin, tmax), hi_ = smaxf(tmin, tmax);
+        const float tNear = smaxf(smaxf(lo_, quad_perm<1, 2, 0, 3>(lo_)), quad_perm<2, 0, 1, 3>(lo_));   // lane 0 / 4: ((x, y), z)
+        const float tFar = sminf(sminf(hi_, quad_perm<1, 2, 0, 3>(hi_)), quad_perm<2, 0, 1, 3>(hi_));
+        Slab S;
+        S.cube = (tFar + PZERO) >= smaxf(tNear, 0.0f);
+        S.near = sminf(tNear, tFar);
+        S.hit = (S.near <= -PZERO) ? smaxf(tNear, tFar) : S.near;
+        const unsigned long long okm = lane_mask(child_ok(S, hitMax, dirlenInv, toffset, predist));
+        const bool ogL = (okm & 1ull) != 0ull, ogR = (okm & 16ull) != 0ull;
+        const float Rnear = rl_f(S.near, 4);
+        const bool leftNear = (lane_mask(lessEqualF(S.near, Rnear)) & 1ull) != 0ull;  // :414, in lane 0
+        const int lkx = rl_i((int)wd, 3), lky = rl_i((int)wd, 7);
+        // from here on the step of rt_traverse in scalar registers
+        const bool leafL = ogL && lkx < 0, leafR = ogR && lky < 0;
+        pl = leafL ? lkx : 0;   // :441-448
+        pr = leafR ? lky : 0;
+        pLeftNear = leftNear;
+        parked = leafL || leafR;
+        const bool intL = ogL != leafL, intR = ogR != leafR;
+        const bool leftFirst = intL && (leftNear || !intR);  // :451-462
+        const int first = leftFirst ? lkx : lky, second = leftFirst ? lky : lkx;
+        if (intL && intR && (lkx != lky)) {
+            if (sp < STACK_CAP) { stk = lj == sp ? second : stk; sp++; }   // (v_writelane_b32 has no builtin in this clang: one compare + select)
+            else if (COUNT) ctr.nDrop += mine ? 1u : 0u;
+        }
+        cur = first;
+        if (!(intL || intR)) {    // :467-476
+            sp--;
+            if (sp >= 0) cur = rl_i(stk, sp);
+        }
+        if (COUNT) ctr.nCap += (sp >= 0 && lastIter && mine) ? 1u : 0u;
+        sp = lastIter ? -1 : sp;
+    }
+}
+
 // CHAIN: a further intersection() over the same rays with another hierarchy (multi-BVH). The
 // search starts from the distance of the chain the ray already carries (traverse(), :335-346) and the hits
 // it bakes overwrite the front of that chain, the rest of the old chain staying linked behind them
@@ -167,6 +316,7 @@ struct TravArgs {
     const float4* tri48;
     const uint32_t* sm;
     uint32_t cap, min_live, min_steps, final_rays;  // Phase, hot part
+    uint32_t solo_max;            // a wave with at most this many rays left walks them one by one (solo_ray); 0: never
     const uint32_t* in_count;
     float4* hit0;                 // cold from here on
     uint32_t* hitN;
@@ -201,6 +351,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const uint32_t* __restrict__ sm = ka.sm;
     struct { uint32_t cap, min_live, min_steps, final_rays; const uint32_t* in_count; } ph = {ka.cap, ka.min_live, ka.min_steps, ka.final_rays, ka.in_count};
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
+    __shared__ uint32_t xch[TRAV_BLOCK / 64][SOLO_MAX][XCH_WORDS];   // solo_ray: rays on their way from their lanes to the wave
     const int tid = threadIdx.x;
     const bool resume = PHASED && ph.in_count != nullptr;
     const uint32_t total = resume ? *ph.in_count : nrays;
@@ -208,6 +359,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const uint32_t min_live = (PHASED && !(resume && total <= ph.final_rays)) ? ph.min_live : 0u;
     const uint32_t cap = (PHASED && !(resume && total <= ph.final_rays)) ? ph.cap : 0xFFFFFFFFu;
     const int capI = (int)min(cap, 0x7FFFFFFFu), minLive1 = (int)min_live - 1, minSteps = (int)min(ph.min_steps, 0x7FFFFFFFu);
+    // (a launch that hands rays over does so below min_live lanes: the solo gear is for launches that finish their rays)
+    const int soloMax = (PHASED && (min_live != 0u || cap != 0xFFFFFFFFu)) ? 0 : (int)min(ka.solo_max, (uint32_t)SOLO_MAX);   // 0: the loop ends with nobody left
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -323,6 +476,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         lastTri = (int)ld_stream((const uint32_t*)&in.lastTri()[slot]);
         float4 hd = ld_stream(&in.head()[slot]);
         head.u = hd.x; head.v = hd.y; head.t = hd.z; head.tri = __float_as_int(hd.w);
+#pragma unroll 4
         for (int k = 0; k < sp; k++) stack[k][tid] = (int)ld_stream((const uint32_t*)&in.stack()[(size_t)k * in.capacity + slot]);
     }
     int wsteps = 0;
@@ -394,10 +548,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             wsteps++;
             const int thr1 = wsteps >= minSteps ? minLive1 : -1;   // nl > thr1  <=>  nl >= min_live once min_steps have run
             handover = (thr1 - nl) & (wsteps - capI);              // < 0: enough lanes live and below the cap
-            if ((((np << 1) - nl) & handover) < 0) continue;
-        } else if ((np << 1) < nl) continue;
+            if (((max(np << 1, soloMax) - nl) & handover) < 0) continue;
+        } else if (nl > max(np << 1, soloMax)) continue;
         const bool capHit = PHASED && handover >= 0;
-        if (nl == 0) break;
+        // nobody left -- or at most solo_max rays and nobody to hand them to: the wave walks those one at a time, all lanes on
+        // one ray (below the loop). One more difference in the AND above and this compare are all the node step pays for it.
+        if (nl <= soloMax) break;
         if (parkedNow) {  // testIntersectionPacked, :261-309
             // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
             const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
@@ -459,6 +615,36 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             if (lane_mask(sp >= 0) == 0ull) break;
         }
         stepping = sp >= 0;   // nobody is parked now
+    }
+    // The solo gear (solo_ray): the rays the loop above has left are walked one at a time, all lanes on one ray. (Behind the
+    // loop, not in it: inside, its values would be live across the node steps, which have no register to spare.)
+    {
+        // (a lane waits for its leaf tests iff it holds a parked link: read from pl / pr, so that the loop's flag does not have to
+        // be kept for its exits)
+        const bool parkedL = pl < 0 || pr < 0;
+        unsigned long long work = lane_mask(sp >= 0 || parkedL);   // none after a complete run or a hand-over
+        if (work != 0ull) {
+            // (the lane number behind an opaque zero, so that it is computed HERE: shared with an earlier lane_id() it -- and the lane
+            // roles the solo gear derives from it -- would be held in registers across the node steps, which have none to spare)
+            uint32_t zero;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+            const int lj = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+            // every ray first leaves its lane (after this the loop's per-lane variables are dead: the solo gear needs the registers)
+            if (sp >= 0 || parkedL)
+                solo_park(&xch[tid >> 6][__popcll(work & ((1ull << lj) - 1ull))][0], origin, direct, divident, norig, dirlenInv, hitMax, toffset, predist,
+                          lastTri, cur, sp, it, pl, pr, pLeftNear, parkedL);
+            // one wave: its LDS operations execute in program order; the fences keep the compiler from moving the reads up
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            SoloCounters sc = {nV, nT, nDrop, nCap, nBakedDrop};
+            for (int k = 0; work != 0ull; k++) {
+                const int Ls = __builtin_ctzll(work);
+                work &= work - 1ull;
+                solo_ray<COUNT>(Ls, (const uint32_t*)node32, tri48, &stack[0][tid & ~63], &xch[tid >> 6][k][0], lj, bakedCount, head, extra, sc, dg_steps);
+            }
+            if (COUNT) { nV = sc.nV; nT = sc.nT; nDrop = sc.nDrop; nCap = sc.nCap; nBakedDrop = sc.nBakedDrop; }
+        }
     }
     if (PHASED && suspendedFlag) alive = false;  // handed over
     const TravArgs* K = cold_args();
@@ -914,6 +1100,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         ta.hit0 = r->hit0; ta.hitN = r->hitN; ta.pool = r->pool; ta.cnt = r->d_cnt; ta.ctr = c->d_counters;
         ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
         ta.cap = 0xFFFFFFFFu;
+        ta.solo_max = r->solo_max;
         if (mode == PSM_TRAVERSE_REFILL) {
             // persistent waves over a pool of rays: at most refill_waves waves per CU, never more lanes than rays
             const uint32_t per_block = TRAV_BLOCK;
@@ -1014,6 +1201,7 @@ int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t 
     ta.node32 = nbase; ta.tri48 = tbase;
     ta.ctr = c->d_counters;
     ta.cap = 0xFFFFFFFFu;
+    ta.solo_max = r0->solo_max;
     std::vector<PhasePlan> plan;
     const int mode = plan_traverse(r0, N, false, plan);
     const uint32_t grid = ((N + TRAV_BLOCK - 1) / TRAV_BLOCK + (8u * XCD_RUN - 1u)) & ~(8u * XCD_RUN - 1u);

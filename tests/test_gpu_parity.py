@@ -457,6 +457,12 @@ TRAVERSE_SCHEDULES = [
     ("adaptive", {"min_live": 64, "min_steps": 0, "final_rays": 0, "max_launches": 15}),   # hand over at the first idle lane
     ("adaptive", {"min_live": 2, "min_steps": 1, "final_rays": 0, "max_launches": 3}),
     ("adaptive", {"min_live": 24, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
+    ("whole", {"solo": 0}),      # the solo gear (psm_rt_set_traverse_solo) off, at its default (2: every entry above and below), and wider
+    ("whole", {"solo": 1}),
+    ("whole", {"solo": 4}),
+    ("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 256, "max_launches": 8, "solo": 4}),
+    ("adaptive", {"min_live": 12, "min_steps": 8, "final_rays": 65536, "max_launches": 3, "solo": 0}),
+    ("phased", {"caps": [24, 24], "solo": 3}),
     ("refill", {"refill_min": 16, "waves_per_cu": 32}),
     ("refill", {"refill_min": 1, "waves_per_cu": 2}),     # every idle lane refills at once; a small persistent grid
     ("refill", {"refill_min": 64, "waves_per_cu": 8}),    # a wave refills only when all its lanes are idle
@@ -465,6 +471,9 @@ TRAVERSE_SCHEDULES = [
 
 
 def _select_schedule(rt, mode, kw):
+    kw = dict(kw)
+    if "solo" in kw:
+        rt.setTraverseSolo(kw.pop("solo"))
     if mode == "phased":
         rt.setTraversePhases(kw["caps"], min_rays=0)
     elif mode == "adaptive":

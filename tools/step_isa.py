@@ -11,10 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def walk(body, start):
-    """Follow the hot path of one wave-step: from the block that loads the node record, through the divergent regions
-    (s_cbranch_execz falls through: somebody is in them), taking the wave-level `continue` (the first scalar conditional
-    branch after the lane counts) and every execnz / unconditional branch, until the walk is back at the start."""
+def _walk(body, start, skip):
     labels = {l.split(":")[0]: i for i, l in enumerate(body) if l.startswith(".LBB")}
     i, valu, salu, br, mem = start, 0, 0, 0, 0
     seen_counts = took_continue = False
@@ -35,16 +32,32 @@ def walk(body, start):
             take = kind in ("branch", "cbranch_execnz")
             if kind.startswith("cbranch_scc") or kind.startswith("cbranch_vcc"):
                 take = seen_counts and not took_continue
+                if take and skip > 0:
+                    skip -= 1
+                    take = False
                 took_continue = took_continue or take
             if take:
                 i = labels[tgt]
                 if i <= start <= i + 3:
-                    break
+                    return (valu, salu, br, mem), True
                 continue
         i += 1
         if i == start:
-            break
-    return valu, salu, br, mem
+            return (valu, salu, br, mem), True
+    return (valu, salu, br, mem), False
+
+
+def walk(body, start):
+    """Follow the hot path of one wave-step: from the block that loads the node record, through the divergent regions
+    (s_cbranch_execz falls through: somebody is in them), taking the wave-level `continue` and every execnz / unconditional
+    branch, until the walk is back at the start. The `continue` is the first scalar conditional branch after the lane counts
+    that leads back to the start: since round 4 the exit to the solo gear (at most solo_max lanes with work) may stand in
+    front of it, so the walk is tried with 0, 1, 2 such branches passed by and the first one that closes the loop counts."""
+    for skip in range(3):
+        counts, closed = _walk(body, start, skip)
+        if closed:
+            return counts
+    return counts
 
 
 def main():
