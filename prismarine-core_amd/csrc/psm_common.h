@@ -96,20 +96,36 @@ PSM_D uint32_t block_scan_array_1024(const uint32_t* in, uint32_t* out, uint32_t
 constexpr int SHADE_BLOCK = PSM_SHADE_BLOCK;           // rays a shading workgroup takes from the queue
 constexpr uint32_t QUEUE_SEG = 4u * SHADE_BLOCK;       // ... and the slots of its output segment: at most 4 rays out per ray in
 
-// Accesses to data that is written once per launch (ray queues, hit records, hand-over state, images): the STORES carry the
-// non-temporal hint, so that these streams do not push the node and triangle records out of L2.
-// The LOADS do not, although it would help as much: a non-temporal load of the hand-over state returned what the slot had
-// held two launches earlier (the two state buffers alternate, so a resume wave reads addresses it read then) -- lost and
-// mixed-up rays in tests/test_gpu_parity.py::test_one_traversal_launch_over_several_pipelines_is_bit_exact, depending on
-// code generation and timing; with plain loads (and non-temporal stores) never. DESIGN.md 5.4.
+// Accesses to data that is written once per launch and read by a LATER launch (ray queues, hit records, hand-over state,
+// images): plain loads and plain stores. Round 3 put the non-temporal hint on them (hipcc: `global_load_dwordx4 ... nt`,
+// `global_store_dwordx4 ... nt`; nt = 1, sc0 = sc1 = 0), which keeps ~1.3 GB per C3 frame from displacing node and triangle
+// records in L2 -- worth 2.5 % with the hint on loads and stores, 1.2 % on stores only. It was taken off the LOADS after an `nt`
+// load of the hand-over state returned, for some slots, what the slot had held two launches earlier (the two state buffers
+// alternate, so a resume wave reads addresses it read -- or another wave of its XCD wrote -- then), and in
+// round 4 off the STORES as well: the 8 XCDs' L2s are not coherent with each other and a launch boundary is what makes one
+// XCD's stores visible to another's loads; what that boundary does to lines allocated under the `nt` policy could not be
+// established from the documents at hand (the failure above says: not always what it does to the others), an `nt` store
+// leaves its line in the storing XCD's L2 exactly as a plain store does (MI355X_MICROARCH.md, "stores of each flavour"), and
+// "it never showed with stores" is an observation, not an argument. The two names stay: they mark the once-per-launch streams.
+// (PSM_EXP_NT_STORES=1: the round-3 stores, an experiment build for the A/B in profiles/r04_nt_stores.txt -- never the product.)
+#ifndef PSM_EXP_NT_STORES
+#define PSM_EXP_NT_STORES 0
+#endif
 typedef float psm_f4v __attribute__((ext_vector_type(4)));
 PSM_D float4 ld_stream(const float4* p) { return *p; }
-PSM_D void st_stream(float4* p, float4 v) {
-    psm_f4v w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, (psm_f4v*)p);
-}
 PSM_D uint32_t ld_stream(const uint32_t* p) { return *p; }
-PSM_D void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+PSM_D void st_stream(float4* p, float4 v) {
+    if (PSM_EXP_NT_STORES) {
+        psm_f4v w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, (psm_f4v*)p);
+    } else {
+        *p = v;
+    }
+}
+PSM_D void st_stream(uint32_t* p, uint32_t v) {
+    if (PSM_EXP_NT_STORES) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 struct RayQueue {
     const float4 *A, *B, *C;   // origin|texel, direct|bitfield, color|pkey

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 
 scenes = importlib.import_module("prismarine-core_amd.scenes")
-HERE = os.environ.get("PSM_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))   # (PSM_GOLDEN_OUT: tools/oracle_asan.sh regenerates into a scratch directory)
+HERE = os.environ.get("PSM_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))   # (PSM_GOLDEN_OUT: oracle/asan.sh regenerates into a scratch directory)
 
 sc = scenes.cornell()
 b = O.build_scene(sc["tris"])

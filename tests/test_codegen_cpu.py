@@ -59,7 +59,7 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
 
 def test_solo_gear_step_is_short(tmp_path):
     """The solo gear's step (trace.hip: solo_ray): one ray on all lanes of the wave. Its point is a short dependent chain --
-    one dword load per lane, two v_fma_mix, quad-permute DPP reductions, the decisions in scalar registers -- so its loop must
+    a lane's share of the record, two v_fma_mix, quad-permute DPP reductions, the decisions in scalar registers -- so its loop must
     stay a fraction of the lane-per-ray step (80 vector + 49-63 scalar instructions) and free of scratch and LDS traffic."""
     path = _asm(tmp_path)
     lines = open(path).read().split("\n")
@@ -74,7 +74,7 @@ def test_solo_gear_step_is_short(tmp_path):
         assert len(dpp) == 2, (name, len(dpp))       # tNear and tFar, once in the kernel
         # the straight-line part of the step: from the record's load to the first branch after the reductions
         a = dpp[0]
-        while "global_load_dword " not in body[a]:
+        while sum(1 for l in body[a:dpp[0]] if "global_load_" in l) < 3:   # the slabs' min and max halfs, the link word
             a -= 1
         b = dpp[-1]
         while not re.match(r"\ts_cbranch", body[b]):
@@ -85,6 +85,6 @@ def test_solo_gear_step_is_short(tmp_path):
         mem = sum(1 for l in seg if re.match(r"\t(ds_|global_|scratch_|buffer_)", l))
         assert valu <= 40, (name, valu)
         assert salu <= 40, (name, salu)
-        assert mem == 1, (name, mem)                 # the record, one dword per lane
+        assert mem == 3, (name, mem)                 # the record: two halfs and a link word per lane, one round trip
         seen += 1
     assert seen == 2
