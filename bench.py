@@ -86,6 +86,8 @@ def parse():
                     help="tuning study: traversal kernel schedule (psm_rt_set_traverse_mode); results never depend on it")
     ap.add_argument("--trav-caps", default="96", help="phased: wave-step caps, comma separated")
     ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the timed call of K steps is taken; the line reports the "
+                                                            "median call, and all of them under \"timing\"")
     ap.add_argument("--solo", type=int, default=-1, help="tuning study: rays a traversal wave takes into the solo gear at most "
                                                           "(psm_rt_set_traverse_solo, 0..4; -1 = the library's default)")
     return ap.parse_args()
@@ -637,19 +639,24 @@ def main():
     wh_launches = sum(s_.traverse_launches for s_ in lane_stats) - ho_launches
     wh_ms = sum(s_.traverse_ms for s_ in lane_stats) - ho_ms
 
-    # timed region: exactly K steps
-    reseed()
-    ctx.stats_reset()
-    dist.barrier()
-    R.batch.sync()
-    t0 = time.perf_counter()
-    traced = run_steps(args.steps)
-    R.batch.sync()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist.max_float(elapsed)
+    # timed region: exactly K steps between barrier + synchronize on both sides, the maximum over the ranks -- taken
+    # `repeats` times over (the same frames: reseeded), `value` and `ms_per_step` from the MEDIAN call, every call's figure
+    # in the line's "timing" object (median and minimum over repeats; one wall-clock sample of a 45 ms call
+    # moves by 1-2 % with whatever else the box does)
+    samples = []
+    for rep in range(max(args.repeats, 1)):
+        reseed()
+        ctx.stats_reset()
+        dist.barrier()
+        R.batch.sync()
+        t0 = time.perf_counter()
+        traced = run_steps(args.steps)
+        R.batch.sync()
+        dist.barrier()
+        samples.append(dist.max_float(time.perf_counter() - t0))
+        assert traced == Rr, (traced, Rr)
+    elapsed = sorted(samples)[(len(samples) - 1) // 2]   # the median call (the lower one of an even count)
     st = kst
-    assert traced == Rr, (traced, Rr)
     total_rays = dist.sum_int(int(Rr))
 
     if args.diag_clock and not dist.active:
@@ -773,9 +780,19 @@ def main():
                                    "emit_refit": st.emit_ms / args.steps,
                                    "camera": st.camera_ms / args.steps, "traverse": st.traverse_ms / args.steps,
                                    "shade": st.shade_ms / args.steps, "sample": st.sample_ms / args.steps},
+            "timing": {"repeats": len(samples), "what": "the timed call of `steps` steps taken this many times over the same frames; value and ms_per_step are the median call's",
+                       "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_min": min(samples) / args.steps * 1e3,
+                       "ms_per_step_max": max(samples) / args.steps * 1e3, "ms_per_step_all": [t_ / args.steps * 1e3 for t_ in samples]},
             "roofline": roof,
             "image_mean": float(img[..., :3].mean()),
         }
+        if dist.active and R.hoststaged:
+            # ranks that share one GPU and exchange through host memory: a rehearsal of the scheduler, never a scaling
+            # measurement -- the line says so at the top level and carries no value a driver could ingest as one
+            out["rehearsal"] = True
+            out["rehearsal_value_mrays_s"] = out["value"]
+            out["value"] = None
+            out["vs_baseline"] = None
         if ray_sets is not None and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, ray_sets, args)
         print(json.dumps(out))

@@ -859,6 +859,21 @@ int psm_rt_set_materials(psm_rt* r, const psm_material* mats, uint32_t count, in
     }
     r->mat_count = count;
     r->mat_offset = load_offset;
+    // rt_shade builds only the lobe that survives the lobe pick as long as the other one's colour is certain to be 0 (shade.hip);
+    // it is NaN instead -- and the reference queues the ray -- where the specular colour is 0 / 0 (a black full-metal material:
+    // albedo 0, metallic 1, both after their fp16 round trip) or a colour overflows or is not a number to begin with. Without
+    // textures a surface is its material's constants (surface.comp:81-161), so the materials decide: `ordinary` = diffuse rgb in
+    // [0, 1] with one component of at least 1/1024, roughness and metallic in [0, 1]. (Residue: a shadow ray's weight is NaN
+    // where the hit point IS the light's centre, a set of measure zero.)
+    r->mats_ordinary = true;
+    for (uint32_t i = 0; i < count; i++) {
+        const psm_material& m = mats[i];
+        bool ok = true;
+        float top = 0.f;
+        for (int k = 0; k < 3; k++) { ok = ok && m.diffuse[k] >= 0.f && m.diffuse[k] <= 1.f; top = m.diffuse[k] > top ? m.diffuse[k] : top; }
+        ok = ok && top >= 1.0f / 1024.0f && m.specular[1] >= 0.f && m.specular[1] <= 1.f && m.specular[2] >= 0.f && m.specular[2] <= 1.f;
+        r->mats_ordinary = r->mats_ordinary && ok;
+    }
     return PSM_OK;
 }
 

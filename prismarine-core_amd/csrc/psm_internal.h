@@ -246,6 +246,7 @@ struct psm_rt {
     int trav_mode = 0;              // PSM_TRAVERSE_* (psm_rt_set_traverse_mode); 0 = automatic
     uint32_t adapt_min_live = 12, adapt_min_steps = 8, adapt_final_rays = 65536, adapt_max_launches = 4;  // tuned on C3, 4 frames in flight (its 2 M-ray rounds plan three launches either way; C5's 8 M-ray rounds take the fourth: -1.3 %)
     uint32_t refill_min = 32, refill_waves_per_cu = 28, refill_min_rays = 1u << 15;  // PSM_TRAVERSE_REFILL (trace.hip)
+    bool mats_ordinary = true;      // no material whose dropped lobe's colour can be NaN (psm_rt_set_materials): rt_shade builds one lobe per hit
     uint32_t solo_max = 2;          // a traversal wave with at most this many rays left walks them one by one, all lanes on one ray (trace.hip: solo_ray); 0: never
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
     uint32_t phase_min_rays = 1u << 19;  // smaller intersections run as one launch (tiles: tools/run_r02_ae.sh)

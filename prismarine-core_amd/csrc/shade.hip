@@ -441,7 +441,7 @@ struct ShadeArgs {
 // surface.comp + rayshading.comp:48-278
 // TEX = false is the same kernel with the sampler table known to be empty (validateTexture fails for every
 // part): the texture-less frame keeps its registers and occupancy
-template <bool TEX, bool MULTI>
+template <bool TEX, bool MULTI, bool BOTH>
 __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
     __shared__ uint32_t scan_tmp[8];
     uint32_t it = blockIdx.x * SHADE_BLOCK + threadIdx.x;
@@ -608,17 +608,25 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
             // from the draws of the ray that survives (#2, #3 for the diffuse ray, #4, #5 for the reflection), and only the
             // surviving rays are built -- the same operations on the same values for everything that reaches the queue.
             const bool refl_lobe = coef != 0.0f;
-            const v3 rc = randomCosineU(refl_lobe ? u4 : u2, refl_lobe ? u5 : u3, normal);
-            v3 sdir;   // the surviving secondary ray's direction
+            // ... as long as that colour is an ordinary number: x * 0 is NaN for x = NaN or Inf, and createRay KEEPS a NaN colour
+            // (`mlength(color) < 0.0001` is false for it) -- a black full-metal surface does that to its reflection ray (albedo 0,
+            // metallic 1: the colour is clamp(0 / 0)), a colour that overflowed does it to the diffuse and shadow rays, and the
+            // reference queues those rays. BOTH = true builds both lobes, the second one from its own draws, and lets createRay
+            // decide, as the reference does; launch_rt_shade picks it whenever the materials at hand can produce such a colour
+            // (any texture; a material that is not `ordinary`, api.hip: psm_rt_set_materials). BOTH = false is the same code with
+            // the second turn known to build rays createRay would drop.
+            auto lobe = [&](const bool lobe_refl) {
+            const v3 rc = randomCosineU(lobe_refl ? u4 : u2, lobe_refl ? u5 : u3, normal);
+            v3 sdir;   // this secondary ray's direction
             {
                 // reflection(), shadinglib.glsl:139-148: mix(reflect(dir, n), randomCosine(n), clamp(roughness * random()))
                 float dn = dot3(normal, ray.direct);
                 v3 refl = mk3(ray.direct.x - 2.0f * dn * normal.x, ray.direct.y - 2.0f * dn * normal.y, ray.direct.z - 2.0f * dn * normal.z);
                 float al = pclamp(refly * u6, 0.0f, 1.0f);
                 v3 mixed = mk3(mixf(refl.x, rc.x, al), mixf(refl.y, rc.y, al), mixf(refl.z, rc.z, al));
-                sdir = normalize3(refl_lobe ? mixed : rc);   // diffuse(): normalize(randomCosine(n)), :106-119
+                sdir = normalize3(lobe_refl ? mixed : rc);   // diffuse(): normalize(randomCosine(n)), :106-119
             }
-            if (!refl_lobe) {
+            if (!lobe_refl) {
                 // ---- diffuse ray: diffuse(), shadinglib.glsl:106-119
                 WRay dr;
                 dr.color = incol * mk3(c_albedo[0], c_albedo[1], c_albedo[2]);
@@ -673,6 +681,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void rt_shade(ShadeArgs a) {
                 S_ACTIVE(rr.bf, R_TYPE(rr.bf) == 2 ? 0 : R_ACTIVE(rr.bf));
                 have[2] = create_ray(rr, in_texel, child_key(in_pkey, 2u), outs[2], a.t_sum, a.t_flag);
             }
+            };
+            lobe(refl_lobe);              // the surviving lobe
+            if (BOTH) lobe(!refl_lobe);   // ... and the other one, whose colour is 0 or NaN
             // ---- emissive: only its deposit (createRay of an inactive ray, rayslib.glsl:162-203)
             {
                 v3 ef = mk3(pmax(incol.x * c_emission[0], 0.0f), pmax(incol.y * c_emission[1], 0.0f), pmax(incol.z * c_emission[2], 0.0f));
@@ -920,10 +931,14 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
         TimedScope ts(c, CAT_SHADE);
         bool any_tex = false;
         for (int i = 1; i < MAX_TEXTURES; i++) any_tex = any_tex || r->tex_host[i].texels != nullptr;
-        if (any_tex && multi) rt_shade<true, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        else if (any_tex) rt_shade<true, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        else if (multi) rt_shade<false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
-        else rt_shade<false, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        // (both lobes of every hit are built where a dropped lobe's colour could be NaN instead of 0: textures -- any texel may be
+        // black metal or transparent --, materials that are not `ordinary`; see the kernel)
+        if (any_tex && multi) rt_shade<true, true, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else if (any_tex) rt_shade<true, false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else if (!r->mats_ordinary && multi) rt_shade<false, true, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else if (!r->mats_ordinary) rt_shade<false, false, true><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else if (multi) rt_shade<false, true, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
+        else rt_shade<false, false, false><<<nb, SHADE_BLOCK, 0, c->stream>>>(a);
         rt_scan_blocks<1024>   // (256 threads: the same with frames in flight, slower alone)
            <<<1, 1024, 0, c->stream>>>(r->d_block, nb, r->limit, r->q_bases[nxt], r->d_cnt, c->d_counters, r->h_cnt);
     }

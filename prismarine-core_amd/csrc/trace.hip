@@ -136,8 +136,8 @@ PSM_D unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(
 // changes gear: it takes the rays one after the other, and for each one
 //   * the ray's constants and state are broadcast (v_readlane) -- wave-uniform from here on, so every decision of the
 //     step (accepted? leaf? nearer child? push, pop, done?) is SCALAR arithmetic and a scalar branch: no lane masks;
-//   * lane j of each group of eight loads ITS part of the 32-byte node record (one round trip): lanes 0,1,2 the left
-//     child's x,y,z slabs (a min and a max half each), lanes 4,5,6 the right child's, lanes 3 and 7 the two links; a lane
+//   * lane j of each group of eight loads ONE word of the 32-byte node record and takes a second one from a neighbour by a
+//     quad permute: lanes 0,1,2 hold the left child's x,y,z slabs, lanes 4,5,6 the right child's, lanes 3 and 7 the links; a lane
 //     evaluates its two plane distances (the same v_fma_mix_f32 on the same operands), tNear / tFar are two quad-permute
 //     DPP v_max / v_min each, IN THE ORDER slab_child combines them (lane 0: ((x, y), z)), the acceptance tests run in lanes
 //     0 and 4 at once and reach the scalar unit as two bits of one ballot;
@@ -177,7 +177,7 @@ PSM_D void solo_park(uint32_t* xch, const v3 origin, const v3 direct, const v3 d
     xch[20] = (uint32_t)pl; xch[21] = (uint32_t)pr; xch[22] = (pLeftNear ? 1u : 0u) | (parked ? 2u : 0u);
 }
 template <bool COUNT>
-PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const float4* __restrict__ tri48, const int* lds_stack_col, const uint32_t* xch, uint32_t* sink,
+PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const float4* __restrict__ tri48, const int* lds_stack_col, const uint32_t* xch,
                     const int lj, int& bakedCount, Baked& head, Baked* extra, SoloCounters& ctr, unsigned long long& wave_steps) {
     const bool mine = lj == L;
     const int j8 = lj & 7, q = lj & 3;
@@ -193,10 +193,14 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
     int pl = __builtin_amdgcn_readfirstlane((int)xch[20]), pr = __builtin_amdgcn_readfirstlane((int)xch[21]);
     const int fl = __builtin_amdgcn_readfirstlane((int)xch[22]);
     bool pLeftNear = (fl & 1) != 0, parked = (fl & 2) != 0;
-    // this lane's part of a node record (12 halfs mn.xyz mx.xyz | mn.xyz mx.xyz, then the two links): lanes 0,1,2 of a group of
-    // eight take the left child's x,y,z slabs (their min and max halfs), lanes 4,5,6 the right child's, lanes 3 and 7 the links
+    // this lane's part of a node record. A child's box is six halfs in three words, [mn.x mn.y] [mn.z mx.x] [mx.y mx.z]; of a
+    // group of eight lanes, lanes 0,1,2 take the left child's x,y,z slabs, lanes 4,5,6 the right child's, lanes 3 and 7 the
+    // two links. Lane x loads word 0, lane y word 2, lane z word 1: every slab lane then finds one of its two planes in the LOW
+    // half of its own word (mn.x, mx.y, mn.z) and the other one in the HIGH half of the word its neighbour z, x, y loaded
+    // (mx.x, mn.y, mx.z) -- one load and one quad permute per lane, and which of the two is the min plane does not matter:
+    // the slab test takes min and max of the two distances (mathlib.glsl:152-157).
     const uint32_t child = (uint32_t)(j8 >> 2);
-    const uint32_t mnsel = child * 6u + (uint32_t)ax, lksel = 6u + child;
+    const uint32_t wsel = q == 3 ? 6u + child : child * 3u + (q == 0 ? 0u : (q == 1 ? 2u : 1u));
     // the ray's stack: entry k in lane k
     int stk = lj < sp ? lds_stack_col[(lj < STACK_CAP ? lj : 0) * TRAV_BLOCK + L] : 0;
     for (;;) {
@@ -237,12 +241,11 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
         if (sp < 0) break;
         it++;
         const bool lastIter = it >= MAX_ITERS;  // :383
-        const uint16_t* rec = (const uint16_t*)(node_dw + ((uint32_t)cur << 3));
-        const uint32_t hmn = rec[mnsel], hmx = rec[mnsel + 3u];   // (three loads of one 32-byte record: one round trip)
-        const uint32_t wd = node_dw[((uint32_t)cur << 3) + lksel];
+        const uint32_t wd = node_dw[((uint32_t)cur << 3) + wsel];
+        const uint32_t wn = (uint32_t)__builtin_amdgcn_mov_dpp((int)wd, 2 | (0 << 2) | (1 << 4) | (3 << 6), 0xF, 0xF, true);   // x <- z, y <- x, z <- y
         if (COUNT) { ctr.nV += mine ? 1u : 0u; wave_steps++; }
         // intersectCubeDual, mathlib.glsl:129-193: slab_child with one axis of one child per lane
-        const float tmin = fmaf(half_lo(hmn), my_dr, my_no), tmax = fmaf(half_lo(hmx), my_dr, my_no);
+        const float tmin = fmaf(half_lo(wd), my_dr, my_no), tmax = fmaf(half_hi(wn), my_dr, my_no);   // (or tmax, tmin: see above)
         const float lo_ = sminf(tmin, tmax), hi_ = smaxf(tmin, tmax);
         const float tNear = smaxf(smaxf(lo_, quad_perm<1, 2, 0, 3>(lo_)), quad_perm<2, 0, 1, 3>(lo_));   // lane 0 / 4: ((x, y), z)
         const float tFar = sminf(sminf(hi_, quad_perm<1, 2, 0, 3>(hi_)), quad_perm<2, 0, 1, 3>(hi_));
@@ -251,15 +254,6 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
         S.near = sminf(tNear, tFar);
         S.hit = (S.near <= -PZERO) ? smaxf(tNear, tFar) : S.near;
         const int lkx = rl_i((int)wd, 3), lky = rl_i((int)wd, 7);
-        // warm the lines the next steps will ask for -- an inner child's record, a leaf's triangle -- while this step's tests
-        // run: two lanes, one dword each, loaded straight into a dead LDS word (no register to wait for), so the next record or
-        // triangle arrives from the CU's L1 instead of L2 / Infinity Cache: the round trip is half of a lone wave's step
-        {
-            const int lk = lj == 0 ? lkx : lky;
-            const bool inner = lk >= 0;   // (selects, not branches: the address is computed by all lanes, two of them load)
-            const char* pa = (inner ? (const char*)node_dw : (const char*)tri48) + (size_t)(uint32_t)(inner ? lk : ~lk) * (inner ? 32u : 48u);
-            if (lj < 2) __builtin_amdgcn_global_load_lds((const uint32_t*)pa, sink, 4, 0, 0);
-        }
         const uint32_t okm = (uint32_t)lane_mask(child_ok(S, hitMax, dirlenInv, toffset, predist));
         const float Rnear = rl_f(S.near, 4);
         // from here on the step of rt_traverse in scalar registers (flags as 0 / 1 integers: one s_and / s_xor each)
@@ -364,7 +358,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const uint32_t* __restrict__ sm = ka.sm;
     struct { uint32_t cap, min_live, min_steps, final_rays; const uint32_t* in_count; } ph = {ka.cap, ka.min_live, ka.min_steps, ka.final_rays, ka.in_count};
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
-    __shared__ uint32_t xch[TRAV_BLOCK / 64][SOLO_MAX + 2][XCH_WORDS];   // solo_ray: rays on their way from their lanes to the wave; the last two blocks (64 words) swallow its prefetch loads
+    __shared__ uint32_t xch[TRAV_BLOCK / 64][SOLO_MAX][XCH_WORDS];   // solo_ray: rays on their way from their lanes to the wave
     const int tid = threadIdx.x;
     const bool resume = PHASED && ph.in_count != nullptr;
     const uint32_t total = resume ? *ph.in_count : nrays;
@@ -654,7 +648,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             for (int k = 0; work != 0ull; k++) {
                 const int Ls = __builtin_ctzll(work);
                 work &= work - 1ull;
-                solo_ray<COUNT>(Ls, (const uint32_t*)node32, tri48, &stack[0][tid & ~63], &xch[tid >> 6][k][0], &xch[tid >> 6][SOLO_MAX][0], lj, bakedCount, head, extra, sc, dg_steps);
+                solo_ray<COUNT>(Ls, (const uint32_t*)node32, tri48, &stack[0][tid & ~63], &xch[tid >> 6][k][0], lj, bakedCount, head, extra, sc, dg_steps);
             }
             if (COUNT) { nV = sc.nV; nT = sc.nT; nDrop = sc.nDrop; nCap = sc.nCap; nBakedDrop = sc.nBakedDrop; }
         }

@@ -6,7 +6,8 @@
 // the receiving side). It is synchronous on the host, bounded (every wait for a peer has a deadline and an abort flag,
 // PSM_ERR_PEER afterwards) and slow -- it exists so that psm_dist_render_frames / psm_dist_render_batch run against
 // peers that park in other rounds, own other band counts and fail (tests/test_gpu_dist.py); it is never picked
-// silently, and bench.py refuses it as the transport of a measured run.
+// silently (PSM_DIST_TRANSPORT=hoststaged asks for it), and a bench.py line that ran over it says "rehearsal": true at the top
+// level and carries value = null: nothing a driver could take for a scaling measurement.
 //
 // Segment: Header | Ctl[world] | i32 slots [world][I32_SLOT] | tile slots [world][slot_bytes].
 //   gather k:    rank r waits until root has consumed its slot of gather k-1 (g_done[r] >= k-1), copies its tile in,
@@ -152,6 +153,9 @@ extern "C" int psm_dist_connect_hoststaged(psm_dist* d, const char* shm_name, si
     const clk::time_point dead = clk::now() + std::chrono::milliseconds(timeout_ms);
     int fd = -1;
     if (d->rank == 0) {
+        // (callers name the segment for ONE run -- a uuid in the tests, a nonce from the side channel in dist.py --, so a file of
+        // that name can only be the leftover of a run that died between create and attach: out of the way with it)
+        (void)shm_unlink(shm_name);
         fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0) return fail(std::string("shm_open(create ") + shm_name + "): " + strerror(errno), PSM_ERR_STATE);
         if (ftruncate(fd, (off_t)t->total) != 0) { close(fd); shm_unlink(shm_name); return fail("ftruncate: " + std::string(strerror(errno)), PSM_ERR_CAPACITY); }

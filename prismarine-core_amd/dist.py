@@ -150,8 +150,12 @@ class Comm:
             if self.min_int(0 if err is not None else 1) == 0:
                 self._drop_native()
                 raise NativeUnavailable("psm_dist_prepare failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
+            # the segment's name carries a nonce of THIS run (rank 0's, summed over the side channel): a segment a killed run
+            # left behind under the same MASTER_PORT can be neither in the way of rank 0's exclusive create nor be opened by
+            # another rank in its place
+            nonce = self.sum_int(int.from_bytes(os.urandom(6), "little") if self.rank == 0 else 0)
             try:
-                self.native.connect_hoststaged("/psm-bench-%s" % os.environ.get("MASTER_PORT", "0"), max(int(slot_bytes), 4096))
+                self.native.connect_hoststaged("/psm-bench-%s-%012x" % (os.environ.get("MASTER_PORT", "0"), nonce), max(int(slot_bytes), 4096))
             except Exception as e:
                 err = e
             if self.min_int(0 if err is not None else 1) == 0:

@@ -29,6 +29,10 @@ def make_scene(scenes, cfg):
         return scenes.cornell(open_top=True)
     if name == "sponza_small":
         return scenes.sponza_like(n_tris=20011)
+    if name == "sponza":        # BASELINE C3 / C4's scene: S-sponza-like, 262 267 triangles
+        return scenes.sponza_like()
+    if name == "stress":        # BASELINE C5's scene: S-stress, 9 999 616 triangles
+        return scenes.stress()
     raise KeyError(name)
 
 

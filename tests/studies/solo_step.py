@@ -63,6 +63,9 @@ def main():
                     if st.wave_steps:
                         cps = st.wave_clock_ticks / st.wave_steps
                         best = cps if best is None else min(best, cps)
+                    if os.environ.get("PSM_SOLO_DBG") and solo and rep == 2:   # the instrumented experiment build (PSM_SOLO_DEBUG=2)
+                        print("      per node visit: load wait %.0f, slab + ballot %.0f, scalar step %.0f ticks (visits %d, wave-steps %d)" % (
+                            st.stack_drops / st.node_visits, st.iter_caps / st.node_visits, st.baked_drops / st.node_visits, st.node_visits, st.wave_steps))
                 print("%-38s %5d %8d %10d %12.0f %12.0f" % (name, solo, waves, int(v[order[:min(waves, 4096)]].max()), best, best / 2.35), flush=True)
         rt.close()
         th.close()

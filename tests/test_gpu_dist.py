@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEER = os.path.join(ROOT, "tests", "dist_peer.py")
 
 
-def run_group(tmp_path, world, timeout=240, **cfg):
+def run_group(tmp_path, world, timeout=420, **cfg):
     """Start `world` ranks (fresh processes sharing GPU 0), wait for all of them; returns their reports."""
     shm = "/psm-test-%s" % uuid.uuid4().hex[:12]
     out = str(tmp_path)
@@ -146,6 +146,30 @@ def test_weighted_band_dealing_equals_unsharded(psm, scenes, tmp_path, world, we
     shares = [pdist.owned_texels(r, world, w, h, weights) for r in range(world)]
     assert sum(shares) == w * h and shares[0] < min(shares[1:])
     check_equal(psm, scenes, tmp_path, world, scene="sponza_small", w=w, h=h, lanes=4, frames=6, seed=21, mode="frames", weights=weights)
+
+
+def test_c4_sponza_1080p_16_frames_tile_sharded_over_4_ranks(psm, scenes, tmp_path):
+    """BASELINE C4 -- S-sponza-like (262 267 triangles), 1920x1080, 16 frames (16 spp), tile-sharded -- through
+    psm_dist_render_frames with bench.py's default dealing (5 : 6 : 6 : 6 of every 23 bands), full rebuild per frame on every
+    rank. World 4, not 8: a GPU box lets 6 processes use its card at once (this one holds the unsharded reference), and the
+    ranks share one GPU through the host-staged transport -- the scheduler, the dealing, the padded tiles, rt_unpack_all and the
+    fold at the metric's full size, not the xGMI gather. Rank 0's image equals psm_lanes_render's: deposit counts exactly,
+    radiance to 1e-5; every rank reports the unsharded rounds per frame (Pipeline.inl:459-461 on the GLOBAL count)."""
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    weights = pdist.default_band_weights(4)
+    assert weights == [5, 6, 6, 6]
+    check_equal(psm, scenes, tmp_path, 4, scene="sponza", w=1920, h=1080, lanes=4, frames=16, seed=1000, mode="frames", weights=weights,
+                timeout_ms=180000)
+
+
+def test_c5_stress_2160p_tile_sharded_over_2_ranks(psm, scenes, tmp_path):
+    """BASELINE C5's scene and resolution sharded: S-stress (9 999 616 triangles, rebuilt per frame on every rank), 3840x2160,
+    2 frames, world 2 with the default 11 : 12 dealing. Same bar as above."""
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    weights = pdist.default_band_weights(2)
+    assert weights == [11, 12]
+    check_equal(psm, scenes, tmp_path, 2, scene="stress", w=3840, h=2160, lanes=2, frames=2, seed=1000, mode="frames", weights=weights,
+                timeout_ms=300000)
 
 
 def test_world3_rank_without_a_band(psm, scenes, tmp_path):
