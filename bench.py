@@ -93,6 +93,19 @@ def parse():
     return ap.parse_args()
 
 
+def sharded_lanes(steps):
+    """Frames in flight per GPU of a tile-sharded run. psm_dist_render_frames deals the frames to two lane groups that alternate
+    batches of lanes / 2 frames; 8 lanes are the measured optimum of a long run. A SHORT call -- the driver's
+    scaling runs are `--steps 20` -- pays for every batch a group runs, so the count is chosen such that the call is an even
+    number of full batches: 20 steps = 4 batches of 5 on 10 lanes (12.5 ms at a 1/8 tile) instead of 5 batches of 4 on 8, where
+    one group runs three batches and the other two (13.5 ms: +8 %, profiles/r04_tile_emulation.txt)."""
+    for lanes in (8, 10, 6, 12):
+        half = lanes // 2
+        if steps % half == 0 and (steps // half) % 2 == 0:
+            return lanes
+    return 8
+
+
 class Renderer:
     def __init__(self, psm, scenes, scene, args, dist):
         self.psm, self.dist, self.args = psm, dist, args
@@ -110,7 +123,7 @@ class Renderer:
             stream = dist.torch.cuda.current_stream().cuda_stream
             dist.same_stream = True
         w, h = args.width, args.height
-        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else 8)
+        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else sharded_lanes(args.steps))
         self.lane_streams = None
         streams = None
         if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
@@ -118,6 +131,10 @@ class Renderer:
             self.lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(self.lanes - 1)]
             streams = [st.cuda_stream for st in self.lane_streams]
         assert args.split == 1 or not dist.active, "--split is the one-GPU schedule; tile-sharded runs keep frames in flight instead"
+        if (args.split > 1 or args.group > 1 or args.traverse == "refill") and not psm.has_experimental():
+            raise SystemExit("bench: --split / --group / --traverse refill are schedules that lost every measurement (DESIGN.md 5.3) and live in an "
+                             "experimental library only: make -C prismarine-core_amd/csrc experimental, then "
+                             "PSM_HIP_LIB=$PWD/prismarine-core_amd/csrc/variants/libpsm_experimental.so")
         self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams, split=args.split, group=max(args.group, 1))
         self.batches = [self.batch]
         if args.split > 1:   # the serial passes (counters, per-stage times) render whole frames on an unsplit lane of their own

@@ -23,12 +23,12 @@ EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_copy_bandwidth", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev", "psm_sort_set_algorithm",
-    "psm_bvh_create", "psm_arena_create", "psm_arena_destroy", "psm_bvh_create_in_arena", "psm_rt_traverse_group", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
+    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_refill", "psm_rt_set_traverse_solo", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_render_grouped", "psm_lanes_render_split", "psm_rt_share_texels", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_solo", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -37,6 +37,22 @@ EXPORTS = [
     "psm_dist_transport_name", "psm_dist_agree", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
     "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile", "psm_dist_set_band_weights",
 ]
+
+# entry points of an EXPERIMENTAL library only (csrc/Makefile: `make experimental`; include/psm_hip.h's PSM_EXPERIMENTAL section): the
+# schedules that were measured and lost -- refill traversal, one traversal launch over several Pipelines, a frame split over
+# several Pipelines. PSM_HIP_LIB=<...>/variants/libpsm_experimental.so selects such a library; has_experimental() says which one is loaded.
+EXPERIMENTAL_EXPORTS = ['psm_arena_create', 'psm_arena_destroy', 'psm_bvh_create_in_arena', 'psm_rt_traverse_group', 'psm_rt_set_traverse_refill', 'psm_lanes_render_grouped', 'psm_lanes_render_split', 'psm_rt_share_texels']
+
+
+def has_experimental():
+    return all(hasattr(lib(), n) for n in EXPERIMENTAL_EXPORTS)
+
+
+def _need_experimental(what):
+    if not has_experimental():
+        raise PsmError("%s needs an experimental library (make -C prismarine-core_amd/csrc experimental; PSM_HIP_LIB=.../variants/"
+                       "libpsm_experimental.so): it lost every measurement and is not part of libpsm_hip.so (DESIGN.md 5.3)" % what)
+
 
 TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE, TRAVERSE_REFILL = range(5)
 TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE,
@@ -242,6 +258,7 @@ class Arena:
     def __init__(self, ctx, slots, max_tris):
         self.ctx, self.slots, self.max_tris = ctx, slots, max_tris
         self._h = C.c_void_p()
+        _need_experimental("psm_arena")
         ctx.check(lib().psm_arena_create(ctx._h, C.c_uint32(slots), C.c_size_t(max_tris), C.byref(self._h)), "psm_arena_create")
 
     def close(self):
@@ -591,10 +608,11 @@ class Pipeline:
 
     def setTraverseRefill(self, refill_min=32, waves_per_cu=28, min_rays=1 << 15):
         """psm_rt_set_traverse_refill: parameters of the "refill" schedule (does not select it)."""
+        _need_experimental("the refill schedule")
         self.ctx.check(lib().psm_rt_set_traverse_refill(self._h, C.c_uint32(refill_min), C.c_uint32(waves_per_cu),
                                                         C.c_uint32(min_rays)), "psm_rt_set_traverse_refill")
 
-    def setTraverseSolo(self, solo_max=2):
+    def setTraverseSolo(self, solo_max=1):
         """psm_rt_set_traverse_solo: a traversal wave left with at most solo_max rays (0..4) walks them one at a time with all its
         lanes on one ray; 0 switches the gear off. Results never depend on it."""
         self.ctx.check(lib().psm_rt_set_traverse_solo(self._h, C.c_uint32(solo_max)), "psm_rt_set_traverse_solo")
@@ -776,6 +794,8 @@ class FrameBatch:
         self.n = lanes
         self.split = split
         self.group = group
+        if split > 1 or group > 1:
+            _need_experimental("FrameBatch(split / group)")
         assert group >= 1 and lanes % group == 0 and (group == 1 or split == 1)
         self.arena = None
         self.lanes = []

@@ -269,6 +269,7 @@ int psm_bvh_destroy(psm_bvh* b) {
     return PSM_OK;
 }
 
+#if PSM_EXPERIMENTAL
 int psm_arena_destroy(psm_arena* a) {
     if (!a) return PSM_ERR_INVALID;
     (void)hipSetDevice(a->ctx->device);
@@ -292,12 +293,15 @@ int psm_arena_create(psm_ctx* c, uint32_t slots, size_t max_tris, psm_arena** ou
     return PSM_OK;
 }
 
+#endif
 static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t slot, psm_bvh** out);
 int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) { return bvh_create(c, max_tris, nullptr, 0, out); }
+#if PSM_EXPERIMENTAL
 int psm_bvh_create_in_arena(psm_ctx* c, psm_arena* arena, uint32_t slot, psm_bvh** out) {
     if (!c || !arena || !out || slot >= arena->slots || c->device != arena->ctx->device) return PSM_ERR_INVALID;
     return bvh_create(c, arena->max_tris, arena, slot, out);
 }
+#endif
 
 static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t slot, psm_bvh** out) {
     if (!c || !out || max_tris == 0) return PSM_ERR_INVALID;
@@ -727,6 +731,7 @@ int psm_rt_set_tile_weighted(psm_rt* r, uint32_t rank, uint32_t world, const uin
     return PSM_OK;
 }
 int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) { return psm_rt_set_tile_weighted(r, rank, world, nullptr); }
+#if PSM_EXPERIMENTAL
 // Several Pipelines that each trace a part of ONE frame (psm_lanes_render_split: the frame's bands dealt to `split`
 // Pipelines on one GPU, so that one part's traversal tail overlaps the other parts' rounds): they write the per-texel
 // results -- jitter position, radiance sum, flag -- of the texels they own into the SAME arrays, the owner's. Texels are
@@ -749,6 +754,7 @@ int psm_rt_share_texels(psm_rt* r, psm_rt* owner) {
     owner->texels_lent = true;
     return PSM_OK;
 }
+#endif
 int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {
     if (!r || !count) return PSM_ERR_INVALID;
     *count = tile_texel_count(r);
@@ -909,6 +915,7 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
     return launch_rt_traverse(r, b);
 }
 
+#if PSM_EXPERIMENTAL
 // One traversal launch over the current queues of n Pipelines, on `on`'s stream (NULL: rts[0]'s context). The caller orders
 // that stream after the queues' writers and the hits' readers after it (the grouped scheduler does it with events).
 static int traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
@@ -927,6 +934,7 @@ static int traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, 
     (void)hipSetDevice(c->device);
     return launch_rt_traverse_group(rts, bvhs, n, c, owner);
 }
+#endif
 
 int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
     if (!r) return PSM_ERR_INVALID;
@@ -935,7 +943,7 @@ int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
 }
 
 int psm_rt_set_traverse_mode(psm_rt* r, int mode) {
-    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_REFILL) return PSM_ERR_INVALID;
+    if (!r || mode < PSM_TRAVERSE_AUTO || mode > (PSM_EXPERIMENTAL ? 4 /* REFILL */ : PSM_TRAVERSE_ADAPTIVE)) return PSM_ERR_INVALID;
     r->trav_mode = mode;
     return PSM_OK;
 }
@@ -968,6 +976,7 @@ int psm_rt_set_traverse_solo(psm_rt* r, uint32_t solo_max) {
     return PSM_OK;
 }
 
+#if PSM_EXPERIMENTAL
 int psm_rt_set_traverse_refill(psm_rt* r, uint32_t refill_min, uint32_t waves_per_cu, uint32_t min_rays) {
     if (!r || refill_min < 1 || refill_min > 64 || waves_per_cu < 2 || waves_per_cu > 32 || (waves_per_cu & 1u)) return PSM_ERR_INVALID;
     r->refill_min = refill_min;
@@ -975,6 +984,7 @@ int psm_rt_set_traverse_refill(psm_rt* r, uint32_t refill_min, uint32_t waves_pe
     r->refill_min_rays = min_rays;
     return PSM_OK;
 }
+#endif
 
 int psm_rt_reset_hits(psm_rt* r) {
     if (!r) return PSM_ERR_INVALID;

@@ -17,7 +17,9 @@
 
 #include <algorithm>
 
+#if PSM_EXPERIMENTAL
 extern "C" int psm_rt_traverse_group_owned(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
+#endif
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -489,6 +491,7 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
 }
 
 
+#if PSM_EXPERIMENTAL
 // ---- one frame split over several Pipelines of ONE GPU --------------------------------------------------------------
 //
 // The reference renders one frame at a time (Viewer.cpp:296-312), and a frame's bounce round cannot end before its
@@ -808,3 +811,4 @@ extern "C" int psm_lanes_render_grouped(psm_rt* const* rts, psm_bvh* const* bvhs
         if (G[g].ev_trav) (void)hipEventDestroy(G[g].ev_trav);
     return rc;
 }
+#endif   // PSM_EXPERIMENTAL (split frames, grouped launches)

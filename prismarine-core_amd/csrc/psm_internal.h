@@ -247,7 +247,7 @@ struct psm_rt {
     uint32_t adapt_min_live = 12, adapt_min_steps = 8, adapt_final_rays = 65536, adapt_max_launches = 4;  // tuned on C3, 4 frames in flight (its 2 M-ray rounds plan three launches either way; C5's 8 M-ray rounds take the fourth: -1.3 %)
     uint32_t refill_min = 32, refill_waves_per_cu = 28, refill_min_rays = 1u << 15;  // PSM_TRAVERSE_REFILL (trace.hip)
     bool mats_ordinary = true;      // no material whose dropped lobe's colour can be NaN (psm_rt_set_materials): rt_shade builds one lobe per hit
-    uint32_t solo_max = 2;          // a traversal wave with at most this many rays left walks them one by one, all lanes on one ray (trace.hip: solo_ray); 0: never
+    uint32_t solo_max = 1;          // a traversal wave with at most this many rays left walks them one by one, all lanes on one ray (trace.hip: solo_ray); 0: never. 1: a frame alone 3.37 -> 3.20 ms, a 1/8 tile 0.633 -> 0.611, 4 frames in flight 2.21 -> 2.19; 2: 3.24 / 0.620 / 2.19 (profiles/r04_solo_gear.txt)
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
     uint32_t phase_min_rays = 1u << 19;  // smaller intersections run as one launch (tiles: tools/run_r02_ae.sh)
     // frames in flight (lanes.hip): pinned slot + events, created on first use

@@ -768,6 +768,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     }
 }
 
+#if PSM_EXPERIMENTAL
 // ---- REFILL: persistent waves that take new rays in batches --------------------------------------------------------
 //
 // The schedules above fix which 64 rays a wave traces; a wave64 then steps as long as its slowest ray and half of every
@@ -1029,6 +1030,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka)
     }
 }
 
+#endif   // PSM_EXPERIMENTAL (REFILL)
+
 constexpr uint32_t RESUME_GRID_CAP = 256 * 32 / (TRAV_BLOCK / 64);  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
 // continuation queues of the hand-over schedules: `need` entries at least (a launch over several Pipelines' queues can hold
@@ -1068,7 +1071,9 @@ static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<Ph
     // kernels fill the tails its extra launches add); a frame on its own is bound by its longest ray, which the extra
     // launches serialise, so it runs one launch; so do rounds under phase_min_rays rays (tiles).
     if (mode == PSM_TRAVERSE_AUTO) mode = r->in_flight > 1 ? PSM_TRAVERSE_ADAPTIVE : PSM_TRAVERSE_WHOLE;
+#if PSM_EXPERIMENTAL
     if (mode == PSM_TRAVERSE_REFILL) return n >= r->refill_min_rays ? PSM_TRAVERSE_REFILL : PSM_TRAVERSE_WHOLE;
+#endif
     if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_PHASED) {
         for (int k = 0; k < r->phase_caps_n; k++) plan.push_back(PhasePlan{r->phase_caps[k], 0u});
@@ -1108,6 +1113,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
         ta.cap = 0xFFFFFFFFu;
         ta.solo_max = r->solo_max;
+#if PSM_EXPERIMENTAL
         if (mode == PSM_TRAVERSE_REFILL) {
             // persistent waves over a pool of rays: at most refill_waves waves per CU, never more lanes than rays
             const uint32_t per_block = TRAV_BLOCK;
@@ -1120,7 +1126,9 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
             TimedScope ts(c, CAT_TRAVERSE_HANDOVER);
             if (c->counting) rt_traverse_refill<true><<<blocks, TRAV_BLOCK, 0, c->stream>>>(ta);
             else rt_traverse_refill<false><<<blocks, TRAV_BLOCK, 0, c->stream>>>(ta);
-        } else if (mode == PSM_TRAVERSE_WHOLE) {
+        } else
+#endif
+        if (mode == PSM_TRAVERSE_WHOLE) {
             TimedScope ts(c, CAT_TRAVERSE);
             if (chain) {
                 if (c->counting) rt_traverse<true, true, false><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
@@ -1173,6 +1181,7 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     return PSM_OK;
 }
 
+#if PSM_EXPERIMENTAL
 // One traversal launch over the current queues of n Pipelines (psm_rt_traverse_group). Every Pipeline's hierarchy must sit in
 // a slot of the same psm_arena (or n == 1); the launch goes to `on`'s stream, and the caller has ordered that stream
 // after whatever wrote the queues and before whatever reads the hits. Schedule as launch_rt_traverse chooses it for rts[0]
@@ -1262,5 +1271,7 @@ int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t 
     }
     return PSM_OK;
 }
+
+#endif   // PSM_EXPERIMENTAL (one launch over several Pipelines)
 
 }  // namespace psm

@@ -18,6 +18,7 @@ A scene is a dict of numpy arrays:
   eye, view float32 [3]     default camera
 """
 import math
+import logging
 import os
 
 import numpy as np
@@ -305,16 +306,37 @@ def stress(n_tris=10_000_000, seed=SEED_STRESS):
 # ---------------------------------------------------------------------------
 
 def write_obj(path, scene):
+    """The scene as Wavefront OBJ + MTL: v / vn per corner, vt (u, 1 - stored v) where the scene has texcoords, usemtl runs,
+    Kd / Ks / Ke (+ d) per material and map_Kd / map_Ke / map_Ks / map_Bump for its texture parts -- each image as
+    `<stem>_tex<slot>.png.npy` (the pre-decoded form read_obj prefers) and, where PIL is importable, as the PNG itself."""
     tris, normals, mats = scene["tris"], scene["normals"], scene["mats"]
-    mtl = os.path.splitext(path)[0] + ".mtl"
+    stem = os.path.splitext(path)[0]
+    mtl = stem + ".mtl"
+    tc = scene.get("texcoords")
+    part_stmt = (("diffusePart", "map_Kd"), ("emissivePart", "map_Ke"), ("specularPart", "map_Ks"), ("bumpPart", "map_Bump"))
+    for slot, img in (scene.get("textures") or {}).items():
+        name = "%s_tex%d.png" % (stem, slot)
+        np.save(name + ".npy", np.ascontiguousarray(img, np.uint8))
+        try:
+            from PIL import Image
+            Image.fromarray(np.ascontiguousarray(img, np.uint8), "RGBA").save(name)
+        except ImportError:
+            pass
     with open(mtl, "w") as f:
         for i, m in enumerate(scene["materials"]):
-            f.write("newmtl m%d\nKd %.6f %.6f %.6f\nKs %.6f %.6f %.6f\nKe %.6f %.6f %.6f\n\n" % (
-                (i,) + tuple(m["diffuse"][:3]) + tuple(m["specular"][:3]) + tuple(m["emissive"][:3])))
+            f.write("newmtl m%d\nKd %.9g %.9g %.9g\nd %.9g\nKs %.9g %.9g %.9g\nKe %.9g %.9g %.9g\n" % (
+                (i,) + tuple(m["diffuse"][:3]) + (m["diffuse"][3],) + tuple(m["specular"][:3]) + tuple(m["emissive"][:3])))
+            for part, stmt in part_stmt:
+                if m.get(part):
+                    f.write("%s %s_tex%d.png\n" % (stmt, os.path.basename(stem), m[part]))
+            f.write("\n")
     with open(path, "w") as f:
         f.write("mtllib %s\n" % os.path.basename(mtl))
         for p in tris.reshape(-1, 3):
             f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        if tc is not None:
+            for p in np.asarray(tc, np.float32).reshape(-1, 2):
+                f.write("vt %.9g %.9g\n" % (p[0], np.float32(1.0) - p[1]))
         for p in normals.reshape(-1, 3):
             f.write("vn %.9g %.9g %.9g\n" % tuple(p))
         cur = -1
@@ -323,74 +345,186 @@ def write_obj(path, scene):
                 cur = int(mats[t])
                 f.write("usemtl m%d\n" % cur)
             a = 3 * t + 1
-            f.write("f %d//%d %d//%d %d//%d\n" % (a, a, a + 1, a + 1, a + 2, a + 2))
+            if tc is not None:
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, a + 1, a + 1, a + 1, a + 2, a + 2, a + 2))
+            else:
+                f.write("f %d//%d %d//%d %d//%d\n" % (a, a, a + 1, a + 1, a + 2, a + 2))
 
 
-def read_mtl(path):
-    names, mats = {}, []
+log = logging.getLogger("prismarine.scenes")
+
+# MTL statements that name an image, and the VirtualMaterial texture part each one feeds (surface.comp:100-161)
+_MTL_MAPS = {"map_kd": "diffusePart", "map_ke": "emissivePart", "map_ks": "specularPart", "map_pr": "specularPart", "map_pm": "specularPart",
+             "map_bump": "bumpPart", "bump": "bumpPart", "norm": "bumpPart"}
+# statements the path has no use for: counted, logged, never silently dropped
+_MTL_KNOWN_UNUSED = ("ka", "ns", "ni", "illum", "tf", "tr", "sharpness", "map_ka", "map_d", "map_ns", "disp", "decal", "refl", "pc", "pcr", "ps", "aniso", "anisor")
+_OBJ_KNOWN_UNUSED = ("o", "g", "s", "vp", "l", "p", "cstype", "deg", "curv", "curv2", "surf", "parm", "trim", "hole", "scrv", "sp", "end", "con", "mg", "bevel",
+                     "c_interp", "d_interp", "lod", "shadow_obj", "trace_obj", "maplib", "usemap")
+
+
+def load_image_rgba8(path):
+    """An image as uint8 [h, w, 4], row 0 = the image's top row. `<path>.npy` (a pre-decoded copy: what travels to a GPU box,
+    where nothing is decoded) wins; otherwise the file is decoded with PIL where PIL is importable."""
+    if os.path.exists(path + ".npy"):
+        a = np.load(path + ".npy")
+    else:
+        try:
+            from PIL import Image
+        except ImportError as e:
+            raise FileNotFoundError("%s: no pre-decoded %s.npy beside it and no PIL to decode it with" % (path, os.path.basename(path))) from e
+        a = np.asarray(Image.open(path).convert("RGBA"))
+    if a.ndim != 3 or a.shape[2] != 4 or a.dtype != np.uint8:
+        raise ValueError("%s: expected uint8 [h, w, 4], got %s %s" % (path, a.dtype, a.shape))
+    return np.ascontiguousarray(a)
+
+
+def read_mtl(path, ignored=None):
+    """Wavefront MTL -> (name -> index, [material dicts], {index: {part: image file}}).
+    Kd -> diffuse rgb, d -> diffuse alpha, Ke -> emissive, Ks -> specular as the path reads it (.y roughness, .z metallic:
+    surface.comp:189; what write_obj writes back), Pr / Pm (the PBR extension) -> roughness / metallic over Ks; map_Kd, map_Ke,
+    map_Ks (map_Pr, map_Pm), map_Bump (bump, norm) -> the diffuse / emissive / specular / bump texture part (options such as
+    `-bm 1` in front of the file name are skipped). Everything else lands in `ignored` (statement -> count)."""
+    names, mats, maps = {}, [], {}
     cur = None
+    ignored = {} if ignored is None else ignored
     if not os.path.exists(path):
-        return names, mats
-    for line in open(path):
-        p = line.split()
-        if not p or p[0].startswith("#"):
+        ignored["mtllib (file not found: %s)" % os.path.basename(path)] = ignored.get("mtllib (file not found: %s)" % os.path.basename(path), 0) + 1
+        return names, mats, maps
+    for ln, line in enumerate(open(path, errors="replace"), 1):
+        p = line.split("#", 1)[0].split()
+        if not p:
             continue
-        if p[0] == "newmtl":
-            cur = _material((0.8, 0.8, 0.8))
-            names[p[1]] = len(mats)
-            mats.append(cur)
-        elif cur is not None and p[0] == "Kd":
-            cur["diffuse"] = tuple(map(float, p[1:4])) + (1.0,)
-        elif cur is not None and p[0] == "Ks":
-            cur["specular"] = tuple(map(float, p[1:4])) + (0.0,)
-        elif cur is not None and p[0] == "Ke":
-            cur["emissive"] = tuple(map(float, p[1:4])) + (1.0,)
-    return names, mats
+        key = p[0].lower()
+        try:
+            if key == "newmtl":
+                cur = _material((0.8, 0.8, 0.8))
+                names[" ".join(p[1:])] = len(mats)
+                mats.append(cur)
+            elif cur is None:
+                raise ValueError("statement before the first newmtl")
+            elif key == "kd":
+                cur["diffuse"] = tuple(map(float, p[1:4])) + (cur["diffuse"][3],)
+            elif key == "d":
+                cur["diffuse"] = cur["diffuse"][:3] + (float(p[-1]),)
+            elif key == "ks":
+                cur["specular"] = tuple(map(float, p[1:4])) + (0.0,)
+            elif key == "pr":
+                cur["specular"] = (cur["specular"][0], float(p[1]), cur["specular"][2], 0.0)
+            elif key == "pm":
+                cur["specular"] = (cur["specular"][0], cur["specular"][1], float(p[1]), 0.0)
+            elif key == "ke":
+                cur["emissive"] = tuple(map(float, p[1:4])) + (1.0,)
+            elif key in _MTL_MAPS:
+                maps.setdefault(len(mats) - 1, {})[_MTL_MAPS[key]] = p[-1]    # the file name is the last token (options precede it)
+            else:
+                tag = key if key in _MTL_KNOWN_UNUSED else key + " (unknown)"
+                ignored["mtl " + tag] = ignored.get("mtl " + tag, 0) + 1
+        except (ValueError, IndexError) as e:
+            raise ValueError("%s:%d: malformed `%s` (%s)" % (path, ln, line.strip(), e)) from e
+    return names, mats, maps
 
 
 def read_obj(path):
-    """Triangles (fans for polygons), optional vn, usemtl. Returns a scene dict."""
-    V, VN, T, TN, M = [], [], [], [], []
-    names, materials = {}, []
+    """Wavefront OBJ -> a scene dict. v / vt / vn / f (v, v/vt, v//vn, v/vt/vn; negative = relative indices; polygons as
+    fans), mtllib / usemtl; texcoords are stored as (u, 1 - v) -- the loader's INVERT_TX_Y, vertex/loader.comp:97-99 -- and only
+    where the file has a `vt` (a face without them gets 0, 0); images named by the materials are loaded into texture slots
+    1.. in order of first use (TextureSet.inl:42-86: slot 0 = none) and the materials' *Part fields point at them.
+    A malformed face (fewer than three corners, an index that is 0 or out of range) raises ValueError with file and line;
+    statements the path does not use are counted in scene["ignored"] and logged, not dropped in silence."""
+    V, VT, VN, T, TT, TN, M = [], [], [], [], [], [], []
+    names, materials, maps = {}, [], {}
+    ignored = {}
     cur = 0
     base = os.path.dirname(path)
-    for line in open(path):
-        p = line.split()
-        if not p or p[0].startswith("#"):
+
+    def resolve(tok, n, what, ln):
+        i = int(tok)
+        j = i - 1 if i > 0 else n + i
+        if i == 0 or j < 0 or j >= n:
+            raise ValueError("%s:%d: %s index %d out of range (1..%d)" % (path, ln, what, i, n))
+        return j
+
+    for ln, line in enumerate(open(path, errors="replace"), 1):
+        p = line.split("#", 1)[0].split()
+        if not p:
             continue
-        if p[0] == "v":
-            V.append(tuple(map(float, p[1:4])))
-        elif p[0] == "vn":
-            VN.append(tuple(map(float, p[1:4])))
-        elif p[0] == "mtllib":
-            names, materials = read_mtl(os.path.join(base, p[1]))
-        elif p[0] == "usemtl":
-            if p[1] not in names:
-                names[p[1]] = len(materials)
-                materials.append(_material((0.8, 0.8, 0.8)))
-            cur = names[p[1]]
-        elif p[0] == "f":
-            idx = []
-            for tok in p[1:]:
-                q = tok.split("/")
-                vi = int(q[0])
-                ni = int(q[2]) if len(q) > 2 and q[2] else 0
-                idx.append((vi - 1 if vi > 0 else len(V) + vi, (ni - 1 if ni > 0 else len(VN) + ni) if ni else -1))
-            for k in range(1, len(idx) - 1):
-                tri = (idx[0], idx[k], idx[k + 1])
-                T.append([V[a] for a, _ in tri])
-                TN.append([VN[b] if b >= 0 else (0.0, 0.0, 0.0) for _, b in tri])
-                M.append(cur)
+        key = p[0]
+        try:
+            if key == "v":
+                V.append(tuple(map(float, p[1:4])))
+                if len(V[-1]) != 3:
+                    raise ValueError("a vertex needs three coordinates")
+            elif key == "vt":
+                VT.append((float(p[1]), float(p[2]) if len(p) > 2 else 0.0))
+            elif key == "vn":
+                VN.append(tuple(map(float, p[1:4])))
+            elif key == "mtllib":
+                n2, m2, mp2 = read_mtl(os.path.join(base, " ".join(p[1:])), ignored)
+                for k, v in mp2.items():
+                    maps[len(materials) + k] = v
+                for k, v in n2.items():
+                    names.setdefault(k, len(materials) + v)
+                materials += m2
+            elif key == "usemtl":
+                nm = " ".join(p[1:])
+                if nm not in names:
+                    names[nm] = len(materials)
+                    materials.append(_material((0.8, 0.8, 0.8)))
+                    ignored["usemtl of an undefined material"] = ignored.get("usemtl of an undefined material", 0) + 1
+                cur = names[nm]
+            elif key == "f":
+                if len(p) < 4:
+                    raise ValueError("a face needs at least three corners")
+                idx = []
+                for tok in p[1:]:
+                    q = tok.split("/")
+                    vi = resolve(q[0], len(V), "vertex", ln)
+                    ti = resolve(q[1], len(VT), "texcoord", ln) if len(q) > 1 and q[1] else -1
+                    ni = resolve(q[2], len(VN), "normal", ln) if len(q) > 2 and q[2] else -1
+                    idx.append((vi, ti, ni))
+                for k in range(1, len(idx) - 1):
+                    tri = (idx[0], idx[k], idx[k + 1])
+                    T.append([V[a] for a, _, _ in tri])
+                    TT.append([(VT[b][0], 1.0 - VT[b][1]) if b >= 0 else (0.0, 0.0) for _, b, _ in tri])
+                    TN.append([VN[c] if c >= 0 else (0.0, 0.0, 0.0) for _, _, c in tri])
+                    M.append(cur)
+            else:
+                tag = key if key in _OBJ_KNOWN_UNUSED else key + " (unknown)"
+                ignored["obj " + tag] = ignored.get("obj " + tag, 0) + 1
+        except (ValueError, IndexError) as e:
+            if str(e).startswith(path):
+                raise
+            raise ValueError("%s:%d: malformed `%s` (%s)" % (path, ln, line.strip(), e)) from e
+    if not T:
+        raise ValueError("%s: no faces" % path)
     if not materials:
         materials = [_material((0.8, 0.8, 0.8))]
+    # images -> texture slots, in order of first use; a material keeps the slot number in its *Part field
+    textures, slot_of = {}, {}
+    for mi in sorted(maps):
+        for part, fname in maps[mi].items():
+            full = os.path.join(base, fname.replace("\\", "/"))
+            if full not in slot_of:
+                if len(textures) >= 31:
+                    raise ValueError("%s: more than 31 images (samplers[MAX_TEXTURES], surface.comp:46-52)" % path)
+                slot_of[full] = len(textures) + 1
+                textures[slot_of[full]] = load_image_rgba8(full)
+            materials[mi] = dict(materials[mi], **{part: slot_of[full]})
     tris = np.asarray(T, np.float32).reshape(-1, 3, 3)
     normals = prepare_normals(tris, np.asarray(TN, np.float32).reshape(-1, 3, 3))
     lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
     c, ext = 0.5 * (lo + hi), float((hi - lo).max())
-    return {"name": os.path.basename(path), "tris": tris, "normals": normals,
-            "mats": np.asarray(M, np.int32), "materials": materials,
-            "eye": (c + np.asarray((0.0, 0.6 * ext, 1.4 * ext))).astype(np.float32),
-            "view": c.astype(np.float32)}
+    if ignored:
+        log.info("%s: statements the path does not use: %s", path, ", ".join("%s x%d" % kv for kv in sorted(ignored.items())))
+    sc = {"name": os.path.basename(path), "tris": tris, "normals": normals,
+          "mats": np.asarray(M, np.int32), "materials": materials, "ignored": ignored,
+          "eye": (c + np.asarray((0.0, 0.6 * ext, 1.4 * ext))).astype(np.float32),
+          "view": c.astype(np.float32)}
+    if VT:
+        sc["texcoords"] = np.asarray(TT, np.float32).reshape(-1, 3, 2)
+    if textures:
+        sc["textures"] = textures
+    return sc
 
 
 def materials_array(materials):

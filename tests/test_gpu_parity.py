@@ -4,12 +4,21 @@ Bit-exact for Morton codes, sort order, BVH topology + boxes and hit chains; bit
 queues the shading kernel emits; accumulated radiance within 1e-4 relative (the only GPU/CPU
 difference left is the order of the float atomic adds into a texel).
 """
+import os
+
 import numpy as np
 import pytest
 
 from util import bits, canonical_nodes
 
 pytestmark = pytest.mark.gpu
+
+
+def _experimental(psm):
+    """The schedules that were measured and lost (refill traversal, grouped launches, split frames: DESIGN.md 5.3) live in
+    `make -C prismarine-core_amd/csrc experimental`'s library only; their parity tests run where PSM_HIP_LIB points at it."""
+    if not psm.has_experimental():
+        pytest.skip("needs the experimental library (PSM_HIP_LIB=.../csrc/variants/libpsm_experimental.so)")
 
 
 def _load(psm, ctx, scene):
@@ -470,8 +479,8 @@ TRAVERSE_SCHEDULES = [
     ("adaptive", {"min_live": 64, "min_steps": 0, "final_rays": 0, "max_launches": 15}),   # hand over at the first idle lane
     ("adaptive", {"min_live": 2, "min_steps": 1, "final_rays": 0, "max_launches": 3}),
     ("adaptive", {"min_live": 24, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
-    ("whole", {"solo": 0}),      # the solo gear (psm_rt_set_traverse_solo) off, at its default (2: every entry above and below), and wider
-    ("whole", {"solo": 1}),
+    ("whole", {"solo": 0}),      # the solo gear (psm_rt_set_traverse_solo) off, at its default (1: every entry above and below), and wider
+    ("whole", {"solo": 2}),
     ("whole", {"solo": 4}),
     ("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 256, "max_launches": 8, "solo": 4}),
     ("adaptive", {"min_live": 12, "min_steps": 8, "final_rays": 65536, "max_launches": 3, "solo": 0}),
@@ -501,6 +510,8 @@ def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, k
     """psm_rt_set_traverse_mode: every kernel schedule that ships -- one launch, fixed-cap phases, ballot-triggered
     hand-over with persistent resume waves -- gives the hits, chains and
     V / T counters of the oracle's uninterrupted per-ray loop (directTraverse.comp:333-484)."""
+    if mode == "refill":
+        _experimental(psm)
     scene = scenes.sponza_like(n_tris=20011)
     w, h = 160, 90
     th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
@@ -530,6 +541,8 @@ def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, k
 def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes, mode, kw):
     """Rays that carry an equal-distance chain of two or more hits cannot hand over (their chain lives in registers):
     they finish in the launch they are in. Duplicated coplanar triangles make thousands of them."""
+    if mode == "refill":
+        _experimental(psm)
     rng = np.random.RandomState(5)
     base = scenes.sponza_like(n_tris=6007)["tris"]
     tris = np.ascontiguousarray(np.concatenate([base, base[:1500]], 0))
@@ -688,6 +701,43 @@ def test_accumulated_radiance(psm, ctx, oracle, scenes, name, w, h, frames):
     ref, stats = oracle.render_frames(scene, w, h, frames=frames, seed=31337, nthreads=8)
     assert stats["rays"] > w * h * frames
     assert ref[..., :3].max() > 0.1
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    rt.close()
+    th.close()
+
+
+OBJ_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj")
+
+
+@pytest.mark.parametrize("stem", ["box", "rbox", "sphere", "Cow", "shelf"])
+def test_obj_files_build_hits_and_radiance(psm, ctx, oracle, scenes, stem):
+    """Models the builder did not write (tests/golden/obj: the reference's Resources/toys data files -- Blender / 3ds Max exports
+    with v / vt / vn faces, groups and four materials) and one textured model of this repo's (map_Kd / map_Bump / map_Ke / map_Ks),
+    from file to image: the HLBVH bit for bit (bounds, Morton codes, order, topology, boxes), the primary rays' hit chains at
+    64x64 bit for bit, and three frames of accumulated radiance within 1e-4 -- textures through TextureSet slots and the
+    texcoords read from `vt` (stored 1 - v, loader.comp:97-99) where the file has them."""
+    scene = scenes.read_obj(os.path.join(OBJ_DIR, stem + ".obj"))
+    assert (stem == "shelf") == bool(scene.get("textures"))
+    _check_build(psm, ctx, oracle, scene)
+    w = h = 64
+    th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
+    ob = oracle.build_scene(scene["tris"])
+    rt.camera_matrices(cam[0], cam[1], time=7)
+    rt.applyMaterials(ms)
+    rays = rt.download_rays()
+    rt.intersection(th)
+    gh, gc = rt.download_hits(rays.shape[0])
+    oh, oc, _ = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], rays["origin"], rays["direct"], 8)
+    _hits_equal(gh, gc, oh, oc)
+    assert (oc > 0).mean() > 0.1                      # the default camera sees the model
+    rt.setSeed(4711)
+    rt.clearSampler()
+    for _ in range(3):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    img = rt.snapHdr()
+    ref, stats = oracle.render_frames(scene, w, h, frames=3, seed=4711, nthreads=8)
+    assert ref[..., :3].max() > 0.05
     np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
     assert np.array_equal(img[..., 3], ref[..., 3])
     rt.close()
@@ -1091,6 +1141,7 @@ def test_frame_split_over_parts_equals_unsplit_frames(psm, oracle, scenes, name,
     tail under the others' rounds), with the `fewer than 32 rays -> stop` rule applied to the frame's total. The image,
     the rounds and the rays traced per frame equal psm_lanes_render's for the same seeds; one frame at a time
     (lanes = 1) and two frames in flight; 64x16 = two bands on four parts (parts without a band)."""
+    _experimental(psm)
     scene = _scene(scenes, name)
     ms = psm.MaterialSet()
     for m in scene["materials"]:
@@ -1158,6 +1209,7 @@ def test_one_traversal_launch_over_several_pipelines_is_bit_exact(psm, ctx, orac
     scenes in the slots of one Arena, whose traversal records carry arena-wide links and triangle ids -- traced by ONE launch
     (every schedule: the hand-over mixes rays of all three in its resume waves). Per Pipeline the hits, chains, V and T are
     the oracle's for its scene; what the hierarchies hand out (topology, boxes, root) is unchanged by the arena."""
+    _experimental(psm)
     rng = np.random.RandomState(11)
     sc = [scenes.sponza_like(n_tris=6007), scenes.cornell(open_top=True), scenes.sponza_like(n_tris=20011)]
     cap = max(s_["tris"].shape[0] for s_ in sc)
@@ -1212,6 +1264,7 @@ def test_grouped_frames_equal_ungrouped_frames(psm, oracle, scenes, name, w, h, 
     """psm_lanes_render_grouped: the lanes form groups whose frames trace every bounce round in one launch over all their
     queues (each frame against its own rebuilt hierarchy in the batch's arena) -- image, rounds and rays per frame equal
     psm_lanes_render's for the same seeds; a short last batch (7 frames on groups of 2), one group of all lanes, groups of 3."""
+    _experimental(psm)
     scene = _scene(scenes, name)
     ms = psm.MaterialSet()
     for m in scene["materials"]:
