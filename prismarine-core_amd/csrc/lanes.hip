@@ -77,6 +77,28 @@ static int fold(psm_rt* r, psm_rt* src, bool* defer = nullptr, bool recorded = f
 
 int rt_fold(psm_rt* r, psm_rt* src, bool* defer) { return fold(r, src, defer); }
 
+// The one step every scheduler of this file is made of. A bounce round of a lane's frame, queued on the lane's stream:
+// intersection + shade (whose segment scan writes the next ray count straight into the lane's pinned slot) + the event that
+// marks the count's arrival ...
+static int lane_queue_round(psm_rt* r, psm_bvh* b, uint32_t time) {
+    int e = psm_rt_traverse(r, b);
+    if (e != PSM_OK) return e;
+    e = psm_rt_shade(r, b, time);
+    if (e != PSM_OK) return e;
+    PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
+    return PSM_OK;
+}
+// ... and one non-blocking look at it: 1 = the round has ended and r->ray_count is what reloadQueuedRays would have learnt
+// (Pipeline.inl:325-359), 0 = still in flight, < 0 = error.
+static int lane_poll_round(psm_rt* r) {
+    hipError_t q = hipEventQuery(r->ev_cnt);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return set_err(r->ctx, PSM_ERR_HIP, "hipEventQuery", q);
+    r->ray_count = *r->h_cnt;
+    r->count_valid = true;
+    return 1;
+}
+
 }  // namespace psm
 
 using namespace psm;
@@ -117,12 +139,9 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
     auto queue_round = [&](Lane& ln) -> int {  // intersection + shade + asynchronous read-back of the next count
         psm_rt* r = ln.rt;
         ln.rays += r->ray_count;
-        int e = psm_rt_traverse(r, ln.bvh);
-        if (e != PSM_OK) return e;
-        e = psm_rt_shade(r, ln.bvh, lcg_next(ln.rand));
+        int e = lane_queue_round(r, ln.bvh, lcg_next(ln.rand));
         if (e != PSM_OK) return e;
         ln.round++;
-        PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
         return PSM_OK;
     };
     uint32_t next_frame = 0;
@@ -184,15 +203,13 @@ extern "C" int psm_lanes_render(psm_rt* const* rts, psm_bvh* const* bvhs, uint32
                 issue_s += std::chrono::duration<double>(t_issued[s] - t0).count();
                 progressed = true;
             } else if (ln.state == RUNNING) {
-                hipError_t q = hipEventQuery(ln.rt->ev_cnt);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) { rc = set_err(ln.rt->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
+                const int q = lane_poll_round(ln.rt);
+                if (q == 0) continue;
+                if (q < 0) { rc = q; break; }
                 progressed = true;
                 t_seen[s] = clk::now();
                 gpu_wait_s += std::chrono::duration<double>(t_seen[s] - t_issued[s]).count();
                 waits++;
-                ln.rt->ray_count = *ln.rt->h_cnt;  // what reloadQueuedRays learns (Pipeline.inl:325-359)
-                ln.rt->count_valid = true;
                 if (ln.round >= depth || ln.rt->ray_count < 32) { rc = finish(ln); t_issued[s] = clk::now(); }
                 else {
                     const clk::time_point t0 = clk::now();
@@ -284,11 +301,8 @@ struct ShardedLanes {
         rounds[s]++;
         if (r->ray_count == 0) return PSM_OK;  // nothing to trace: the lane is re-examined at once
         traced[s] += r->ray_count;
-        int e = psm_rt_traverse(r, bvhs[s]);
+        int e = lane_queue_round(r, bvhs[s], t);
         if (e != PSM_OK) return e;
-        e = psm_rt_shade(r, bvhs[s], t);
-        if (e != PSM_OK) return e;
-        PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));
         st[s] = RUNNING;
         return PSM_OK;
     }
@@ -313,11 +327,8 @@ struct ShardedLanes {
     // one non-blocking look at lane s: true when its round in flight has ended (the lane has then been stepped on)
     bool poll(uint32_t s) {
         if (rc != PSM_OK || st[s] != RUNNING) return false;
-        hipError_t q = hipEventQuery(rts[s]->ev_cnt);
-        if (q == hipErrorNotReady) return false;
-        if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); return false; }
-        rts[s]->ray_count = *rts[s]->h_cnt;
-        rts[s]->count_valid = true;
+        const int q = lane_poll_round(rts[s]);
+        if (q <= 0) { if (q < 0) rc = q; return false; }
         st[s] = IDLE;
         while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
         return true;
@@ -338,14 +349,7 @@ struct ShardedLanes {
             for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++) {
                 if (st[s] != RUNNING) continue;
                 if (s >= g0 && s < g1) waiting = true;
-                hipError_t q = hipEventQuery(rts[s]->ev_cnt);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); break; }
-                progressed = true;
-                rts[s]->ray_count = *rts[s]->h_cnt;
-                rts[s]->count_valid = true;
-                st[s] = IDLE;
-                while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
+                if (poll(s)) progressed = true;
             }
             if (!waiting) {
                 bool again = false;
