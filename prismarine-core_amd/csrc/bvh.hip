@@ -451,58 +451,92 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     int count = (int)sm[SM_COUNT];
     int s = blockIdx.x * 256 + threadIdx.x;
     if (!RECORDS && s == 0 && count < 2) sm[SM_ROOT] = (uint32_t)-1;
-    if (s >= count - 1) return;
-    uint64_t ks = keys[s], ks1 = keys[s + 1];
-    int f, l;
+    // (no early return: the wave searches its widest ranges together, below, and needs all its lanes for that)
+    const bool live = s < count - 1;
+    if (!live) s = 0;
+    const uint64_t ks = count > 0 ? keys[s] : 0ull, ks1 = count > 1 ? keys[s + 1] : 0ull;
+    // The node's range [f, l]: the keys around the gap that share the gap's common prefix -- nlz(key ^ ks) >= delta -- or, inside
+    // a run of equal codes (delta = 64 says exactly that), the run. A lane gallops up to 63 keys away on its own; one gap in 64
+    // belongs to a node over more than that, and its search is what the whole wave used to wait for: up to 2 x 23 dependent key
+    // reads at 10 M leaves. Those ends are now found by the WAVE, one open end at a time: 64 probes per step, the distance
+    // growing (then shrinking) by a factor of 64 -- three steps for a range of 4096 keys, seven for 10 M.
+    const int D = ks != ks1 ? nlz64(ks ^ ks1) : 64;
+    constexpr int SOLO_REACH = 32;   // the largest gallop step a lane takes alone
+    int lo = s, hi = s + 1;
+    bool openL = false, openR = false;
+    if (live) {
+        int step = 1;
+        for (;;) {   // leftmost f with nlz(key[f] ^ ks) >= D (monotone towards s); lo: known inside
+            if (lo - step < 0) break;
+            if (step > SOLO_REACH) { openL = true; break; }
+            if (nlz64(keys[lo - step] ^ ks) < D) break;
+            lo -= step; step <<= 1;
+        }
+        if (!openL) {   // answer in (lo - step, lo]
+            int bad = max(lo - step, -1);
+            while (lo - bad > 1) {
+                int mid = (lo + bad) >> 1;
+                if (nlz64(keys[mid] ^ ks) >= D) lo = mid; else bad = mid;
+            }
+        }
+        step = 1;
+        for (;;) {
+            if (hi + step >= count) break;
+            if (step > SOLO_REACH) { openR = true; break; }
+            if (nlz64(keys[hi + step] ^ ks) < D) break;
+            hi += step; step <<= 1;
+        }
+        if (!openR) {
+            int bad = min(hi + step, count);
+            while (bad - hi > 1) {
+                int mid = (hi + bad) >> 1;
+                if (nlz64(keys[mid] ^ ks) >= D) hi = mid; else bad = mid;
+            }
+        }
+    }
+    {   // the open ends, one after the other, all lanes on one search (wave-uniform state; a lane's result lands in its lo / hi)
+        const int lj = lane_id();
+        for (int side = 0; side < 2; side++) {
+            unsigned long long open = __builtin_amdgcn_ballot_w64(side == 0 ? openL : openR);
+            uint64_t last_k = 0; int last_D = -1, last_at = 0;   // neighbours inside one run of equal codes ask the same question
+            while (open != 0ull) {
+                const int L = __builtin_ctzll(open);
+                open &= open - 1ull;
+                const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ks, L), khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ks >> 32), L);
+                const uint64_t k0 = ((uint64_t)khi << 32) | klo;
+                const int D0 = __builtin_amdgcn_readlane(D, L);
+                long long at = __builtin_amdgcn_readlane(side == 0 ? lo : hi, L);   // known inside
+                if (D0 == 64 && last_D == 64 && k0 == last_k) {
+                    at = last_at;
+                } else {
+                    const long long dir = side == 0 ? -1 : 1;
+                    long long w = 1;
+                    for (;;) {   // outwards: probes at at + dir * (j + 1) * w
+                        const long long p = at + dir * (long long)(lj + 1) * w;
+                        const bool in = p >= 0 && p < count && nlz64(keys[p] ^ k0) >= D0;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                        if (m == ~0ull) { at += dir * 64 * w; w *= 64; continue; }
+                        at += dir * (long long)__builtin_ctzll(~m) * w;   // the last probe inside (none: `at` stays)
+                        break;
+                    }
+                    while (w > 1) {   // inwards: the end lies within w keys beyond `at`
+                        w /= 64;
+                        const long long p = at + dir * (long long)(lj + 1) * w;
+                        const bool in = lj < 63 && p >= 0 && p < count && nlz64(keys[p] ^ k0) >= D0;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                        at += dir * (long long)__builtin_ctzll(~m) * w;
+                    }
+                    last_k = k0; last_D = D0; last_at = (int)at;
+                }
+                if (lj == L) { if (side == 0) lo = (int)at; else hi = (int)at; }
+            }
+        }
+    }
+    if (!live) return;
+    int f = lo, l = hi;
     int parent = -1;       // the gap the parent splits at; -1: not known yet
     bool is_left = false;  // this node is its parent's left child
-    if (ks != ks1) {
-        int delta = nlz64(ks ^ ks1);
-        // leftmost f with nlz(key[f]^ks) >= delta (monotone towards s)
-        {
-            int step = 1, lo = s;  // lo: known inside
-            while (lo - step >= 0 && nlz64(keys[lo - step] ^ ks) >= delta) { lo -= step; step <<= 1; }
-            // answer in (lo-step, lo]
-            int bad = max(lo - step, -1);
-            while (lo - bad > 1) {
-                int mid = (lo + bad) >> 1;
-                if (nlz64(keys[mid] ^ ks) >= delta) lo = mid; else bad = mid;
-            }
-            f = lo;
-        }
-        {
-            int step = 1, hi = s + 1;
-            while (hi + step < count && nlz64(keys[hi + step] ^ ks) >= delta) { hi += step; step <<= 1; }
-            int bad = min(hi + step, count);
-            while (bad - hi > 1) {
-                int mid = (hi + bad) >> 1;
-                if (nlz64(keys[mid] ^ ks) >= delta) hi = mid; else bad = mid;
-            }
-            l = hi;
-        }
-    } else {
-        int a, b;
-        {
-            int step = 1, lo = s;
-            while (lo - step >= 0 && keys[lo - step] == ks) { lo -= step; step <<= 1; }
-            int bad = max(lo - step, -1);
-            while (lo - bad > 1) {
-                int mid = (lo + bad) >> 1;
-                if (keys[mid] == ks) lo = mid; else bad = mid;
-            }
-            a = lo;
-        }
-        {
-            int step = 1, hi = s + 1;
-            while (hi + step < count && keys[hi + step] == ks) { hi += step; step <<= 1; }
-            int bad = min(hi + step, count);
-            while (bad - hi > 1) {
-                int mid = (hi + bad) >> 1;
-                if (keys[mid] == ks) hi = mid; else bad = mid;
-            }
-            b = hi;
-        }
-        f = a; l = b;
+    if (ks == ks1) {       // inside a run of equal codes [f, l]: findSplit halves ranges at (first + last) >> 1
         for (;;) {
             int m = (f + l) >> 1;
             if (s == m) break;
