@@ -190,9 +190,9 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
     const float my_dr = u2f(xch[8 + ax]), my_no = u2f(xch[12 + ax]);
     int lastTri = __builtin_amdgcn_readfirstlane((int)xch[16]), cur = __builtin_amdgcn_readfirstlane((int)xch[17]);
     int sp = __builtin_amdgcn_readfirstlane((int)xch[18]), it = __builtin_amdgcn_readfirstlane((int)xch[19]);
-    int pl = __builtin_amdgcn_readfirstlane((int)xch[20]), pr = __builtin_amdgcn_readfirstlane((int)xch[21]);
+    const int pl = __builtin_amdgcn_readfirstlane((int)xch[20]), pr = __builtin_amdgcn_readfirstlane((int)xch[21]);
     const int fl = __builtin_amdgcn_readfirstlane((int)xch[22]);
-    bool pLeftNear = (fl & 1) != 0, parked = (fl & 2) != 0;
+    const bool pLeftNear = (fl & 1) != 0, parked = (fl & 2) != 0;
     // this lane's part of a node record. A child's box is six halfs in three words, [mn.x mn.y] [mn.z mx.x] [mx.y mx.z]; of a
     // group of eight lanes, lanes 0,1,2 take the left child's x,y,z slabs, lanes 4,5,6 the right child's, lanes 3 and 7 the
     // two links. Lane x loads word 0, lane y word 2, lane z word 1: every slab lane then finds one of its two planes in the LOW
@@ -200,11 +200,18 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
     // (mx.x, mn.y, mx.z) -- one load and one quad permute per lane, and which of the two is the min plane does not matter:
     // the slab test takes min and max of the two distances (mathlib.glsl:152-157).
     const uint32_t child = (uint32_t)(j8 >> 2);
-    const uint32_t wsel = q == 3 ? 6u + child : child * 3u + (q == 0 ? 0u : (q == 1 ? 2u : 1u));
+    const uint32_t wsel4 = 4u * (q == 3 ? 6u + child : child * 3u + (q == 0 ? 0u : (q == 1 ? 2u : 1u)));   // byte offset of this lane's word
     // the ray's stack: entry k in lane k
     int stk = lj < sp ? lds_stack_col[(lj < STACK_CAP ? lj : 0) * TRAV_BLOCK + L] : 0;
+    // the node step leaves its accepted leaves as (leafL, leafR, lkx, lky, leftNear); the links are decoded here, where one
+    // step in eight needs them
+    uint32_t leafL = pl < 0 ? 1u : 0u, leafR = pr < 0 ? 1u : 0u, leftNear = pLeftNear ? 1u : 0u;
+    int lkx = pl, lky = pr;
+    (void)parked;
     for (;;) {
-        if (parked) {  // testIntersectionPacked, :261-309
+        if ((leafL | leafR) != 0u) {  // testIntersectionPacked, :261-309
+            const int pl = leafL ? lkx : 0, pr = leafR ? lky : 0;
+            const bool pLeftNear = leftNear != 0u;
             const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
             const int tx = ~(lo ? pl : pr), ty = ~(lo ? pr : pl);
             const bool validx = (tx >= 0) && (tx != lastTri);
@@ -236,12 +243,13 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
                     }
                 }
             }
-            parked = false;
+            leafL = 0u; leafR = 0u;
         }
         if (sp < 0) break;
         it++;
         const bool lastIter = it >= MAX_ITERS;  // :383
-        const uint32_t wd = node_dw[((uint32_t)cur << 3) + wsel];
+        // (a 32-bit byte offset on the scalar base: the node array is < 4 GiB by the 2^27-triangle cap)
+        const uint32_t wd = *(const uint32_t*)((const char*)node_dw + (((uint32_t)cur << 5) | wsel4));
         const uint32_t wn = (uint32_t)__builtin_amdgcn_mov_dpp((int)wd, 2 | (0 << 2) | (1 << 4) | (3 << 6), 0xF, 0xF, true);   // x <- z, y <- x, z <- y
         if (COUNT) { ctr.nV += mine ? 1u : 0u; wave_steps++; }
         // intersectCubeDual, mathlib.glsl:129-193: slab_child with one axis of one child per lane
@@ -249,21 +257,20 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
         const float lo_ = sminf(tmin, tmax), hi_ = smaxf(tmin, tmax);
         const float tNear = smaxf(smaxf(lo_, quad_perm<1, 2, 0, 3>(lo_)), quad_perm<2, 0, 1, 3>(lo_));   // lane 0 / 4: ((x, y), z)
         const float tFar = sminf(sminf(hi_, quad_perm<1, 2, 0, 3>(hi_)), quad_perm<2, 0, 1, 3>(hi_));
-        Slab S;
-        S.cube = (tFar + PZERO) >= smaxf(tNear, 0.0f);
-        S.near = sminf(tNear, tFar);
-        S.hit = (S.near <= -PZERO) ? smaxf(tNear, tFar) : S.near;
-        const int lkx = rl_i((int)wd, 3), lky = rl_i((int)wd, 7);
-        const uint32_t okm = (uint32_t)lane_mask(child_ok(S, hitMax, dirlenInv, toffset, predist));
-        const float Rnear = rl_f(S.near, 4);
+        const float near = sminf(tNear, tFar);
+        const float hit = (near <= -PZERO) ? smaxf(tNear, tFar) : near;
+        lkx = rl_i((int)wd, 3); lky = rl_i((int)wd, 7);
+        // child_ok (directTraverse.comp:416-430 as rt_traverse tests it), its four tests as four lane masks ANDed in the scalar unit
+        // (as one boolean expression they come back through a 0 / 1 vector register: two instructions more)
+        const uint32_t okm = (uint32_t)(lane_mask((tFar + PZERO) >= smaxf(tNear, 0.0f)) & lane_mask(hit <= hitMax) & lane_mask(hit > -PZERO) &
+                                        lane_mask((((near + toffset) * dirlenInv) - PZERO) <= predist));
+        // :414 in lane 0: lessEqualF(L.near, R.near) = (R.near - L.near) > -PZERO, the right child's value fetched from lane 4
+        // by the subtraction itself (DPP row_shl:4)
+        const float Rnear = u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(near), 0x104, 0xF, 0xF, true));
+        leftNear = (uint32_t)lane_mask((Rnear - near) > -PZERO) & 1u;
         // from here on the step of rt_traverse in scalar registers (flags as 0 / 1 integers: one s_and / s_xor each)
-        const uint32_t leftNear = (uint32_t)lane_mask(lessEqualF(S.near, Rnear)) & 1u;  // :414, in lane 0
         const uint32_t ogL = okm & 1u, ogR = (okm >> 4) & 1u;
-        const uint32_t leafL = ogL & ((uint32_t)lkx >> 31), leafR = ogR & ((uint32_t)lky >> 31);
-        pl = leafL ? lkx : 0;   // :441-448
-        pr = leafR ? lky : 0;
-        pLeftNear = leftNear != 0u;
-        parked = (leafL | leafR) != 0u;
+        leafL = ogL & ((uint32_t)lkx >> 31); leafR = ogR & ((uint32_t)lky >> 31);   // :441-448: accepted leaves wait for the block above
         const uint32_t intL = ogL ^ leafL, intR = ogR ^ leafR;   // accepted and not a leaf
         const uint32_t leftFirst = intL & (leftNear | (intR ^ 1u));  // :451-462
         const int first = leftFirst ? lkx : lky, second = leftFirst ? lky : lkx;
