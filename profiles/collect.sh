@@ -11,14 +11,14 @@
 # usage: profiles/collect.sh <tag> ["<extra bench.py args>"]   -> gpurun_out/<tag>_{kt,kt1,kt1a,fetch,write,sq,tcc}/
 #        then profiles/make_traffic.py, and copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 EXTRA=${2:-}
 STEPS=${STEPS:-8}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # the profiler initialises the runtime before bench.py can set it
-B="python3 $REPO/bench.py --no-cpu-baseline --no-obj-roundtrip"
+B="python3 $REPO/bench.py --no-cpu-baseline --no-obj-roundtrip --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -- $B --steps $STEPS --warmup 2 $EXTRA > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
 echo "kt done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt1 -- $B --steps $STEPS --warmup 2 --lanes 1 $EXTRA > $OUT/${TAG}_kt1_bench.json 2> $OUT/${TAG}_kt1.err
