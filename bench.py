@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  `value` = rays traced by all ranks / wall time of 
 (inputs resident in HBM).  `roofline` prices the traversal kernel THE TIMED REGION LAUNCHES (with frames in
 flight: the hand-over kernel rt_traverse<false,false,true>): HIP events around every traversal launch on every
 lane's stream in a repeat of the timed call, algorithmic bytes (R*44 + V*64 + T*36, from per-round
-counters) over that time, and first the physical figures of the committed PMC passes (profiles/traffic_r03.json:
+counters) over that time, and first the physical figures of the committed PMC passes (profiles/traffic_r04.json:
 HBM-side traffic, VALU issue and lane utilisation); the single-launch kernel of a frame running alone is priced
 beside it.  `cpu_baseline` times the CPU oracle's traversal (oracle/, scalar C + OpenMP, every hardware thread)
 on a bounded sample of the same rays.
@@ -409,7 +409,7 @@ SIMDS = 1024
 def pmc_entry(scene, width, height, kernel):
     """Per-launch PMC figures of `kernel` for this workload from the committed rocprofv3 passes (profiles/collect.sh ->
     profiles/make_traffic.py): bench.py cannot run the profiler on itself."""
-    for name in ("traffic_r03.json",):
+    for name in ("traffic_r04.json", "traffic_r03.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
