@@ -22,6 +22,9 @@ namespace psm {
 constexpr int SM_M = 0;
 constexpr int SM_ROOT = 25;
 
+#ifndef PSM_EXP_WAVELOG
+#define PSM_EXP_WAVELOG 0   // 1: an experiment build whose traversal waves log when they ended and how many wave-steps they spent at 1, 2, 3-4, 5-8, 9-16, 17+ lanes with work
+#endif
 #ifndef PSM_TRAV_BLOCK
 #define PSM_TRAV_BLOCK 64
 #endif
@@ -331,6 +334,9 @@ struct TravArgs {
     const uint32_t* sm;
     uint32_t cap, min_live, min_steps, final_rays;  // Phase, hot part
     uint32_t solo_max;            // a wave with at most this many rays left walks them one by one (solo_ray); 0: never
+#if PSM_EXP_WAVELOG
+    uint32_t* wavelog;            // experiment build (tests/studies/wave_log.py): 8 words per wave of a fresh-ray launch
+#endif
     const uint32_t* in_count;
     float4* hit0;                 // cold from here on
     uint32_t* hitN;
@@ -378,6 +384,11 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
     if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
+#if PSM_EXP_WAVELOG
+    uint32_t wl_steps[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wl_solo_before = 0;
+#endif
     if (PHASED && blockIdx.x == 0 && tid < (int)MAX_PHASES) {   // (instead of a memset launch in front of every round: 40 us on a lane's critical path with frames in flight)
         uint32_t* z = cold_args()->zero_cnt;
         if (z) z[tid] = 0u;
@@ -552,6 +563,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         const int np = __popcll(lane_mask(parkedNow));
         const int nl = np + __popcll(lane_mask(stepping));
         if (COUNT) dg_steps++;
+#if PSM_EXP_WAVELOG
+        wl_steps[nl <= 1 ? 0 : (nl <= 2 ? 1 : (nl <= 4 ? 2 : (nl <= 8 ? 3 : (nl <= 16 ? 4 : 5))))]++;
+#endif
         // Keep stepping the others while fewer than half of the lanes with work wait for a leaf test (with nobody able to
         // step, np == nl: the tests run; with nobody left at all, nl == 0, the wave is done) -- unless the launch's cap is
         // reached or too few lanes have work left to be worth a wave (PHASED). Three differences whose signs are the three
@@ -652,6 +666,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             SoloCounters sc = {nV, nT, nDrop, nCap, nBakedDrop};
+#if PSM_EXP_WAVELOG
+            wl_solo_before = __builtin_amdgcn_s_memrealtime();
+#endif
             // (s_setprio 3 for the wave while it is in the gear changed nothing: 2.185 / 3.167 / 0.603 ms against 2.186 / 3.167 / 0.603,
             // profiles/r04_solo_gear.txt -- the one-ray waves are not starved by the bulk's waves, they run when the chip has emptied)
             for (int k = 0; work != 0ull; k++) {
@@ -758,6 +775,15 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         else st_stream(&hit0[i], make_float4(head.u, head.v, head.t, __int_as_float(head.tri)));
         st_stream(&hitN[i], count | (off << 4));
     }
+#if PSM_EXP_WAVELOG
+    if (!resume && cold_args()->wavelog && lane_id() == 0) {
+        uint32_t* rec = cold_args()->wavelog + (size_t)8 * (blockIdx.x * (TRAV_BLOCK / 64) + (tid >> 6));
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        rec[0] = (uint32_t)wl_t0; rec[1] = (uint32_t)t1;                       // 100 MHz ticks (low words)
+        rec[2] = wl_solo_before ? (uint32_t)wl_solo_before : (uint32_t)t1;     // when the wave went into the solo gear (or ended)
+        rec[3] = wl_steps[1]; rec[4] = wl_steps[2]; rec[5] = wl_steps[3]; rec[6] = wl_steps[4]; rec[7] = wl_steps[5];
+    }
+#endif
     if (!resume) break;
     }  // batches
     if (COUNT) {
@@ -1122,6 +1148,9 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
         ta.cap = 0xFFFFFFFFu;
         ta.solo_max = r->solo_max;
+#if PSM_EXP_WAVELOG
+        { const char* e = getenv("PSM_EXP_WAVELOG_PTR"); ta.wavelog = e ? (uint32_t*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
+#endif
 #if PSM_EXPERIMENTAL
         if (mode == PSM_TRAVERSE_REFILL) {
             // persistent waves over a pool of rays: at most refill_waves waves per CU, never more lanes than rays
