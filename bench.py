@@ -88,7 +88,6 @@ def parse():
     ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the timed call of K steps is taken; the line reports the "
                                                             "median call, and all of them under \"timing\"")
-    ap.add_argument("--no-reorder", action="store_true", help="tuning study: switch the history-ordered dispatch off (psm_rt_set_traverse_reorder)")
     ap.add_argument("--solo", type=int, default=-1, help="tuning study: rays a traversal wave takes into the solo gear at most "
                                                           "(psm_rt_set_traverse_solo, 0..4; -1 = the library's default)")
     return ap.parse_args()
@@ -163,9 +162,6 @@ class Renderer:
         if args.solo >= 0:
             for b in self.batches:
                 b.each(lambda r: r.setTraverseSolo(args.solo))
-        if args.no_reorder:
-            for b in self.batches:
-                b.each(lambda r: r.setTraverseReorder(False))
         if args.traverse != "auto" or args.trav_adaptive or args.trav_refill:
             def tune(r):
                 if args.trav_refill:

@@ -278,14 +278,6 @@ int psm_rt_set_traverse_adaptive(psm_rt* rt, uint32_t min_live, uint32_t min_ste
  * them. Per ray nothing changes: the node steps and triangle tests of directTraverse.comp:333-484 in the same order, hits,
  * chains and counters bit-exact. 0 switches the gear off. */
 int psm_rt_set_traverse_solo(psm_rt* rt, uint32_t solo_max);
-/* History-ordered dispatch (round 4; on by default, a tuning knob: results never depend on it). A traversal launch over a bounce
- * round's 2 M rays is four generations of resident waves and ends with the lifetime of a wave of the last one -- 300-400 us of a
- * round's 830 for a frame on its own. The launch's runs of 64 workgroups ("chunks", 4096 consecutive rays) record how long their
- * waves lived, and the launch of the SAME bounce round of the NEXT frame starts the costliest chunks first (one tiny sort kernel in
- * front of it), so that the last generation is the cheap ones. Frames of one accumulation -- and of a viewer whose camera moves
- * slowly -- resemble each other; a frame that does not merely keeps last frame's (harmless) order. camera() / shade() number the
- * rounds; uploaded queues, further hierarchies of a multi-BVH queue and intersections under 2^19 rays are not reordered. */
-int psm_rt_set_traverse_reorder(psm_rt* rt, int enable);
 /* forget the chains of the current queue without changing it (the reference's ray.hit = -1, rayslib.glsl:149) */
 int psm_rt_reset_hits(psm_rt* rt);
 /* applyMaterials + shade, Pipeline.inl:407-436 -> surface.comp + rayshading.comp, then the

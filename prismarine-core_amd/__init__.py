@@ -28,7 +28,7 @@ EXPORTS = [
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
     "psm_rt_set_lights", "psm_rt_set_sky", "psm_rt_set_skybox", "psm_rt_set_texture", "psm_rt_set_materials", "psm_rt_camera", "psm_rt_set_camera_mode", "psm_rt_ray_count",
-    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_solo", "psm_rt_set_traverse_reorder", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
+    "psm_rt_traverse", "psm_rt_set_traverse_mode", "psm_rt_set_traverse_phases", "psm_rt_set_traverse_adaptive", "psm_rt_set_traverse_solo", "psm_rt_reset_hits", "psm_rt_shade", "psm_rt_sample", "psm_rt_sample_from", "psm_lanes_render", "psm_lanes_run_sharded", "psm_rt_clear_sampler", "psm_rt_snap",
     "psm_rt_get_texels_dev", "psm_rt_set_texels_dev", "psm_rt_tile_texels", "psm_rt_pack_texels_dev",
     "psm_rt_unpack_texels_dev", "psm_rt_unpack_tiles_dev", "psm_rt_ray_count_dev", "psm_rt_set_ray_count", "psm_rt_download_rays", "psm_rt_download_hits",
     "psm_rt_upload_rays", "psm_rt_download_texels",
@@ -616,10 +616,6 @@ class Pipeline:
         """psm_rt_set_traverse_solo: a traversal wave left with at most solo_max rays (0..4) walks them one at a time with all its
         lanes on one ray; 0 switches the gear off. Results never depend on it."""
         self.ctx.check(lib().psm_rt_set_traverse_solo(self._h, C.c_uint32(solo_max)), "psm_rt_set_traverse_solo")
-
-    def setTraverseReorder(self, enable=True):
-        """psm_rt_set_traverse_reorder: start the chunks of a round's traversal launch in the order of what they cost one frame earlier."""
-        self.ctx.check(lib().psm_rt_set_traverse_reorder(self._h, C.c_int(1 if enable else 0)), "psm_rt_set_traverse_reorder")
 
     def resetHits(self):
         """Forget the hit chains of the current queue (ray.hit = -1): the next intersection() starts afresh."""

@@ -618,7 +618,7 @@ int psm_rt_destroy(psm_rt* r) {
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     rt_free_grid(r);
-    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table); dev_free(r->d_geoms); dev_free(r->d_chunk_cost); dev_free(r->d_chunk_order);
+    dev_free(r->presampled); dev_free(r->filtered); dev_free(r->d_lights); dev_free(r->d_mats); dev_free(r->d_cnt); dev_free(r->d_sky); dev_free(r->d_tex_table); dev_free(r->d_geoms);
     if (r->d_phase_mem) (void)hipFree(r->d_phase_mem);
     if (r->h_cnt) (void)hipHostFree(r->h_cnt);
     if (r->ev_cnt) (void)hipEventDestroy(r->ev_cnt);
@@ -638,12 +638,9 @@ int psm_rt_create(psm_ctx* c, psm_rt** out) {
     if (rc == PSM_OK) rc = dev_alloc(c, &r->d_lights, (size_t)16);
     if (rc == PSM_OK) rc = dev_alloc(c, &r->d_tex_table, (size_t)MAX_TEXTURES);
     if (rc == PSM_OK) rc = dev_alloc(c, &r->d_geoms, (size_t)MAX_TRAV_OBJECTS);
-    if (rc == PSM_OK) rc = dev_alloc(c, &r->d_chunk_cost, (size_t)MAX_ORDER_ROUNDS * MAX_ORDER_CHUNKS);
-    if (rc == PSM_OK) rc = dev_alloc(c, &r->d_chunk_order, (size_t)MAX_ORDER_CHUNKS);
     if (rc == PSM_OK) r->tex_dirty = true;
     if (rc != PSM_OK) { psm_rt_destroy(r); return rc; }
     (void)hipMemsetAsync(r->d_cnt, 0, 32, c->stream);
-    (void)hipMemsetAsync(r->d_chunk_cost, 0, sizeof(uint32_t) * MAX_ORDER_ROUNDS * MAX_ORDER_CHUNKS, c->stream);
     // default sun, Pipeline.inl:93-98
     psm_light L[16];
     std::memset(L, 0, sizeof(L));
@@ -973,13 +970,6 @@ int psm_rt_set_traverse_adaptive(psm_rt* r, uint32_t min_live, uint32_t min_step
     return PSM_OK;
 }
 
-int psm_rt_set_traverse_reorder(psm_rt* r, int enable) {
-    if (!r) return PSM_ERR_INVALID;
-    r->reorder = enable ? 1 : 0;
-    for (uint32_t k = 0; k < 16; k++) r->chunk_n[k] = 0;   // what was learnt so far is forgotten
-    return PSM_OK;
-}
-
 int psm_rt_set_traverse_solo(psm_rt* r, uint32_t solo_max) {
     if (!r || solo_max > 4u) return PSM_ERR_INVALID;
     r->solo_max = solo_max;
@@ -1113,7 +1103,6 @@ int psm_rt_upload_rays(psm_rt* r, const psm_ray* src, uint32_t count) {
     r->ray_count = count;
     r->count_valid = true;
     r->trav_n = 0;
-    r->round_index = MAX_ORDER_ROUNDS;   // an uploaded queue belongs to no round of a frame: nothing learnt, nothing recorded
     return PSM_OK;
 }
 

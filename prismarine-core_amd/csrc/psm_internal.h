@@ -247,14 +247,6 @@ struct psm_rt {
     uint32_t adapt_min_live = 12, adapt_min_steps = 8, adapt_final_rays = 65536, adapt_max_launches = 4;  // tuned on C3, 4 frames in flight (its 2 M-ray rounds plan three launches either way; C5's 8 M-ray rounds take the fourth: -1.3 %)
     uint32_t refill_min = 32, refill_waves_per_cu = 28, refill_min_rays = 1u << 15;  // PSM_TRAVERSE_REFILL (trace.hip)
     bool mats_ordinary = true;      // no material whose dropped lobe's colour can be NaN (psm_rt_set_materials): rt_shade builds one lobe per hit
-    // Dispatch order of a fresh-ray traversal launch, learnt from the launch of the same bounce round one frame earlier (trace.hip):
-    // the launch's chunks of XCD_RUN waves accumulate how long their waves lived, and the next frame starts the costliest chunks first.
-    uint32_t* d_chunk_cost = nullptr;    // [MAX_ORDER_ROUNDS][MAX_ORDER_CHUNKS] wave lifetimes summed per chunk (100 MHz ticks)
-    uint32_t* d_chunk_order = nullptr;   // [MAX_ORDER_CHUNKS] the permutation the next launch uses
-    uint32_t chunk_n[16] = {};           // chunks the cost row of round k was recorded for (0: nothing recorded yet)
-    uint32_t round_index = 0;            // bounce round of the current queue: 0 after camera(), + 1 per shade()
-    int reorder = 1;                     // psm_rt_set_traverse_reorder
-    uint32_t reorder_min_rays = 1u << 19;   // a launch of at most one generation of resident waves (8192 x 64 rays) has no dispatch order to speak of
     uint32_t solo_max = 1;          // a traversal wave with at most this many rays left walks them one by one, all lanes on one ray (trace.hip: solo_ray); 0: never. 1: a frame alone 3.37 -> 3.20 ms, a 1/8 tile 0.633 -> 0.611, 4 frames in flight 2.21 -> 2.19; 2: 3.24 / 0.620 / 2.19 (profiles/r04_solo_gear.txt)
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
     uint32_t phase_min_rays = 1u << 19;  // smaller intersections run as one launch (tiles: tools/run_r02_ae.sh)
@@ -311,7 +303,6 @@ int launch_bvh_emit_records(psm_bvh* b);
 int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
 int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views);
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
-constexpr uint32_t MAX_ORDER_ROUNDS = 16, MAX_ORDER_CHUNKS = 4096;   // 4096 chunks x 64 waves x 64 rays = currentRayLimit's maximum (4096^2)
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
 int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);

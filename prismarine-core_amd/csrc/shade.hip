@@ -875,7 +875,6 @@ int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uin
     r->ray_count = nrays;
     r->count_valid = true;
     r->trav_n = 0;
-    r->round_index = 0;
     r->q_nb[r->cur] = 1;
     return PSM_OK;
 }
@@ -928,7 +927,6 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
         PSM_HIP(c, hipStreamSynchronize(c->stream));
     }
     r->trav_n = 0;  // the queue changes: the next intersection() starts new chains
-    r->round_index++;
     {
         TimedScope ts(c, CAT_SHADE);
         bool any_tex = false;

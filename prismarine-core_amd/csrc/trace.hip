@@ -347,8 +347,6 @@ struct TravArgs {
     TravState in, out;
     uint32_t* out_count;
     uint32_t* zero_cnt;           // the last launch of a hand-over round clears the OTHER set of continuation counts (next round's)
-    const uint32_t* order;        // fresh-ray launch: chunk that dispatch slot p works on (NULL: p itself), see rt_order_chunks
-    uint32_t* cost;               // ... and where a chunk's waves add up how long they lived (NULL: nowhere)
     uint32_t gn;                  // GROUP: queues in the table
     GroupQueue gq[MAX_GROUP];
 };
@@ -405,20 +403,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     // of 128-thread workgroups). Resume: every wave strides over the continuation queue.
     constexpr uint32_t XCD_GROUP = XCD_RUN;
     const uint32_t bq = blockIdx.x >> 3;   // position within the XCD's sequence
-    // Which run of XCD_GROUP workgroups' rays ("chunk") this workgroup's run is: dispatch slot p = the p-th run the chip starts.
-    // By default chunk p -- or the chunk the launch of the same bounce round ONE FRAME EARLIER found p-th most expensive
-    // (rt_order_chunks): a launch over 2 M rays is four generations of resident waves and ends with the lifetime of a wave of the
-    // last one (profiles/r04_wave_log.txt: 300-400 of a round's 830 us); with the costly chunks started first the last generation
-    // is the cheap ones. Rays, results and counters do not depend on which wave traces them.
-    auto my_chunk = [&]() -> uint32_t {   // (looked up again at the wave's end rather than carried through the loop in a scalar register)
-        uint32_t ch = ((blockIdx.x >> 3) / XCD_GROUP) * 8u + (blockIdx.x & 7u);
-        if (!GROUP) { const uint32_t* ord = cold_args()->order; if (ord) ch = ord[ch]; }
-        return ch;
-    };
-    const uint32_t vb_ = (resume ? 0u : my_chunk()) * XCD_GROUP + (bq % XCD_GROUP);
+    const uint32_t vb_ = ((bq / XCD_GROUP) * 8u + (blockIdx.x & 7u)) * XCD_GROUP + (bq % XCD_GROUP);
     const uint32_t vblock = resume ? blockIdx.x : vb_;
-    uint32_t life_t0 = 0;   // 100 MHz ticks, low word: differences are what counts
-    if (!resume && !GROUP && !COUNT) life_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
     for (uint32_t batch = vblock * TRAV_BLOCK + (uint32_t)(tid & ~63); batch < total; batch += gridDim.x * TRAV_BLOCK) {
     const uint32_t slot = batch + (uint32_t)(tid & 63);
     bool alive = slot < total;
@@ -798,10 +784,6 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         rec[3] = wl_steps[1]; rec[4] = wl_steps[2]; rec[5] = wl_steps[3]; rec[6] = wl_steps[4]; rec[7] = wl_steps[5];
     }
 #endif
-    if (!resume && !GROUP && !COUNT) {   // this wave's lifetime, to its chunk's account (one atomic per wave; 100 MHz ticks)
-        uint32_t* cost = cold_args()->cost;
-        if (cost && lane_id() == 0) atomicAdd(&cost[my_chunk()], (uint32_t)__builtin_amdgcn_s_memrealtime() - life_t0);
-    }
     if (!resume) break;
     }  // batches
     if (COUNT) {
@@ -1085,36 +1067,6 @@ __global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka)
 
 #endif   // PSM_EXPERIMENTAL (REFILL)
 
-// The dispatch order of the next fresh-ray launch of a bounce round from the chunk costs its last launch recorded: chunks in
-// descending cost, ties and chunks without a record (the round has more rays than last time) in ascending number; then the
-// record is cleared for the launch that follows. One workgroup, a bitonic sort of at most 4096 keys in LDS: ~5 us, once per
-// round, on the lane's stream right in front of the traversal launch.
-__global__ __launch_bounds__(1024) void rt_order_chunks(uint32_t* __restrict__ cost, uint32_t old_n, uint32_t new_n, uint32_t* __restrict__ order) {
-    __shared__ unsigned long long key[MAX_ORDER_CHUNKS];
-    uint32_t m = 1;
-    while (m < new_n) m <<= 1;
-    for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-        const unsigned long long c = i < new_n ? (i < old_n ? (unsigned long long)cost[i] + 1ull : 1ull) : 0ull;   // padding sorts last
-        key[i] = (c << 32) | (unsigned long long)(0xFFFFFFFFu - i);
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= m; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const unsigned long long a = key[i], b = key[x];
-                    const bool desc = (i & k) == 0;              // descending blocks first: the whole array ends up descending
-                    if (desc ? a < b : a > b) { key[i] = b; key[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i = threadIdx.x; i < new_n; i += 1024) order[i] = 0xFFFFFFFFu - (uint32_t)key[i];
-    const uint32_t top = old_n > new_n ? old_n : new_n;
-    for (uint32_t i = threadIdx.x; i < top; i += 1024) cost[i] = 0u;
-}
-
 constexpr uint32_t RESUME_GRID_CAP = 256 * 32 / (TRAV_BLOCK / 64);  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
 // continuation queues of the hand-over schedules: `need` entries at least (a launch over several Pipelines' queues can hold
@@ -1196,18 +1148,6 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
         ta.cap = 0xFFFFFFFFu;
         ta.solo_max = r->solo_max;
-        // history-ordered dispatch (see rt_traverse: chunk): the first traversal of a bounce round's queue, big enough to be more
-        // than one generation of resident waves, in a frame loop (camera() / shade() keep the round's number)
-        const uint32_t nchunks = grid / XCD_RUN;
-        if (r->reorder && !chain && !c->counting && r->round_index < MAX_ORDER_ROUNDS && nchunks <= MAX_ORDER_CHUNKS && n >= r->reorder_min_rays) {
-            uint32_t* cost = r->d_chunk_cost + (size_t)r->round_index * MAX_ORDER_CHUNKS;
-            if (r->chunk_n[r->round_index]) {
-                rt_order_chunks<<<1, 1024, 0, c->stream>>>(cost, r->chunk_n[r->round_index], nchunks, r->d_chunk_order);
-                ta.order = r->d_chunk_order;
-            }
-            ta.cost = cost;
-            r->chunk_n[r->round_index] = nchunks;
-        }
 #if PSM_EXP_WAVELOG
         { const char* e = getenv("PSM_EXP_WAVELOG_PTR"); ta.wavelog = e ? (uint32_t*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
 #endif

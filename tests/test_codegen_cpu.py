@@ -52,10 +52,9 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
         blk = blk[:blk.index(".wavefront_size")]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 64, kern
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, kern
-        # (a few scalars of the hand-over kernel -- its own time stamp and the like, written in the prologue, read in the epilogue -- are
-        # parked in the lanes of one vector register since the solo gear and the dispatch order came; none of it inside the loop: the
-        # walk above counts 80 vector instructions in the step with or without them, and a reload there would be one more)
-        assert int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1)) <= 4, kern
+        # (one scalar of the hand-over kernel's prologue is parked in a vector lane since the solo gear came: lines 105 / 244 of
+        # its assembly, long before the loop; the walk above would count a reload inside the step)
+        assert int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1)) <= 1, kern
 
 
 def test_solo_gear_step_is_short(tmp_path):
