@@ -93,19 +93,6 @@ def parse():
     return ap.parse_args()
 
 
-def sharded_lanes(steps):
-    """Frames in flight per GPU of a tile-sharded run. psm_dist_render_frames deals the frames to two lane groups that alternate
-    batches of lanes / 2 frames; 8 lanes are the measured optimum of a long run. A SHORT call -- the driver's
-    scaling runs are `--steps 20` -- pays for every batch a group runs, so the count is chosen such that the call is an even
-    number of full batches: 20 steps = 4 batches of 5 on 10 lanes (12.5 ms at a 1/8 tile) instead of 5 batches of 4 on 8, where
-    one group runs three batches and the other two (13.5 ms: +8 %, profiles/r04_tile_emulation.txt)."""
-    for lanes in (8, 10, 6, 12):
-        half = lanes // 2
-        if steps % half == 0 and (steps // half) % 2 == 0:
-            return lanes
-    return 8
-
-
 class Renderer:
     def __init__(self, psm, scenes, scene, args, dist):
         self.psm, self.dist, self.args = psm, dist, args
@@ -123,7 +110,7 @@ class Renderer:
             stream = dist.torch.cuda.current_stream().cuda_stream
             dist.same_stream = True
         w, h = args.width, args.height
-        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else sharded_lanes(args.steps))
+        self.lanes = args.lanes if args.lanes > 0 else (4 if dist.world <= 1 else 8)
         self.lane_streams = None
         streams = None
         if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
