@@ -532,11 +532,10 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
             }
         }
     }
-    if (!live) return;
     int f = lo, l = hi;
     int parent = -1;       // the gap the parent splits at; -1: not known yet
     bool is_left = false;  // this node is its parent's left child
-    if (ks == ks1) {       // inside a run of equal codes [f, l]: findSplit halves ranges at (first + last) >> 1
+    if (live && ks == ks1) {   // inside a run of equal codes [f, l]: findSplit halves ranges at (first + last) >> 1
         for (;;) {
             int m = (f + l) >> 1;
             if (s == m) break;
@@ -545,8 +544,38 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
             if (s < m) l = m; else f = m + 1;
         }
     }
-    uint4 lb = key_to_box(seg_query(st, (uint32_t)f, (uint32_t)s));          // refit.comp:91-98
-    uint4 rb = key_to_box(seg_query(st, (uint32_t)(s + 1), (uint32_t)l));
+    // The child boxes: unions of the sorted leaves [f, s] and [s + 1, l] from the min / max segment tree (refit.comp:91-98). A range
+    // of up to 64 leaves is at most 7 levels of the tree, walked by the lane; a wider one -- again the one node in 64 the wave would
+    // wait for, up to 2 x 24 levels -- is gathered by the WAVE: the tree nodes of a range [A, B) are known in closed form (level k
+    // contributes entry ceil(A / 2^k) if that is odd and entry floor(B / 2^k) - 1 if floor(B / 2^k) is odd, while ceil < floor), so lane
+    // 2k takes the low candidate of level k, lane 2k + 1 the high one, and six shuffles unite them (min / max: any order).
+    uint4 cb[2];
+    {
+        const uint32_t qa[2] = {(uint32_t)f, (uint32_t)(s + 1)}, qb[2] = {(uint32_t)s + 1u, (uint32_t)l + 1u};   // [qa, qb)
+        const int lj = lane_id();
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool wide = live && qb[side] - qa[side] > 64u;
+            cb[side] = (live && !wide) ? seg_query(st, qa[side], qb[side] - 1u) : box_identity();
+            unsigned long long open = __builtin_amdgcn_ballot_w64(wide);
+            while (open != 0ull) {
+                const int L = __builtin_ctzll(open);
+                open &= open - 1ull;
+                const uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)qa[side], L), B = (uint32_t)__builtin_amdgcn_readlane((int)qb[side], L);
+                const uint32_t k = (uint32_t)lj >> 1;                       // this lane's level (A, B < 2^28: the sums below fit)
+                const uint32_t lo_k = k < 28u ? (A + ((1u << k) - 1u)) >> k : 1u, hi_k = k < 28u ? B >> k : 0u;
+                const bool take = lo_k < hi_k && (((lj & 1) == 0 ? lo_k : hi_k) & 1u) != 0u;
+                uint4 v = take ? st.seg[st.off[k] + ((lj & 1) == 0 ? lo_k : hi_k - 1u)] : box_identity();
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1)
+                    v = box_union(v, make_uint4(__shfl_xor(v.x, d, 64), __shfl_xor(v.y, d, 64), __shfl_xor(v.z, d, 64), __shfl_xor(v.w, d, 64)));
+                if (lj == L) cb[side] = v;
+            }
+        }
+    }
+    if (!live) return;
+    uint4 lb = key_to_box(cb[0]);
+    uint4 rb = key_to_box(cb[1]);
     if (RECORDS) {
         // children [f,s] and [s+1,l] (splitNode, build-new.comp:70-117; leaf link child-link.comp:34-53)
         int2 lk;
