@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void bvh_segtree(uint4* __restrict__ seg, SegL
 struct SegTree {
     const uint4* seg;
     uint32_t off[32];
+    uint32_t nlev;   // levels the tree has (entries of off beyond it repeat its end)
 };
 
 // union of sorted leaves [f, l]
@@ -453,8 +454,34 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     if (!RECORDS && s == 0 && count < 2) sm[SM_ROOT] = (uint32_t)-1;
     // (no early return: the wave searches its widest ranges together, below, and needs all its lanes for that)
     const bool live = s < count - 1;
+    // Everything a lane reads on its own lies within 64 leaves of its gap (its gallop reaches 63 keys, the tree nodes of a range of
+    // up to 64 leaves cover leaves of that range only): the workgroup stages that window -- 385 sorted keys and the segment tree's
+    // levels 0..6 over them, 18 KB -- in LDS with coalesced loads, and the ten or so DEPENDENT reads of a node's search and of its two
+    // box queries become LDS reads (the kernel was bound by exactly that chain: 4.4 L2 requests per node at 15 % of the L2's rate).
+    constexpr int WIN = 64, WKEYS = 256 + 2 * WIN + 1;
+    __shared__ uint64_t wkey[WKEYS];
+    __shared__ uint4 wseg[WKEYS + WKEYS / 2 + WKEYS / 4 + WKEYS / 8 + WKEYS / 16 + WKEYS / 32 + WKEYS / 64 + 14];
+    const int b0 = blockIdx.x * 256;
+    const int w0 = max(b0 - WIN, 0), w1 = min(b0 + 256 + WIN + 1, count);   // keys [w0, w1)
+    int lvl_off[8], lvl_lo[7];   // level k's entries [w0 >> k, ((w1 - 1) >> k) + 1) start at wseg[lvl_off[k]]
+    {
+        int at = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            lvl_off[k] = at; lvl_lo[k] = w0 >> k;
+            at += w1 > w0 ? (((w1 - 1) >> k) - (w0 >> k) + 1) : 0;
+        }
+        lvl_off[7] = at;
+        for (int i = threadIdx.x; i < w1 - w0; i += 256) wkey[i] = keys[w0 + i];
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (k < (int)st.nlev)   // (a small tree has fewer levels; no range reaches the ones it lacks)
+                for (int i = threadIdx.x; i < lvl_off[k + 1] - lvl_off[k]; i += 256) wseg[lvl_off[k] + i] = st.seg[st.off[k] + (uint32_t)(lvl_lo[k] + i)];
+        __syncthreads();
+    }
+    auto key_at = [&](int i) -> uint64_t { return (i >= w0 && i < w1) ? wkey[i - w0] : keys[i]; };
     if (!live) s = 0;
-    const uint64_t ks = count > 0 ? keys[s] : 0ull, ks1 = count > 1 ? keys[s + 1] : 0ull;
+    const uint64_t ks = count > 0 ? key_at(s) : 0ull, ks1 = count > 1 ? key_at(s + 1) : 0ull;
     // The node's range [f, l]: the keys around the gap that share the gap's common prefix -- nlz(key ^ ks) >= delta -- or, inside
     // a run of equal codes (delta = 64 says exactly that), the run. A lane gallops up to 63 keys away on its own; one gap in 64
     // belongs to a node over more than that, and its search is what the whole wave used to wait for: up to 2 x 23 dependent key
@@ -469,28 +496,28 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
         for (;;) {   // leftmost f with nlz(key[f] ^ ks) >= D (monotone towards s); lo: known inside
             if (lo - step < 0) break;
             if (step > SOLO_REACH) { openL = true; break; }
-            if (nlz64(keys[lo - step] ^ ks) < D) break;
+            if (nlz64(key_at(lo - step) ^ ks) < D) break;
             lo -= step; step <<= 1;
         }
         if (!openL) {   // answer in (lo - step, lo]
             int bad = max(lo - step, -1);
             while (lo - bad > 1) {
                 int mid = (lo + bad) >> 1;
-                if (nlz64(keys[mid] ^ ks) >= D) lo = mid; else bad = mid;
+                if (nlz64(key_at(mid) ^ ks) >= D) lo = mid; else bad = mid;
             }
         }
         step = 1;
         for (;;) {
             if (hi + step >= count) break;
             if (step > SOLO_REACH) { openR = true; break; }
-            if (nlz64(keys[hi + step] ^ ks) < D) break;
+            if (nlz64(key_at(hi + step) ^ ks) < D) break;
             hi += step; step <<= 1;
         }
         if (!openR) {
             int bad = min(hi + step, count);
             while (bad - hi > 1) {
                 int mid = (hi + bad) >> 1;
-                if (nlz64(keys[mid] ^ ks) >= D) hi = mid; else bad = mid;
+                if (nlz64(key_at(mid) ^ ks) >= D) hi = mid; else bad = mid;
             }
         }
     }
@@ -556,7 +583,18 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
 #pragma unroll
         for (int side = 0; side < 2; side++) {
             const bool wide = live && qb[side] - qa[side] > 64u;
-            cb[side] = (live && !wide) ? seg_query(st, qa[side], qb[side] - 1u) : box_identity();
+            cb[side] = box_identity();
+            if (live && !wide) {   // seg_query over the staged levels: the range lies inside the window
+                uint32_t qlo = qa[side], qhi = qb[side];
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    if (qlo < qhi) {
+                        if (qlo & 1u) { cb[side] = box_union(cb[side], wseg[lvl_off[k] + (int)qlo - lvl_lo[k]]); qlo++; }
+                        if (qhi & 1u) { qhi--; cb[side] = box_union(cb[side], wseg[lvl_off[k] + (int)qhi - lvl_lo[k]]); }
+                        qlo >>= 1; qhi >>= 1;
+                    }
+                }
+            }
             unsigned long long open = __builtin_amdgcn_ballot_w64(wide);
             while (open != 0ull) {
                 const int L = __builtin_ctzll(open);
@@ -600,8 +638,8 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
         return;
     }
     if (parent < 0) {
-        const int dL = f > 0 ? nlz64(keys[f - 1] ^ keys[f]) : -1;
-        const int dR = l < count - 1 ? nlz64(keys[l] ^ keys[l + 1]) : -1;
+        const int dL = f > 0 ? nlz64(key_at(f - 1) ^ key_at(f)) : -1;
+        const int dR = l < count - 1 ? nlz64(key_at(l) ^ key_at(l + 1)) : -1;
         is_left = dR > dL;
         parent = is_left ? l : f - 1;
     }
@@ -664,6 +702,7 @@ int launch_bvh_emit(psm_bvh* b) {
     SegTree st;
     st.seg = b->d_seg;
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
+    st.nlev = (uint32_t)nlev;
     uint32_t grid = (n + 255u) / 256u;
     bvh_emit<false><<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
                                                  b->d_range, b->d_node32, (int)b->node_off, (int)b->tri_off);
@@ -681,6 +720,7 @@ int launch_bvh_emit_records(psm_bvh* b) {
     SegTree st;
     st.seg = b->d_seg;
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
+    st.nlev = (uint32_t)nlev;
     bvh_emit<true><<<(n + 255u) / 256u, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
                                                              b->d_range, b->d_node32, (int)b->node_off, (int)b->tri_off);
     PSM_HIP(c, hipGetLastError());
