@@ -513,8 +513,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     // tests is exactly the reference's (:441-476) -- a parked lane does nothing in between -- but the wave
     // issues the ~150-instruction triangle block for ~half its live lanes instead of for 3-4 of them.
     int pl = 0, pr = 0;  // parked leaf links as stored in the node record (~triangle id: negative), 0 = none
-    bool pLeftNear = false;
-    bool parkedNow = false;  // pl < 0 || pr < 0; false again once the tests have run
+    int pLeftNear = 0;   // (an integer in a vector register, written under the step's own exec mask: as a flag it was a lane mask merged by the scalar unit at every step)
+    // (a lane waits for its leaf tests iff pl | pr < 0: read from the two links where it is needed -- as a flag of its own it was a
+    // lane mask the scalar unit merged at every step; with sp: (sp | pl | pr) >= 0 says "a node step is due" in one compare)
     bool stepping = sp >= 0; // a node step is due: sp >= 0 && !parkedNow (assigned for the whole wave at once, no merge)
     for (;;) {
         if (stepping) {
@@ -537,8 +538,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 const bool leafL = ogL && lfL, leafR = ogR && lfR;
                 pl = leafL ? lk.x : 0;   // accepted leaves, :441-448: tested below (kept undecoded: one select each)
                 pr = leafR ? lk.y : 0;
-                pLeftNear = leftNear;
-                parkedNow = leafL || leafR;
+                pLeftNear = leftNear ? 1 : 0;
                 const bool intL = ogL != leafL, intR = ogR != leafR;  // accepted and not a leaf (one mask XOR, no second compare)
                 const bool leftFirst = intL && (leftNear || !intR);  // :451-462: both ? leftNear : intL
                 const int first = leftFirst ? lk.x : lk.y, second = leftFirst ? lk.y : lk.x;
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             }
         }
         // wave-uniform bookkeeping, in scalar registers: np lanes wait for a leaf test, nl lanes have work of any kind
-        stepping = sp >= 0 && !parkedNow;
-        const int np = __popcll(lane_mask(parkedNow));
+        stepping = (sp | pl | pr) >= 0;
+        const int np = __popcll(lane_mask((pl | pr) < 0));
         const int nl = np + __popcll(lane_mask(stepping));
         if (COUNT) dg_steps++;
 #if PSM_EXP_WAVELOG
@@ -582,9 +582,9 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         // nobody left -- or at most solo_max rays and nobody to hand them to: the wave walks those one at a time, all lanes on
         // one ray (below the loop). One more difference in the AND above and this compare are all the node step pays for it.
         if (nl <= soloMax) break;
-        if (parkedNow) {  // testIntersectionPacked, :261-309
+        if ((pl | pr) < 0) {  // testIntersectionPacked, :261-309
             // both leaves: the nearer one first (:441-448); otherwise the one that is a leaf (pl, pr are 0 when not)
-            const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
+            const bool lo = (pl < 0) && (pLeftNear != 0 || pr >= 0);
             const int tx = ~(lo ? pl : pr), ty = ~(lo ? pr : pl);  // triangle ids, -1 = none (~0)
             const bool validx = (tx >= 0) && (tx != lastTri);
             const bool validy = (ty >= 0) && (ty != lastTri) && (tx != ty);
@@ -613,7 +613,6 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
                 again = false;
             }
             pl = 0; pr = 0;
-            parkedNow = false;
         }
         if (capHit) {
             // every parked test has just run. Rays with work left and a chain of at most one hit hand their state
@@ -660,7 +659,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
             // every ray first leaves its lane (after this the loop's per-lane variables are dead: the solo gear needs the registers)
             if (sp >= 0 || parkedL)
                 solo_park(&xch[tid >> 6][__popcll(work & ((1ull << lj) - 1ull))][0], origin, direct, divident, norig, dirlenInv, hitMax, toffset, predist,
-                          lastTri, cur, sp, it, pl, pr, pLeftNear, parkedL);
+                          lastTri, cur, sp, it, pl, pr, pLeftNear != 0, parkedL);
             // one wave: its LDS operations execute in program order; the fences keep the compiler from moving the reads up
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -39,8 +39,8 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
             a -= 1
         valu, salu, branches, mem = mod.walk(body, a)
         assert 60 <= valu <= 84, (name, valu)        # 80 at the end of round 3 (94 at the end of round 2)
-        assert salu <= 66, (name, salu)              # hand-over 63 / single launch 49 with the exit to the solo gear (round 3: 61 / 45; round 2: 86)
-        assert branches <= 6, (name, branches)       # 6 / 4
+        assert salu <= 54, (name, salu)              # hand-over 50 / single launch 37: the exit to the solo gear is in, the parked / left-near flags are no longer lane masks (round 3: 61 / 45; round 2: 86)
+        assert branches <= 6, (name, branches)       # 5 / 4
         assert mem == 4, (name, mem)                 # two record loads, the stack's push and pop: no scratch in the step
         assert not any("v_pk_" in l for l in body), name   # no packed-fp32 pairs (the SLP vectoriser's)
         seen += 1
@@ -51,7 +51,9 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
         blk = meta[meta.index(".name:           " + kern):]
         blk = blk[:blk.index(".wavefront_size")]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 64, kern
-        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, kern
+        # (the hand-over kernel parks two vector registers of its prologue in scratch -- stored before the batch loop, reloaded in a
+        # batch's set-up and in the hand-over's write-out; the step itself has no scratch access: `mem == 4` above)
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) <= (2 if "ILb0ELb0ELb1E" in kern else 0), kern
         # (one scalar of the hand-over kernel's prologue is parked in a vector lane since the solo gear came: lines 105 / 244 of
         # its assembly, long before the loop; the walk above would count a reload inside the step)
         assert int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1)) <= 1, kern
