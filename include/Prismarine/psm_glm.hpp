@@ -1,4 +1,6 @@
-// psm_glm.hpp -- the few glm types/functions the Prismarine host API mentions in its signatures.
+// psm_glm.hpp -- the few glm types/functions the Prismarine host API mentions in its signatures, and the ones the reference's
+// viewer builds its node transforms with (Source/Examples/Viewer.cpp:240-258: make_mat4 / make_vec3 / make_quat, translate,
+// scale, mat4_cast on doubles).
 // If a real glm is on the include path it is used; otherwise this minimal stand-in (column-major,
 // glm conventions: m[col][row], perspective/lookAt right-handed, depth -1..1) keeps the headers
 // self-contained.  Host-side convenience only: kernels never see these types.
@@ -8,6 +10,7 @@
 #include <glm/glm.hpp>
 #include <glm/gtc/matrix_transform.hpp>
 #include <glm/gtc/type_ptr.hpp>
+#include <glm/gtc/quaternion.hpp>
 #define PSM_HAVE_GLM 1
 #endif
 #endif
@@ -103,13 +106,27 @@ template <typename T> inline tmat4<T> perspective(T fovy, T aspect, T zn, T zf) 
     r[3][2] = -(T(2) * zf * zn) / (zf - zn);
     return r;
 }
+// glm/gtc/type_ptr.hpp make_*: copies of the memory (a matrix column by column, a quaternion as x, y, z, w)
+template <typename T> inline tmat4<T> make_mat4(const T* p) { tmat4<T> r(T(0)); for (int c = 0; c < 4; c++) for (int j = 0; j < 4; j++) r[c][j] = p[4 * c + j]; return r; }
+template <typename T> inline tvec3<T> make_vec3(const T* p) { return tvec3<T>(p[0], p[1], p[2]); }
+template <typename T> struct tquat { T x, y, z, w; };
+template <typename T> inline tquat<T> make_quat(const T* p) { return tquat<T>{p[0], p[1], p[2], p[3]}; }
+// glm/gtc/quaternion.inl mat3_cast / mat4_cast, in its operation order (tests/golden/glm_gltf_transforms.npz)
+template <typename T> inline tmat4<T> mat4_cast(const tquat<T>& q) {
+    tmat4<T> r(T(1));
+    T qxx(q.x * q.x), qyy(q.y * q.y), qzz(q.z * q.z), qxz(q.x * q.z), qxy(q.x * q.y), qyz(q.y * q.z), qwx(q.w * q.x), qwy(q.w * q.y), qwz(q.w * q.z);
+    r[0][0] = T(1) - T(2) * (qyy + qzz); r[0][1] = T(2) * (qxy + qwz); r[0][2] = T(2) * (qxz - qwy);
+    r[1][0] = T(2) * (qxy - qwz); r[1][1] = T(1) - T(2) * (qxx + qzz); r[1][2] = T(2) * (qyz + qwx);
+    r[2][0] = T(2) * (qxz + qwy); r[2][1] = T(2) * (qyz - qwx); r[2][2] = T(1) - T(2) * (qxx + qyy);
+    return r;
+}
 template <typename T> inline T pi() { return T(3.14159265358979323846264338327950288); }
 template <typename T> inline const T* value_ptr(const tmat4<T>& m) { return &m.c[0].x; }
 template <typename T> inline const T* value_ptr(const tvec4<T>& v) { return &v.x; }
 
 typedef tvec2<float> vec2; typedef tvec3<float> vec3; typedef tvec4<float> vec4;
 typedef tvec2<int> ivec2; typedef tvec4<int> ivec4; typedef tvec4<unsigned> uvec4;
-typedef tvec3<double> dvec3; typedef tmat4<float> mat4; typedef tmat4<double> dmat4;
+typedef tvec3<double> dvec3; typedef tmat4<float> mat4; typedef tmat4<double> dmat4; typedef tquat<float> quat; typedef tquat<double> dquat;
 
 }  // namespace glm
 #endif  // !PSM_HAVE_GLM

@@ -326,38 +326,48 @@ class TriangleHierarchy:
         texcoord_accessor (v is stored as 1 - v, loader.comp:97-99),
         transform / transform_inv (row-major 4x4), material_id, index16, node_count, primitive_type,
         loading_offset. The pools are uploaded to device buffers and resolved by the HIP gather kernel."""
-        verts = np.ascontiguousarray(mesh["vertices"], np.float32)
-        idx = None if mesh.get("indices") is None else np.ascontiguousarray(mesh["indices"], np.uint32)
-        hv = self.ctx.buf_alloc(max(verts.nbytes, 4))
-        self.ctx.buf_upload(hv, verts)
-        hi = None
-        if idx is not None:
-            hi = self.ctx.buf_alloc(max(idx.nbytes, 4))
-            self.ctx.buf_upload(hi, idx)
+        self.loadMeshes([mesh])
+
+    def loadMeshes(self, meshes):
+        """loadMesh for every description of `meshes`, in order. Descriptions that share a pool (the same numpy array: the
+        primitives of one glTF buffer, gltf.read_gltf) share its upload, as the reference's primitives share a GL buffer
+        (Viewer.cpp:133-139)."""
+        pools = {}   # id(array) -> (handle, contiguous array kept alive)
+
+        def dev(a, dtype):
+            if id(a) not in pools:
+                c = np.ascontiguousarray(a, dtype)
+                h = self.ctx.buf_alloc(max(c.nbytes, 4))
+                pools[id(a)] = (h, c, a)
+                self.ctx.buf_upload(h, c)
+            h, c, _ = pools[id(a)]
+            return self.ctx.buf_ptr(h)[0], c.size
+
         try:
-            acc = (Accessor * len(mesh["accessors"]))(*[Accessor(*a) for a in mesh["accessors"]])
-            views = (BufferView * len(mesh["views"]))(*[BufferView(*v) for v in mesh["views"]])
-            d = MeshDesc()
-            d.d_vertices, d.vertex_floats = self.ctx.buf_ptr(hv)[0], verts.size
-            d.d_indices, d.index_words = (self.ctx.buf_ptr(hi)[0] if hi is not None else None), (idx.size if idx is not None else 0)
-            d.accessors, d.accessor_count = C.cast(acc, C.c_void_p), len(mesh["accessors"])
-            d.views, d.view_count = C.cast(views, C.c_void_p), len(mesh["views"])
-            d.vertex_accessor, d.normal_accessor = mesh["vertex_accessor"], mesh.get("normal_accessor", -1)
-            d.texcoord_accessor, d.modifier_accessor = mesh.get("texcoord_accessor", -1), -1
-            t = np.ascontiguousarray(mesh["transform"], np.float32).reshape(16)
-            ti = np.ascontiguousarray(mesh["transform_inv"], np.float32).reshape(16)
-            for k in range(16):
-                d.transform[k], d.transform_inv[k] = t[k], ti[k]
-            d.material_id, d.is_indexed, d.index16 = mesh.get("material_id", self.materialID), int(idx is not None), int(mesh.get("index16", 0))
-            d.node_count, d.primitive_type = mesh["node_count"], mesh.get("primitive_type", 0)
-            d.loading_offset = mesh.get("loading_offset", 0)
-            self.ctx.check(lib().psm_bvh_load_mesh(self._h, C.byref(d)), "psm_bvh_load_mesh")
-            self.triangleCount += mesh["node_count"] * (2 if mesh.get("primitive_type", 0) == 1 else 1)
-            self.markDirty()
+            for mesh in meshes:
+                idx = mesh.get("indices")
+                acc = (Accessor * len(mesh["accessors"]))(*[Accessor(*a) for a in mesh["accessors"]])
+                views = (BufferView * len(mesh["views"]))(*[BufferView(*v) for v in mesh["views"]])
+                d = MeshDesc()
+                d.d_vertices, d.vertex_floats = dev(mesh["vertices"], np.float32)
+                d.d_indices, d.index_words = dev(idx, np.uint32) if idx is not None else (None, 0)
+                d.accessors, d.accessor_count = C.cast(acc, C.c_void_p), len(mesh["accessors"])
+                d.views, d.view_count = C.cast(views, C.c_void_p), len(mesh["views"])
+                d.vertex_accessor, d.normal_accessor = mesh["vertex_accessor"], mesh.get("normal_accessor", -1)
+                d.texcoord_accessor, d.modifier_accessor = mesh.get("texcoord_accessor", -1), -1
+                t = np.ascontiguousarray(mesh["transform"], np.float32).reshape(16)
+                ti = np.ascontiguousarray(mesh["transform_inv"], np.float32).reshape(16)
+                for k in range(16):
+                    d.transform[k], d.transform_inv[k] = t[k], ti[k]
+                d.material_id, d.is_indexed, d.index16 = mesh.get("material_id", self.materialID), int(idx is not None), int(mesh.get("index16", 0))
+                d.node_count, d.primitive_type = mesh["node_count"], mesh.get("primitive_type", 0)
+                d.loading_offset = mesh.get("loading_offset", 0)
+                self.ctx.check(lib().psm_bvh_load_mesh(self._h, C.byref(d)), "psm_bvh_load_mesh")
+                self.triangleCount += mesh["node_count"] * (2 if mesh.get("primitive_type", 0) == 1 else 1)
+                self.markDirty()
         finally:
-            self.ctx.buf_free(hv)
-            if hi is not None:
-                self.ctx.buf_free(hi)
+            for h, _, _ in pools.values():
+                self.ctx.buf_free(h)
 
     def isDirty(self):
         return self._dirty

@@ -1,0 +1,273 @@
+"""glTF scene loading as the reference's viewer does it (Source/Examples/Viewer.cpp:66-279): prismarine-core_amd/gltf.py
+against the reference's vendored glm (committed fixture), against an independent numpy evaluation of the file by the glTF
+specification's own rules, and through the oracle's loader restatement. No GPU needed."""
+import base64
+import importlib
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from util import bits
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COURT = os.path.join(GOLD, "gltf", "court.gltf")
+
+
+@pytest.fixture(scope="module")
+def gltf():
+    return importlib.import_module("prismarine-core_amd.gltf")
+
+
+def _golden():
+    return np.load(os.path.join(GOLD, "glm_gltf_transforms.npz"))
+
+
+def _node(z, t):
+    node = {}
+    if z["has"][t, 0]:
+        node["matrix"] = z["matrix"][t].tolist()
+    for k, key in ((1, "translation"), (2, "scale"), (3, "rotation")):
+        if z["has"][t, k]:
+            node[key] = z[key][t].tolist()
+    return node
+
+
+def test_node_transforms_match_reference_glm(gltf):
+    """parent * (matrix * T * S * R) in doubles, the root's scale(mscale), and what setTransform uploads for them -- bit for bit
+    what the reference's vendored glm computes through the calls Viewer.cpp:240-258 / VertexInstance.inl:54-58 make
+    (tests/golden/glm_gltf_transforms.npz, written by make_glm_golden.py from oracle/_ref/libglm_pin.so)."""
+    z = _golden()
+    n = z["parent"].shape[0]
+    assert n > 100 and z["has"][:16].tolist() == [[(t >> k) & 1 for k in range(4)] for t in range(16)]   # every combination
+    for t in range(n):
+        m = gltf.node_transform(z["parent"][t].reshape(4, 4).T, _node(z, t))
+        assert np.array_equal(m.view(np.uint64), z["transform"][t].reshape(4, 4).T.copy().view(np.uint64)), t
+        tf, tfi = gltf.mesh_transform(m)
+        assert np.array_equal(bits(tf), bits(z["mesh_transform"][t])), t
+        assert np.array_equal(bits(tfi.reshape(4, 4).T.reshape(16)), bits(z["mesh_transform_inv"][t])), t
+    for s, r in zip(z["mscale"], z["roots"]):
+        assert np.array_equal(gltf.root_transform(s).view(np.uint64), r.reshape(4, 4).T.copy().view(np.uint64))
+
+
+def test_viewer_order_is_t_s_r_not_t_r_s(gltf):
+    """The viewer multiplies T * S * R (Viewer.cpp:249-251); glTF defines T * R * S. With a non-uniform scale they differ, and
+    as_viewer=False composes the specification's order."""
+    node = {"translation": [1.0, 2.0, 3.0], "rotation": [0.0, 0.38268343236508978, 0.0, 0.92387953251128674], "scale": [1.0, 2.0, 3.0]}
+    eye = np.eye(4)
+    a, b = gltf.node_transform(eye, node), gltf.node_transform(eye, node, as_viewer=False)
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    R = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]])
+    T = np.eye(4); T[:3, 3] = [1, 2, 3]
+    S = np.diag([1.0, 2.0, 3.0, 1.0])
+    np.testing.assert_allclose(a, T @ S @ R, atol=1e-12)
+    np.testing.assert_allclose(b, T @ R @ S, atol=1e-12)
+    assert np.abs(a - b).max() > 0.5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/External/include/glm"), reason="the reference tree is not on this machine")
+def test_gltf_glm_fixture_is_what_the_reference_glm_computes():
+    """Where /root/reference exists: the committed fixture is the output of the glm the reference vendors."""
+    import ctypes as C
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_glm_golden", os.path.join(GOLD, "make_glm_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    L = mod.pin_lib()
+    z = _golden()
+    for t in range(0, z["parent"].shape[0], 5):
+        has, hm = z["has"][t], bool(z["has"][t, 0])
+        out = np.zeros(16)
+        arg = lambda k, a: mod.p(np.ascontiguousarray(a[t])) if has[k] and (k == 0 or not hm) else None
+        L.glm_pin_gltf_node(mod.p(np.ascontiguousarray(z["parent"][t])), arg(0, z["matrix"]), arg(1, z["translation"]),
+                            arg(2, z["scale"]), arg(3, z["rotation"]), mod.p(out))
+        assert np.array_equal(out.view(np.uint64), z["transform"][t].view(np.uint64)), t
+        tf, tfi = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        L.glm_pin_mesh_transform(mod.p(out), mod.p(tf), mod.p(tfi))
+        assert np.array_equal(bits(tf), bits(z["mesh_transform"][t])) and np.array_equal(bits(tfi), bits(z["mesh_transform_inv"][t]))
+
+
+def test_host_header_glm_standin_builds_the_viewers_node_transforms(tmp_path):
+    """include/Prismarine/psm_glm.hpp (what a C++ host gets when no glm is installed): the viewer's node-transform code
+    (Viewer.cpp:246-258: make_mat4 / make_vec3 / make_quat, translate, scale, mat4_cast, dmat4 products, setTransform's
+    transpose and inverse) compiled against the stand-in gives the reference glm's matrices bit for bit -- zero for zero
+    included, as long as no operand is a negative zero (the stand-in's product starts its sums at +0)."""
+    import subprocess
+    z = _golden()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "glm_standin_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DPSM_NO_SYSTEM_GLM", "-I", os.path.join(root, "include"),
+                           "-o", exe, os.path.join(root, "tests", "cpp", "glm_standin_check.cpp")])
+    n = z["parent"].shape[0]
+    lines = ["%d" % n]
+    for t in range(n):
+        vals = np.concatenate([z["parent"][t], z["matrix"][t], z["translation"][t], z["scale"][t], z["rotation"][t]]).astype(np.float64)
+        lines.append(" ".join(str(int(v)) for v in z["has"][t]) + " " + " ".join("%016x" % w for w in vals.view(np.uint64)))
+    out = subprocess.run([exe, "gltf"], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+    for t in range(n):
+        w = out[t].split()
+        tr = np.array([int(x, 16) for x in w[:16]], np.uint64).view(np.float64)
+        a = np.array([int(x, 16) for x in w[16:32]], np.uint32).view(np.float32)
+        b = np.array([int(x, 16) for x in w[32:48]], np.uint32).view(np.float32)
+        assert np.array_equal(tr, z["transform"][t]) and np.array_equal(a, z["mesh_transform"][t]) and np.array_equal(b, z["mesh_transform_inv"][t]), t
+        nz = z["transform"][t] != 0
+        assert np.array_equal(tr.view(np.uint64)[nz], z["transform"][t].view(np.uint64)[nz]), t
+
+
+# ---- the file ----------------------------------------------------------------------------------------------------------------
+
+def test_court_scene_is_loaded_the_viewers_way(gltf, caplog):
+    import logging
+    with caplog.at_level(logging.INFO, logger="prismarine.gltf"):
+        sc = gltf.read_gltf(COURT)
+    inst = sc["instances"]
+    # load order = the walk's order: floor, box, pyramid, lone triangle, pillar (three levels down), the second box
+    assert [m["node_count"] for m in inst] == [128, 12, 6, 1, 12, 12]
+    assert [m["material_id"] for m in inst] == [1, 0, 2, -1, 3, 0]
+    assert sc["triangle_count"] == 171
+    assert [m["index16"] for m in inst] == [0, 1, 1, 0, 1, 1]
+    assert inst[3]["indices"] is None                                   # no indices: one triangle (Structs.hpp:218)
+    assert inst[2]["loading_offset"] % 2 == 1                           # 16-bit indices at 2 mod 4 bytes
+    assert inst[1]["accessors"] == [(3, 2, 0), (0, 2, 0), (6, 1, 0)]     # NORMAL, POSITION, TEXCOORD_0: std::map order; offset4 in floats
+    assert (inst[1]["vertex_accessor"], inst[1]["normal_accessor"], inst[1]["texcoord_accessor"]) == (1, 0, 2)
+    assert sc["views"][0] == (0, 8) and inst[2]["normal_accessor"] == -1
+    assert inst[4]["vertices"] is not inst[0]["vertices"] and inst[1]["vertices"] is inst[5]["vertices"]   # two buffers; an instance shares its pool
+    assert np.array_equal(inst[1]["transform"], inst[1]["transform"]) and not np.array_equal(inst[1]["transform"], inst[5]["transform"])
+    # materials, Viewer.cpp:84-137
+    m = sc["materials"]
+    assert len(m) == 5
+    assert m[0]["diffuse"] == tuple(float(np.float32(v)) for v in (0.8, 0.3, 0.2)) + (1.0,)
+    assert m[0]["specular"] == (1.0, float(np.float32(0.9)), 0.0, 1.0) and m[0]["emissive"] == (0.0, 0.0, 0.0, 0.0)
+    assert m[1]["diffuse"] == (1.0, 1.0, 1.0, 1.0) and m[1]["diffusePart"] == 1 and m[1]["bumpPart"] == 2
+    assert m[2]["emissive"] == (4.0, 3.0, 2.0, 1.0) and m[2]["emissivePart"] == 0       # its image does not exist: slot 0
+    assert m[3]["specular"] == (1.0, 1.0, 1.0, 1.0) and m[3]["diffuse"] == (1.0, 1.0, 1.0, 1.0)
+    assert m[4]["diffusePart"] == 1                                                   # the same image through another texture: one slot
+    # textures: bottom row first (FreeImage_GetBits -> glTextureSubImage2D, TextureSet.inl:103-118)
+    assert sorted(sc["textures"]) == [1, 2]
+    tiles = np.load(os.path.join(GOLD, "gltf", "court_tiles.png.npy"))
+    assert np.array_equal(sc["textures"][1], tiles[::-1]) and sc["textures"][2].shape == (16, 16, 4)
+    # nothing is dropped in silence
+    ig = sc["ignored"]
+    for what in ("attribute COLOR_0", "children of a node with a mesh", "nodes deeper than four levels", "primitive mode 1",
+                 "primitive without indices", "scenes beyond the first", "image file not found: court_missing.png", "samplers",
+                 "material.doubleSided"):
+        assert any(k.startswith(what) for k in ig), what
+    assert "not used by the path" in caplog.text
+    # the careful reading: children of mesh nodes, the deep chain, every vertex of the un-indexed primitive
+    sc2 = gltf.read_gltf(COURT, as_viewer=False)
+    assert len(sc2["instances"]) == 8 and sc2["triangle_count"] == 171 + 1 + 12 + 12
+
+
+def _spec_read(g, buffers, ai):
+    """An accessor read by the glTF specification's rules (byte offsets, byteStride or tight packing)."""
+    a = g["accessors"][ai]
+    bv = g["bufferViews"][a["bufferView"]]
+    dt, n = {5126: ("<f4", 4), 5123: ("<u2", 2), 5125: ("<u4", 4)}[a["componentType"]]
+    nc = {"SCALAR": 1, "VEC2": 2, "VEC3": 3}[a["type"]]
+    stride = bv.get("byteStride", nc * n)
+    base = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+    raw = buffers[bv["buffer"]]
+    return np.stack([np.frombuffer(raw, dt, nc, base + i * stride) for i in range(a["count"])]).astype(np.float64 if dt == "<f4" else np.int64)
+
+
+def _spec_world(g, ni, parent):
+    nd = g["nodes"][ni]
+    if "matrix" in nd:
+        local = np.array(nd["matrix"], np.float64).reshape(4, 4).T
+    else:
+        T, S, R = np.eye(4), np.eye(4), np.eye(4)
+        if "translation" in nd:
+            T[:3, 3] = nd["translation"]
+        if "scale" in nd:
+            S[:3, :3] = np.diag(nd["scale"])
+        if "rotation" in nd:
+            x, y, z, w = nd["rotation"]
+            R[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]
+        local = T @ S @ R                       # the viewer's order
+    return parent @ local
+
+
+def test_court_geometry_against_the_specifications_reading(gltf, oracle):
+    """Every instance through the oracle's loader restatement (what the HIP gather kernel is held to, bit for bit, on the GPU)
+    against the file read by the glTF specification's own rules in float64 numpy: positions and texcoords to 1e-5, normals by
+    the inverse transpose, the face-normal fallback where the file has no normals, material ids, the order of the triangles."""
+    g = json.load(open(COURT))
+    base = os.path.dirname(COURT)
+    buffers = []
+    for b in g["buffers"]:
+        buffers.append(base64.b64decode(b["uri"].split(",", 1)[1]) if b["uri"].startswith("data:") else open(os.path.join(base, b["uri"]), "rb").read())
+    sc = gltf.read_gltf(COURT, mscale=1.5)
+    walk = [(1, [0]), (2, [0]), (3, [0]), (3, [0]), (7, [0, 4, 6]), (8, [0])]      # node and its ancestors, in load order
+    prim = [(1, 0), (0, 0), (2, 0), (2, 1), (3, 0), (0, 0)]                        # (mesh, primitive)
+    for inst, (ni, anc), (mi, pi) in zip(sc["instances"], walk, prim):
+        M = np.diag([1.5, 1.5, 1.5, 1.0])
+        for a in anc:
+            M = _spec_world(g, a, M)
+        M = _spec_world(g, ni, M)
+        p = g["meshes"][mi]["primitives"][pi]
+        P = _spec_read(g, buffers, p["attributes"]["POSITION"])
+        idx = _spec_read(g, buffers, p["indices"]).reshape(-1) if "indices" in p else np.arange(3)
+        tri = P[idx].reshape(-1, 3, 3)
+        world = (np.concatenate([tri, np.ones(tri.shape[:2] + (1,))], 2) @ M.T)[..., :3]
+        pos, nrm, mats, tex = oracle.load_mesh(inst, with_tex=True)
+        assert pos.shape[0] == tri.shape[0] == inst["node_count"]
+        np.testing.assert_allclose(pos.reshape(-1, 3, 3), world, rtol=2e-6, atol=2e-6)
+        assert np.all(mats == p.get("material", -1))
+        if "NORMAL" in p["attributes"]:
+            N = _spec_read(g, buffers, p["attributes"]["NORMAL"])[idx].reshape(-1, 3, 3) @ np.linalg.inv(M)[:3, :3]
+        else:
+            fn = np.cross(world[:, 1] - world[:, 0], world[:, 2] - world[:, 0])
+            N = np.repeat(fn[:, None, :], 3, 1)
+        N = N / np.linalg.norm(N, axis=-1, keepdims=True)
+        np.testing.assert_allclose(nrm.reshape(-1, 3, 3), N, atol=3e-6)
+        if "TEXCOORD_0" in p["attributes"]:
+            uv = _spec_read(g, buffers, p["attributes"]["TEXCOORD_0"])[idx].reshape(-1, 3, 2)
+            np.testing.assert_allclose(tex.reshape(-1, 3, 2), np.stack([uv[..., 0], 1.0 - uv[..., 1]], -1), atol=1e-6)   # INVERT_TX_Y
+        else:
+            assert np.all(tex.reshape(-1, 3, 2) == np.float32([0.0, 1.0]))
+
+
+def test_court_renders_on_the_oracle(gltf, oracle, scenes):
+    """The loaded scene is a scene: the oracle builds it and three frames see the lamp's light on the textured floor."""
+    from util import gltf_soup
+    sc = gltf_soup(oracle, gltf.read_gltf(COURT))
+    assert sc["tris"].shape[0] == 171 and sc["texcoords"].shape == (171, 3, 2)
+    img, stats = oracle.render_frames(sc, 48, 32, frames=2, seed=3, nthreads=8)
+    assert np.isfinite(img).all() and img[..., :3].max() > 0.05 and (img[..., 3] > 0).mean() > 0.9
+
+
+@pytest.mark.parametrize("edit,what", [
+    (lambda g: g["accessors"][0].update(bufferView=99), "bufferView"),
+    (lambda g: g["accessors"][0].update(componentType=5123), "component type"),
+    (lambda g: g["meshes"][0]["primitives"][0]["attributes"].pop("POSITION"), "POSITION"),
+    (lambda g: g["meshes"][0]["primitives"][0].update(indices=77), "indices"),
+    (lambda g: g["meshes"][0]["primitives"][0].update(material=9), "material"),
+    (lambda g: g["nodes"][1].update(mesh=12), "mesh"),
+    (lambda g: g["nodes"][4].update(children=[0]), "ancestor"),
+    (lambda g: g["buffers"][0].update(uri="nowhere.bin"), "not found"),
+    (lambda g: g["buffers"][0].pop("uri"), "uri"),
+    (lambda g: g["buffers"][0].update(byteLength=1 << 20), "byteLength"),
+    (lambda g: g["bufferViews"][0].update(byteStride=30), "byteStride"),
+    (lambda g: g["textures"][0].update(source=5), "source"),
+    (lambda g: g["materials"][1]["pbrMetallicRoughness"]["baseColorTexture"].update(index=40), "baseColorTexture"),
+])
+def test_malformed_gltf_raises_naming_the_element(gltf, tmp_path, edit, what):
+    d = tmp_path / "g"
+    shutil.copytree(os.path.join(GOLD, "gltf"), d)
+    g = json.load(open(d / "court.gltf"))
+    edit(g)
+    json.dump(g, open(d / "court.gltf", "w"))
+    with pytest.raises(ValueError) as e:
+        gltf.read_gltf(str(d / "court.gltf"))
+    assert what in str(e.value) and "court.gltf" in str(e.value)
+
+
+def test_not_json_and_binary_containers_are_refused(gltf, tmp_path):
+    p = tmp_path / "x.glb"
+    p.write_bytes(b"glTF\x02\x00\x00\x00" + b"\0" * 20)
+    with pytest.raises(ValueError):
+        gltf.read_gltf(str(p))

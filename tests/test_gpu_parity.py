@@ -744,6 +744,124 @@ def test_obj_files_build_hits_and_radiance(psm, ctx, oracle, scenes, stem):
     th.close()
 
 
+def test_gltf_scene_from_file_to_image(psm, ctx, oracle, scenes):
+    """The reference viewer's only input format (Source/Examples/Viewer.cpp:66-279), tests/golden/gltf/court.gltf: interleaved
+    and planar views, a padded stride, 16-bit indices at an odd half-word, a primitive without normals, one without indices, two
+    buffers, T * S * R and matrix nodes, an instance, textures by slot. Every (node, primitive) goes through psm_bvh_load_mesh --
+    the gather kernel de-indexes, reads by accessor, transforms, falls back to face normals -- and must equal the oracle's
+    loader restatement bit for bit (positions, normals, texcoords, material ids, in loading order); then the HLBVH and the
+    primary hits bit for bit and three frames of radiance within 1e-4."""
+    import importlib
+    from util import gltf_soup
+    gltf = importlib.import_module("prismarine-core_amd.gltf")
+    gs = gltf.read_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gltf", "court.gltf"))
+    scene = gltf_soup(oracle, gs)
+    n = gs["triangle_count"]
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(n)
+    ms = psm.MaterialSet()
+    ts = gltf.load_into(gs, th, ms)
+    assert th.triangleCount == n == scene["tris"].shape[0] and ms.getMaterialCount() == 5 and len(ts.textures) == 3
+    assert np.array_equal(bits(th.download(psm.BVH_POSITIONS, np.float32, 9 * n)), bits(scene["tris"].reshape(-1)))
+    assert np.array_equal(bits(th.download(psm.BVH_NORMALS, np.float32, 9 * n)), bits(scene["normals"].reshape(-1)))
+    assert np.array_equal(bits(th.download(psm.BVH_TEXCOORDS, np.float32, 6 * n)), bits(scene["texcoords"].reshape(-1)))
+    assert np.array_equal(th.download(psm.BVH_MATERIALS, np.int32, n), scene["mats"])
+    _check_build(psm, ctx, oracle, scene)            # (the same soup through loadTriangles: every stage of the build)
+    th.build()
+    ob = oracle.build_scene(scene["tris"])
+    assert np.array_equal(th.download(psm.BVH_KEYS, np.uint64, ob["count"]), ob["keys"])
+    w, h = 64, 48
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
+    rt.camera_matrices(cam[0], cam[1], time=7)
+    rt.applyMaterials(ms)
+    rays = rt.download_rays()
+    rt.intersection(th)
+    gh, gc = rt.download_hits(rays.shape[0])
+    oh, oc, _ = oracle.traverse(ob["nodes"], scene["tris"], ob["M"], rays["origin"], rays["direct"], 8)
+    _hits_equal(gh, gc, oh, oc)
+    assert (oc > 0).mean() > 0.5
+    rt.setSeed(4711)
+    rt.clearSampler()
+    for _ in range(3):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"])
+    img = rt.snapHdr()
+    ref, stats = oracle.render_frames(scene, w, h, frames=3, seed=4711, nthreads=8)
+    assert ref[..., :3].max() > 0.05
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    rt.close()
+    th.close()
+
+
+def test_cpp_header_layer_loads_a_gltf_scene_like_the_viewer(psm, ctx, oracle, tmp_path):
+    """include/Prismarine drop-in headers: the viewer's glTF loop (Viewer.cpp:133-277) in C++ -- raw buffers, BufferViewSet,
+    a TriangleArrayInstance + AccessorSet per primitive, the node walk in (stand-in) glm doubles, setTransform + loadMesh per
+    (node, primitive) -- leaves in the hierarchy exactly what gltf.read_gltf + the oracle's loader give: positions, normals,
+    texcoords and material ids bit for bit, in loading order (tests/cpp/gltf_load.cpp; the parsed file goes over in a flat
+    binary form written here from the JSON, the step the reference leaves to tinygltf)."""
+    import base64
+    import importlib
+    import json
+    import struct
+    import subprocess
+    from util import gltf_soup
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gltf_load")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(root, "include"), "-DPSM_NO_SYSTEM_GLM",
+                           os.path.join(root, "tests", "cpp", "gltf_load.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "prismarine-core_amd"), "-lpsm_hip",
+                           "-Wl,-rpath," + os.path.join(root, "prismarine-core_amd")])
+    path = os.path.join(root, "tests", "golden", "gltf", "court.gltf")
+    g = json.load(open(path))
+    blob = bytearray()
+    i32 = lambda *v: blob.extend(struct.pack("<%di" % len(v), *v))
+    f64 = lambda v: blob.extend(struct.pack("<%dd" % len(v), *v))
+    i32(len(g["buffers"]))
+    for b in g["buffers"]:
+        raw = base64.b64decode(b["uri"].split(",", 1)[1]) if b["uri"].startswith("data:") else open(os.path.join(os.path.dirname(path), b["uri"]), "rb").read()
+        raw = raw + b"\0" * (-len(raw) % 4)
+        i32(len(raw))
+        blob.extend(raw)
+    i32(len(g["bufferViews"]))
+    for v in g["bufferViews"]:
+        i32(v["buffer"], v.get("byteOffset", 0), v.get("byteStride", 0))
+    i32(len(g["accessors"]))
+    for a in g["accessors"]:
+        i32(a["bufferView"], a.get("byteOffset", 0), a["componentType"], a["count"])
+    i32(len(g["meshes"]))
+    for m in g["meshes"]:
+        i32(len(m["primitives"]))
+        for p in m["primitives"]:
+            at = p["attributes"]
+            i32(at.get("POSITION", -1), at.get("NORMAL", -1), at.get("TEXCOORD_0", -1), p.get("indices", -1), p.get("material", -1), p.get("mode", 4))
+    i32(len(g["nodes"]))
+    for nd in g["nodes"]:
+        hm = "matrix" in nd
+        i32(nd.get("mesh", -1), int(hm), int("translation" in nd and not hm), int("scale" in nd and not hm), int("rotation" in nd and not hm))
+        f64(nd.get("matrix", [0.0] * 16)); f64(nd.get("translation", [0.0] * 3)); f64(nd.get("scale", [1.0] * 3)); f64(nd.get("rotation", [0.0] * 4))
+        kids = nd.get("children", [])
+        i32(len(kids), *kids)
+    roots = g["scenes"][0]["nodes"]
+    i32(len(roots), *roots)
+    f64([1.25])
+    inp, out = str(tmp_path / "model.bin"), str(tmp_path / "soup.bin")
+    open(inp, "wb").write(bytes(blob))
+    subprocess.check_call([exe, inp, out])
+    gltf = importlib.import_module("prismarine-core_amd.gltf")
+    scene = gltf_soup(oracle, gltf.read_gltf(path, mscale=1.25))
+    raw = np.fromfile(out, np.uint8)
+    n = int(raw[:4].view(np.int32)[0])
+    assert n == scene["tris"].shape[0] == 171
+    body = raw[4:].view(np.float32)
+    assert np.array_equal(bits(body[:9 * n]), bits(scene["tris"].reshape(-1)))
+    assert np.array_equal(bits(body[9 * n:18 * n]), bits(scene["normals"].reshape(-1)))
+    assert np.array_equal(bits(body[18 * n:24 * n]), bits(scene["texcoords"].reshape(-1)))
+    assert np.array_equal(body[24 * n:].view(np.int32), scene["mats"])
+
+
 def test_tile_sharding_equals_full_frame(psm, ctx, scenes):
     """rendering row tiles separately (bounce loop in lock step on the global ray count)
     and merging texel sums reproduces the unsharded frame."""

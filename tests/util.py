@@ -78,3 +78,21 @@ def canonical_nodes(root, link, pairbox, rng, node_dt):
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def gltf_soup(oracle, gscene):
+    """A scene dict (tris / normals / mats / texcoords / materials / textures / eye / view) from a gltf.read_gltf result,
+    every instance resolved by the ORACLE's loader restatement (vertex/loader.comp:32-152) in loading order."""
+    P, N, M, T = [], [], [], []
+    for inst in gscene["instances"]:
+        pos, nrm, mats, tex = oracle.load_mesh(inst, with_tex=True)
+        P.append(pos); N.append(nrm); M.append(mats); T.append(tex)
+    tris = np.concatenate(P).reshape(-1, 3, 3)
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    c, ext = 0.5 * (lo + hi), float((hi - lo).max())
+    sc = {"name": gscene["name"], "tris": tris, "normals": np.concatenate(N).reshape(-1, 3, 3), "mats": np.concatenate(M).astype(np.int32),
+          "texcoords": np.concatenate(T).reshape(-1, 3, 2), "materials": gscene["materials"],
+          "eye": (c + np.asarray((0.1 * ext, 0.35 * ext, 0.6 * ext))).astype(np.float32), "view": c.astype(np.float32)}
+    if gscene["textures"]:
+        sc["textures"] = gscene["textures"]
+    return sc
