@@ -733,21 +733,24 @@ class Pipeline:
 
 
 def write_pfm(path, image):
-    """Save an HDR snapshot (snapHdr(); the app writes EXR on key L, Application.hpp:324-343) as a PFM file:
-    'PF', width height, scale -1.0 (little endian), rows bottom to top, RGB float32."""
+    """Save an HDR snapshot (snapHdr(); the app writes EXR on key L, Application.hpp:324-343) as a PFM file: 'PF', width height,
+    scale -1.0 (little endian), RGB float32, rows BOTTOM TO TOP -- which is the order snapHdr() returns them in: row 0 of the
+    sampler's image is the picture's bottom row (camera.comp:61: texel row 0 is NDC y = -1; the reference's HdrImage and FreeImage's
+    scanlines are bottom-up alike), so the rows are written as they come."""
     img = np.ascontiguousarray(image[..., :3], np.float32)
     with open(path, "wb") as f:
         f.write(("PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0])).encode())
-        f.write(img[::-1].astype("<f4").tobytes())
+        f.write(img.astype("<f4").tobytes())
 
 
 def read_pfm(path):
+    """The image of a PFM file in snapHdr()'s row order (row 0 = the picture's bottom row)."""
     with open(path, "rb") as f:
         assert f.readline().strip() == b"PF"
         w, h = (int(v) for v in f.readline().split())
         scale = float(f.readline())
         data = np.frombuffer(f.read(), "<f4" if scale < 0 else ">f4").reshape(h, w, 3)
-    return data[::-1].copy()
+    return data.copy()
 
 
 def traverse_group(pipelines, hierarchies, on=None):
