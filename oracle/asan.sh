@@ -1,6 +1,6 @@
 #!/bin/bash
 # The CPU oracle -- the only pin the kernels have -- under AddressSanitizer + UBSan. CPU only.
-#   oracle/asan.sh            tests/test_oracle_cpu.py + the golden regeneration against the sanitizer build
+#   oracle/asan.sh            tests/test_oracle_cpu.py, tests/test_gltf_cpu.py + the golden regeneration against the sanitizer build
 set -e
 cd "$(dirname "$0")/.."
 make -C oracle -s asan
@@ -9,7 +9,7 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export PSM_ORACLE_LIB=$PWD/oracle/libpsm_oracle_asan.so
 export OMP_NUM_THREADS=${OMP_NUM_THREADS:-4}
-python -m pytest tests/test_oracle_cpu.py -q -x -p no:cacheprovider "$@"
+python -m pytest tests/test_oracle_cpu.py tests/test_gltf_cpu.py -q -x -p no:cacheprovider "$@"
 # the golden fixtures again, into a scratch directory, and compared with the committed ones
 out=$(mktemp -d)
 PSM_GOLDEN_OUT=$out python tests/golden/make_golden.py

@@ -20,6 +20,8 @@ Faithful to the viewer, including what a careful loader would do differently (`a
     32-bit (:205-213);
   * a primitive without indices keeps MeshUniformStruct's nodeCount = 1: one triangle (Structs.hpp:218);
   * a primitive without a material has material id -1, which shades as "no material" (surface.comp);
+  * emissiveFactor goes into VirtualMaterial.emissive as the viewer puts it there (:114-120) -- and lights nothing: the path takes
+    emission from the emissive TEXTURE only (fetchEmissive, surface.comp:104-110);
   * a texture whose image cannot be read is slot 0, "none" (TextureSet.inl:88-101).
 The image files a scene names are decoded by scenes.load_image_rgba8 (a pre-decoded `<file>.npy` wins, so nothing is decoded on
 a GPU box) and handed over bottom row first, the order FreeImage gives the reference's glTextureSubImage2D (TextureSet.inl:103-118).

@@ -271,3 +271,24 @@ def test_not_json_and_binary_containers_are_refused(gltf, tmp_path):
     p.write_bytes(b"glTF\x02\x00\x00\x00" + b"\0" * 20)
     with pytest.raises(ValueError):
         gltf.read_gltf(str(p))
+
+
+def test_oracle_loader_reads_outside_the_pool_as_zero(oracle):
+    """The oracle's loader on 60 random descriptions (tests/util.py: offsets before and past the pool, strides of every kind,
+    indices past the vertices): it returns what it is asked for, never reads outside the arrays it was given (oracle/asan.sh runs
+    this file under AddressSanitizer), and the same description with its pool extended by zeros gives the same triangles -- a
+    word outside the pool reads 0 (robust buffer access, vertex/loader.comp:32-54), unless an unsigned offset wrapped into it."""
+    from util import random_mesh_descriptions
+    same = 0
+    for case, mesh in enumerate(random_mesh_descriptions(20261005, 60)):
+        pos, nrm, mats, tex = oracle.load_mesh(mesh, with_tex=True)
+        assert pos.shape[0] == mesh["node_count"] * (2 if mesh["primitive_type"] else 1) and np.all(mats == mesh["material_id"])
+        if all(v[0] >= 0 for v in mesh["views"]) and all(a[0] >= 0 for a in mesh["accessors"]):
+            big = dict(mesh, vertices=np.concatenate([mesh["vertices"], np.zeros(70000 * 12, np.float32)]))
+            if mesh["indices"] is not None:
+                big["indices"] = np.concatenate([mesh["indices"], np.zeros(64, np.uint32)])
+            p2, n2, m2, t2 = oracle.load_mesh(big, with_tex=True)
+            ok = ~np.isnan(pos)
+            assert np.array_equal(bits(pos)[ok], bits(p2)[ok]) and np.array_equal(bits(tex), bits(t2)), case
+            same += 1
+    assert same > 20

@@ -1018,6 +1018,28 @@ def test_load_mesh_matches_oracle(psm, ctx, oracle, scenes, kw):
     th.close()
 
 
+def test_load_mesh_random_descriptions_incl_out_of_range(psm, ctx, oracle):
+    """Mesh descriptions now come from files (gltf.read_gltf): 60 seeded random ones -- strides smaller and larger than the
+    element, overlapping views, accessor offsets before and past the pool, indices that point past the vertices, 16- and 32-bit
+    indices at random loading offsets, quads, pools of odd length -- must read as the oracle's loader reads them (a word outside
+    the pool is 0, as a robust GL buffer access gives; vertex/loader.comp:32-54), bit for bit, and must not fault."""
+    from util import random_mesh_descriptions
+    for case, mesh in enumerate(random_mesh_descriptions(20261005, 60)):
+        opos, onrm, omats, otex = oracle.load_mesh(mesh, with_tex=True)
+        n = opos.shape[0]
+        th = psm.TriangleHierarchy(ctx)
+        th.allocate(n)
+        th.loadMesh(mesh)
+        assert th.triangleCount == n, case
+        got = [th.download(w, np.float32, k * n).reshape(n, k) for w, k in ((psm.BVH_POSITIONS, 9), (psm.BVH_NORMALS, 9), (psm.BVH_TEXCOORDS, 6))]
+        for g, o, what in zip(got, (opos, onrm, otex), ("positions", "normals", "texcoords")):
+            gn, on = np.isnan(g), np.isnan(o)      # a degenerate triangle's face normal is 0 / 0 on both machines
+            assert np.array_equal(gn, on), (case, what)
+            assert np.array_equal(bits(g)[~on], bits(o)[~on]), (case, what)
+        assert np.array_equal(th.download(psm.BVH_MATERIALS, np.int32, n), omats), case
+        th.close()
+
+
 def test_textures_change_the_image_and_slots_can_be_freed(psm, ctx, oracle, scenes):
     """TextureSet slot reuse (TextureSet.inl:42-86): freeing the bump + emissive textures falls back to the
     untextured branches of surface.comp; an unknown / empty slot is ignored (validateTexture, :81-83)."""

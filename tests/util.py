@@ -96,3 +96,33 @@ def gltf_soup(oracle, gscene):
     if gscene["textures"]:
         sc["textures"] = gscene["textures"]
     return sc
+
+
+def random_mesh_descriptions(seed, count):
+    """Seeded random loadMesh descriptions, sane and not: strides smaller and larger than the element, overlapping views,
+    offsets before and past the pool, indices past the vertices, 16- / 32-bit indices at random loading offsets, quads."""
+    rng = np.random.RandomState(seed)
+    for case in range(count):
+        nfl = int(rng.randint(7, 600))
+        verts = rng.uniform(-4, 4, nfl).astype(np.float32)
+        if case % 7 == 0:
+            verts[rng.randint(0, nfl, 3)] = [0.0, -0.0, 1e-30]
+        views = [(int(rng.randint(-3, nfl + 5)), int(rng.choice([0, 0, 1, 2, 3, 4, 6, 8, 11, -2]))) for _ in range(int(rng.randint(1, 4)))]
+        acc = [(int(rng.randint(-2, 12)), int(rng.choice([0, 1, 2, 2, 2, 3])), int(rng.randint(0, len(views)))) for _ in range(int(rng.randint(1, 5)))]
+        quads = bool(rng.randint(0, 4) == 0)
+        nodes = int(rng.randint(1, 40))
+        indexed = bool(rng.randint(0, 3))
+        idx16 = bool(rng.randint(0, 2))
+        idx = None
+        if indexed:
+            nw = int(rng.randint(1, 80))
+            hi = 65536 if idx16 and rng.randint(0, 3) == 0 else max(nfl // 2, 2)
+            idx = (rng.randint(0, hi, nw).astype(np.uint32) | (rng.randint(0, hi, nw).astype(np.uint32) << 16 if idx16 else 0)).astype(np.uint32)
+        a = rng.uniform(0, 6.28)
+        t = np.array([[np.cos(a), 0.1, np.sin(a), rng.uniform(-2, 2)], [0, rng.uniform(0.3, 2), 0, rng.uniform(-2, 2)],
+                      [-np.sin(a), 0, np.cos(a), rng.uniform(-2, 2)], [0, 0, 0, 1]], np.float32)
+        yield {"vertices": verts, "indices": idx, "accessors": acc, "views": views,
+               "vertex_accessor": int(rng.randint(0, len(acc))), "normal_accessor": int(rng.randint(-1, len(acc))),
+               "texcoord_accessor": int(rng.randint(-1, len(acc))), "transform": t.reshape(16),
+               "transform_inv": np.linalg.inv(t.astype(np.float64)).astype(np.float32).reshape(16), "material_id": int(rng.randint(-1, 5)),
+               "index16": int(idx16), "node_count": nodes, "primitive_type": int(quads), "loading_offset": int(rng.randint(0, 30))}
