@@ -167,8 +167,8 @@ def _numbers(v, n):
     return None
 
 
-def read_gltf(path, mscale=1.0, as_viewer=True):
-    """A .gltf file -> a scene dict:
+def _read_gltf(path, mscale, as_viewer):
+    """(read_gltf below) A .gltf file -> a scene dict:
       instances   mesh descriptions in loading order, one per (node, primitive): the arguments of TriangleHierarchy.loadMesh
       materials   VirtualMaterial dicts (scenes.materials_array), texture parts as TextureSet slots
       textures    {slot: uint8 [h, w, 4] image, bottom row first}
@@ -316,7 +316,8 @@ def read_gltf(path, mscale=1.0, as_viewer=True):
     instances = []
 
     def traverse(ni, parent, recursive, seen):
-        node = nodes[_index(ni, len(nodes), "node", path)]
+        ni = _index(ni, len(nodes), "node", path)
+        node = nodes[ni]
         if ni in seen:
             raise ValueError("%s: node %d is its own ancestor" % (path, ni))
         transform = node_transform(parent, node, as_viewer)
@@ -335,7 +336,7 @@ def read_gltf(path, mscale=1.0, as_viewer=True):
                 return
         for c in kids:
             if recursive >= 0 or not as_viewer:
-                traverse(int(c), transform, recursive - 1, seen | {ni})
+                traverse(c, transform, recursive - 1, seen | {ni})
             else:
                 note("nodes deeper than four levels (not visited, Viewer.cpp:266)")
         if node.get("camera") is not None:
@@ -347,7 +348,7 @@ def read_gltf(path, mscale=1.0, as_viewer=True):
     if gscenes:
         root = root_transform(mscale)
         for ni in gscenes[0].get("nodes", []):
-            traverse(int(ni), root, 2, frozenset())
+            traverse(ni, root, 2, frozenset())
         if len(gscenes) > 1:
             note("scenes beyond the first", len(gscenes) - 1)
     else:
@@ -360,6 +361,16 @@ def read_gltf(path, mscale=1.0, as_viewer=True):
     return {"name": os.path.basename(path), "instances": instances, "materials": materials, "textures": textures,
             "triangle_count": sum(m["node_count"] for m in instances), "buffers": buffers, "views": views,
             "templates": templates, "ignored": ignored}
+
+
+def read_gltf(path, mscale=1.0, as_viewer=True):
+    """A .gltf file -> a scene dict (instances = the arguments of TriangleHierarchy.loadMesh in loading order, materials, textures by
+    slot, triangle_count, buffers, views, templates, ignored): see the module's text. Malformed input of any kind -- a missing or
+    mistyped member as much as an index out of range -- raises ValueError naming the file."""
+    try:
+        return _read_gltf(path, mscale, as_viewer)
+    except (KeyError, TypeError, IndexError, AttributeError, OverflowError) as e:
+        raise ValueError("%s: malformed glTF (%s: %s)" % (path, type(e).__name__, e)) from e
 
 
 def load_into(scene, intersector, material_manager=None, texture_set=None):

@@ -253,6 +253,9 @@ def test_court_renders_on_the_oracle(gltf, oracle, scenes):
     (lambda g: g["buffers"][0].update(byteLength=1 << 20), "byteLength"),
     (lambda g: g["bufferViews"][0].update(byteStride=30), "byteStride"),
     (lambda g: g["textures"][0].update(source=5), "source"),
+    (lambda g: g["nodes"][4].update(children=["x"]), "node index"),
+    (lambda g: g["meshes"][1]["primitives"][0].update(attributes=[1, 2]), "malformed"),
+    (lambda g: g.update(bufferViews=[3]), "malformed"),
     (lambda g: g["materials"][1]["pbrMetallicRoughness"]["baseColorTexture"].update(index=40), "baseColorTexture"),
 ])
 def test_malformed_gltf_raises_naming_the_element(gltf, tmp_path, edit, what):
