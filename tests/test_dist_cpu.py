@@ -279,6 +279,27 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert all(ln.endswith("= 2") for ln in lines)
 
 
+def test_bench_under_the_drivers_launcher_command():
+    """The driver's own N > 1 command -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W -- with --dry-run appended: every rank takes RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the launcher (no second spawn), reaches its communicator and sees the whole group (gloo, no GPU)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("bench.py dry run")]
+    assert len(lines) == 2 and {ln.split("rank ")[1].split(" ")[0] for ln in lines} == {"0", "1"}
+    assert all(ln.endswith("= 2") for ln in lines)
+
+
 def test_native_decide_equals_python_protocol():
     """psm_dist_decide (the C ABI's host-side restatement of the global `< 32 rays -> stop` rule used by
     psm_dist_render_batch) against dist.decide_sharded (the protocol the gloo tests above exercise) on random
