@@ -112,7 +112,7 @@ class Renderer:
         w, h = args.width, args.height
         # frames in flight: 4 on one GPU; 12 for a tile of a sharded frame (a tile's launches are all tail: profiles/r04_tile_emulation.txt,
         # 8 -> 12 lanes with 16 hardware queues: a worker's 1/8 tile 0.611 -> 0.588 ms, C5's 3.82 -> 3.64)
-        self.lanes = args.lanes if args.lanes > 0 else (12 if (dist.world > 1 or args.emulate_tile) else 4)
+        self.lanes = args.lanes if args.lanes > 0 else ((8 if self.hoststaged else 12) if (dist.world > 1 or args.emulate_tile) else 4)
         self.lane_streams = None
         streams = None
         if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
@@ -531,7 +531,10 @@ def main():
     os.environ["NCCL_DEBUG"] = os.environ.get("PSM_NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout
     # one hardware queue per frame in flight + the accumulating stream + the communicator's (the runtime's default of 4 makes
     # streams share a queue): 8 for the 4 lanes of one GPU, 16 for the 12 lanes of a tile; read by the HIP runtime when it initialises
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if (args.gpus > 1 or args.force_dist or args.emulate_tile) else "8")
+    # (a rehearsal of several ranks on ONE shared GPU keeps 8: beyond ~20 queues per GPU the runtime's scheduling collapses -- 24 queues
+    # under 16 lanes 2.4 times slower, two ranks with 16 each twelve times, profiles/r04_tile_emulation.txt)
+    shared_gpu = os.environ.get("PSM_DIST_TRANSPORT", "rccl") == "hoststaged"
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if ((args.gpus > 1 or args.force_dist or args.emulate_tile) and not shared_gpu) else "8")
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus))) if args.gpus > 1 else 1
     psm = importlib.import_module("prismarine-core_amd")
     pdist = importlib.import_module("prismarine-core_amd.dist")
