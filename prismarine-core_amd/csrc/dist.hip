@@ -114,6 +114,7 @@ int psm_dist_destroy(psm_dist* d) {
     if (d->d_i32) (void)hipFree(d->d_i32);
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
     if (d->ev_out) (void)hipEventDestroy(d->ev_out);
+    if (d->ev_x) (void)hipEventDestroy(d->ev_x);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
     return PSM_OK;
@@ -290,6 +291,16 @@ int psm_dist_allgather_i32(psm_dist* d, const int32_t* send, int32_t* recv, uint
     int trc = d->tr.allgather_i32(d->tr.user, d->d_i32, d->d_i32 + n, n, (void*)d->stream);
     if (trc != PSM_OK) return transport_err(d, trc, "allgather");
     PSM_HIP(c, hipMemcpyAsync(recv, d->d_i32 + n, (size_t)n * d->world * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    if (d->idle_fn) {   // the peers may be a while: the caller's other lanes are served meanwhile (psm_dist_render_frames)
+        if (!d->ev_x) PSM_HIP(c, hipEventCreateWithFlags(&d->ev_x, hipEventDisableTiming));
+        PSM_HIP(c, hipEventRecord(d->ev_x, d->stream));
+        for (;;) {
+            const hipError_t q = hipEventQuery(d->ev_x);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return set_err(c, PSM_ERR_HIP, "psm_dist_allgather_i32: hipEventQuery", q);
+            d->idle_fn(d->idle_user);
+        }
+    }
     PSM_HIP(c, hipStreamSynchronize(d->stream));
     return PSM_OK;
 }

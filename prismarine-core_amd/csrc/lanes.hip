@@ -340,6 +340,11 @@ struct ShardedLanes {
         st[s] = IDLE;
         while (rc == PSM_OK && st[s] == IDLE) rc = step(s);
     }
+    // one non-blocking pass over every lane that has a round in flight (whoever holds the host thread for a while calls it)
+    void poll_all() {
+        for (uint32_t s = 0; s < lanes && rc == PSM_OK; s++)
+            if (st[s] == RUNNING) (void)poll(s);
+    }
     // drive EVERY lane that has a round in flight until lanes [g0, g1) are all parked (lanes outside keep running)
     int drive(uint32_t g0, uint32_t g1) {
         uint32_t idle_spins = 0;
@@ -403,6 +408,9 @@ extern "C" int psm_lanes_run_sharded(psm_rt* const* rts, psm_bvh* const* bvhs, u
 // group's frames keep the chip busy, and group g starts its next frames as soon as its tiles are on their way. Every
 // rank makes the same psm_dist_* calls in the same order (group 0's batch, group 1's, group 0's ...), so one
 // communicator serves both groups. Frames fold in frame order: batch b = frames [b*h, (b+1)*h), h = lanes / 2.
+// The host thread is the only one that queues a lane's next round, so whatever else it does for a batch -- the exchange and its
+// wait for the peers, a frame's gather and fold, a lane's rebuild and camera -- it looks after every lane with a round in
+// flight in between (ShardedLanes::poll_all): a sixth of a tile's wall time used to pass with nobody looking.
 extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, const float cam_inv[16],
                                       const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
                                       int rebuild, const double* opt, psm_rt* fold_into, uint32_t* rounds_out /* [frames] or NULL */) {
@@ -432,7 +440,10 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
         f += n;
     }
     auto start_batch = [&](const Batch& B) {
-        for (uint32_t k = 0; k < B.n; k++) L.start(gbeg[B.g] + k, frame_seeds[B.f0 + k], cam_inv, proj_inv, rebuild, opt);
+        for (uint32_t k = 0; k < B.n; k++) {
+            L.start(gbeg[B.g] + k, frame_seeds[B.f0 + k], cam_inv, proj_inv, rebuild, opt);
+            L.poll_all();
+        }
     };
     // `local` is this rank's own failure. A failed rank keeps the collective sequence (rounds = -1 at the exchanges,
     // placeholder tiles in gathers already decided) until an exchange has told everybody; `rc` is the call's fate as all
@@ -445,6 +456,8 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
     }
     std::vector<int32_t> mine, all, verdict;
     std::vector<uint32_t> force;
+    d->idle_user = &L;
+    d->idle_fn = [](void* u) { ((ShardedLanes*)u)->poll_all(); };
     for (size_t b = 0; b < batches.size() && rc == PSM_OK && !transport_dead; b++) {
         const Batch& B = batches[b];
         const uint32_t g0 = gbeg[B.g], n = B.n;
@@ -453,9 +466,9 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
         if (local == PSM_OK) local = L.drive(g0, g0 + n);
         for (;;) {
             for (uint32_t k = 0; k < n && local == PSM_OK; k++) {
+                // (a parked lane's last count has been read behind the event that follows its last kernel: nothing of its frame is
+                // in flight, and no host synchronisation is needed -- 30 us apiece with a dozen streams about)
                 psm_rt* r = rts[g0 + k];
-                hipError_t e = hipStreamSynchronize(r->ctx->stream);  // parked: its last count has been read; cheap
-                if (e != hipSuccess) local = set_err(r->ctx, PSM_ERR_HIP, "hipStreamSynchronize (parked lane)", e);
                 mine[k] = (int32_t)rounds[g0 + k];
                 mine[n + k] = (int32_t)r->ray_count;
             }
@@ -477,12 +490,15 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
         for (uint32_t k = 0; k < n; k++) {  // frame order; a rank that fails here still takes part in the gathers that are due
             if (!dist_frame_gather(d, rts[g0 + k], fold_into, local, &L.pending[g0 + k])) { transport_dead = true; break; }
             if (rounds_out) rounds_out[B.f0 + k] = rounds[g0 + k];
+            L.poll_all();
         }
         if (!transport_dead && local == PSM_OK && b + groups < batches.size()) {  // this group's next frames (their camera() waits for the gather: stream order)
             start_batch(batches[b + groups]);
             local = L.rc;
         }
     }
+    d->idle_fn = nullptr;
+    d->idle_user = nullptr;
     if (!transport_dead && rc == PSM_OK) rc = psm_dist_agree(d, local);  // a failure after the last decision reaches everybody here
     if (local != PSM_OK) rc = local;
     for (uint32_t s = 0; s < lanes; s++) {

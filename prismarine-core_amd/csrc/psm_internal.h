@@ -264,7 +264,10 @@ struct psm_dist {
     psm_dist_transport tr = {};
     bool connected = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_x = nullptr;
+    // while psm_dist_allgather_i32 waits for its result the caller's lanes go on being served (psm_dist_render_frames sets it)
+    void (*idle_fn)(void*) = nullptr;
+    void* idle_user = nullptr;
     int rank = 0, world = 1;
     int tile_rank = 0, tile_world = 1;  // the tile geometry gathers use: (rank, world) unless psm_dist_emulate_tile changed it
     psm::BandMap bands;                 // the dealing of the bands (psm_dist_set_band_weights); default round-robin over tile_world
