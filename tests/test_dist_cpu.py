@@ -273,10 +273,10 @@ def test_bench_gpus2_starts_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                          capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("bench.py dry run")]
-    assert len(lines) == 2
-    assert {ln.split("rank ")[1].split(" ")[0] for ln in lines} == {"0", "1"}
-    assert all(ln.endswith("= 2") for ln in lines)
+    import re
+    # (the ranks share this process's stdout: two lines written at the same moment can arrive as one)
+    seen = re.findall(r"bench\.py dry run: rank (\d+) of (\d+) reached its communicator; all-reduce over the group = (\d+)", out.stdout)
+    assert sorted(seen) == [("0", "2", "2"), ("1", "2", "2")], out.stdout[-1000:]
 
 
 def test_bench_under_the_drivers_launcher_command():
@@ -287,17 +287,21 @@ def test_bench_under_the_drivers_launcher_command():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
-                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    for attempt in range(3):   # (the port is free when it is picked, not necessarily when the launcher binds it: another try then)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                             env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        if out.returncode == 0 or "address already in use" not in (out.stderr + out.stdout).lower():
+            break
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("bench.py dry run")]
-    assert len(lines) == 2 and {ln.split("rank ")[1].split(" ")[0] for ln in lines} == {"0", "1"}
-    assert all(ln.endswith("= 2") for ln in lines)
+    import re
+    # (the ranks share the launcher's stdout: two lines written at the same moment can arrive as one)
+    seen = re.findall(r"bench\.py dry run: rank (\d+) of (\d+) reached its communicator; all-reduce over the group = (\d+)", out.stdout)
+    assert sorted(seen) == [("0", "2", "2"), ("1", "2", "2")], out.stdout[-1000:]
 
 
 def test_native_decide_equals_python_protocol():
