@@ -792,6 +792,18 @@ def test_gltf_scene_from_file_to_image(psm, ctx, oracle, scenes):
     assert ref[..., :3].max() > 0.05
     np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
     assert np.array_equal(img[..., 3], ref[..., 3])
+    # which way up: row 0 of snapHdr() is the picture's BOTTOM row (camera.comp:61: texel row 0 is NDC y = -1; the reference's
+    # HdrImage alike) -- the camera looks down on the court from above, so the last rows are sky and the first are floor -- and a
+    # PFM file stores its rows bottom to top: write_pfm writes them as they come (it used to flip them: upside-down snapshots)
+    sky = np.float32([0.5, 0.7, 1.0])
+    np.testing.assert_allclose(img[-1, :, :3], np.broadcast_to(sky, (w, 3)), rtol=1e-5)
+    assert np.abs(img[0, :, :3] - sky).max(-1).min() > 0.05
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        psm.write_pfm(os.path.join(d, "s.pfm"), img)
+        raw = open(os.path.join(d, "s.pfm"), "rb").read()
+        body = np.frombuffer(raw[raw.index(b"-1.0\n") + 5:], "<f4").reshape(h, w, 3)
+        assert np.array_equal(body[0], img[0, :, :3]) and np.array_equal(psm.read_pfm(os.path.join(d, "s.pfm")), img[..., :3])
     rt.close()
     th.close()
 
