@@ -196,19 +196,22 @@ def _worker_parked(rank, world, port, w, h, seeds, rows, out_path):
     comm.close()
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_parking_protocol_equals_unsharded(tmp_path, oracle, scenes):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("rows", [((0, 2), (2, 30)), ((0, 1), (1, 2), (2, 5), (5, 9), (9, 14), (14, 20), (20, 26), (26, 30))],
+                         ids=["world2", "world8"])
+def test_two_rank_parking_protocol_equals_unsharded(tmp_path, oracle, scenes, rows):
     """The free-running sharded protocol (lanes park on their LOCAL count, dist.decide_sharded applies the stop rule
-    to the GLOBAL one): a rank whose tile dies early has to catch up and keep drawing rand() in step."""
+    to the GLOBAL one): a rank whose tile dies early has to catch up and keep drawing rand() in step. With two ranks, and
+    with the eight of the driver's largest run (gloo; strips of one to six rows: several ranks park rounds before the frame ends)."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     w, h, seeds = 36, 30, (5, 977)
-    rows = ((0, 2), (2, h))  # rank 0 owns two rows: its local count drops below 32 rounds before the frame ends
+    world = len(rows)   # (world 2: rank 0 owns two rows: its local count drops below 32 rounds before the frame ends)
     out = str(tmp_path / "parked.npy")
-    mp.spawn(_worker_parked, args=(2, port, w, h, seeds, rows, out), nprocs=2, join=True)
+    mp.spawn(_worker_parked, args=(world, port, w, h, seeds, rows, out), nprocs=world, join=True)
     merged = np.load(out)
     meta = np.load(out + ".meta.npy")
     pdist = importlib.import_module("prismarine-core_amd.dist")
