@@ -431,14 +431,28 @@ int psm_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d) {
     return rc;
 }
 
+// the optimisation matrix of the next build on the device (NULL: identity). A frame loop rebuilds with the same matrix every
+// time: the 10-us copy in front of the rebuild is made only when the matrix has changed -- and then behind a synchronisation,
+// because the copy reads the hierarchy's own host copy, which an earlier copy still in flight must not see overwritten.
+static int bvh_upload_opt(psm_bvh* b, const double* opt) {
+    psm_ctx* c = b->ctx;
+    static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const double* want = opt ? opt : ident;
+    if (b->opt_uploaded && memcmp(b->opt_host, want, sizeof(b->opt_host)) == 0) return PSM_OK;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    b->opt_uploaded = false;
+    memcpy(b->opt_host, want, sizeof(b->opt_host));
+    PSM_HIP(c, hipMemcpyAsync(b->d_opt, b->opt_host, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    b->opt_uploaded = true;
+    return PSM_OK;
+}
+
 int psm_bvh_stage_bounds(psm_bvh* b, const double* opt) {
     if (!b) return PSM_ERR_INVALID;
     psm_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);
     if (b->tri_count == 0) return set_err(c, PSM_ERR_STATE, "build: no triangles");
-    static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    PSM_HIP(c, hipMemcpyAsync(b->d_opt, opt ? opt : ident, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (opt) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    { int rc = bvh_upload_opt(b, opt); if (rc != PSM_OK) return rc; }
     b->built = false;  // a new build has begun: the node records of the last one can no longer be produced (psm_bvh_download)
     int rc = launch_bvh_bounds(b);
     if (rc == PSM_OK) b->bounds_done = true;
@@ -525,9 +539,7 @@ int psm_bvh_build(psm_bvh* b, const double* opt) {
         return rc;
     }
     (void)hipSetDevice(c->device);
-    static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    PSM_HIP(c, hipMemcpyAsync(b->d_opt, opt ? opt : ident, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (opt) PSM_HIP(c, hipStreamSynchronize(c->stream));  // the caller's matrix may be a temporary
+    { int rc = bvh_upload_opt(b, opt); if (rc != PSM_OK) return rc; }
     if (!b->build_graph && bvh_capture_graph(b) != PSM_OK) {  // no graph on this runtime / stream: plain launches from now on
         b->use_graph = false;
         return bvh_build_plain(b, opt);

@@ -175,6 +175,8 @@ struct psm_bvh {
     // [25] root link, [26..33] bounds floats after pad
     uint32_t* d_small = nullptr;
     double* d_opt = nullptr;      // optimisation matrix (16 doubles)
+    double opt_host[16] = {};     // ... as last uploaded (a rebuild with the same matrix skips the 10-us copy in front of it)
+    bool opt_uploaded = false;
     uint4* d_seg = nullptr;       // segment tree of sortable-key boxes, levels concatenated
     std::vector<size_t> seg_off;  // level offsets (entries)
     int32_t* d_sorted_tri = nullptr;
