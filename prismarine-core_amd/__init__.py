@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("PSM_HIP_LIB") or os.path.join(_HERE, "libpsm_hip.so")
 EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_copy_bandwidth", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
-    "psm_sort_u64_u32", "psm_sort_u64_u32_dev", "psm_sort_set_algorithm",
+    "psm_sort_u64_u32", "psm_sort_u64_u32_dev", "psm_sort_set_algorithm", "psm_sort_get_algorithm",
     "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
@@ -224,8 +224,15 @@ class RadixSort:
         self.ctx = ctx
 
     def setAlgorithm(self, algorithm):
-        """0: histogram / scan / scatter kernels per pass (default); 1: one-sweep histograms + look-back scatter."""
+        """2 (default): hybrid -- two global passes over the top sixteen key bits, the rest in LDS; 0: histogram / scan /
+        scatter kernels for all eight passes; 1: one-sweep histograms + look-back scatter."""
         self.ctx.check(lib().psm_sort_set_algorithm(self.ctx._h, C.c_int(algorithm)), "psm_sort_set_algorithm")
+
+    def getAlgorithm(self):
+        """(asked, effective): they differ once a hybrid sort has overflowed a chunk and the context fell back to 0."""
+        a, e = C.c_int(0), C.c_int(0)
+        self.ctx.check(lib().psm_sort_get_algorithm(self.ctx._h, C.byref(a), C.byref(e)), "psm_sort_get_algorithm")
+        return a.value, e.value
 
     def sort(self, keys_handle, vals_handle, size=1, descending=0):
         # `descending` is accepted and ignored like the reference's shaders do (radix/includes.glsl:50-55)

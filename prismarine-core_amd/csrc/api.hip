@@ -119,6 +119,12 @@ static int ctx_create(int device, void* ext_stream, bool use_ext, psm_ctx** out)
         delete c;
         return PSM_ERR_HIP;
     }
+    if (const char* t = std::getenv("PSM_SORT_TUNE")) {   // study knob (tools/sort_bench.py): "S_small,S_large,threads" of radix_local
+        unsigned a = 0, b = 0, th = 0;
+        if (std::sscanf(t, "%u,%u,%u", &a, &b, &th) == 3 && a >= 64 && a <= 4096 && b >= 64 && b <= 4096 && (th == 256 || th == 512 || th == 1024)) {
+            c->sort_hybrid_s_small = a; c->sort_hybrid_s_large = b; c->sort_hybrid_threads = th;
+        }
+    }
     *out = c;
     return PSM_OK;
 }
@@ -134,6 +140,7 @@ int psm_ctx_destroy(psm_ctx* c) {
     dev_free(c->sort_keys_tmp);
     dev_free(c->sort_vals_tmp);
     dev_free(c->sort_hist);
+    if (c->sort_overflow) (void)hipHostFree(c->sort_overflow);
     dev_free(c->d_counters);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -237,8 +244,19 @@ int psm_buf_ptr(psm_ctx* c, uint32_t h, void** p, size_t* bytes) {
 
 // ---- sort -----------------------------------------------------------------------------------------
 int psm_sort_set_algorithm(psm_ctx* c, int algorithm) {
-    if (!c || algorithm < 0 || algorithm > 1) return PSM_ERR_INVALID;
+    if (!c || algorithm < 0 || algorithm > 2) return PSM_ERR_INVALID;
     c->sort_algorithm = algorithm;
+    c->sort_demoted = false;   // asking for the hybrid sort again gives it another chance
+    if (c->sort_overflow) {
+        (void)hipStreamSynchronize(c->stream);
+        *c->sort_overflow = 0u;
+    }
+    return PSM_OK;
+}
+int psm_sort_get_algorithm(psm_ctx* c, int* asked, int* effective) {
+    if (!c) return PSM_ERR_INVALID;
+    if (asked) *asked = c->sort_algorithm;
+    if (effective) *effective = sort_effective_algorithm(c);
     return PSM_OK;
 }
 int psm_sort_u64_u32_dev(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n) {
@@ -470,7 +488,7 @@ int psm_bvh_stage_sort(psm_bvh* b) {
     if (!b) return PSM_ERR_INVALID;
     (void)hipSetDevice(b->ctx->device);
     if (!b->morton_done) return set_err(b->ctx, PSM_ERR_STATE, "sort before morton");
-    int rc = launch_sort(b->ctx, b->d_keys, b->d_idx, b->tri_count, b->d_small + SM_COUNT);
+    int rc = launch_sort(b->ctx, b->d_keys, b->d_idx, b->tri_count, b->d_small + SM_COUNT, 63);   // Morton codes: 3 x 21 bits
     if (rc == PSM_OK) b->sort_done = true;
     return rc;
 }
@@ -507,7 +525,7 @@ static int bvh_capture_graph(psm_bvh* b) {
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return PSM_ERR_HIP; }
     rc = launch_bvh_bounds(b);
     if (rc == PSM_OK) rc = launch_bvh_morton(b);
-    if (rc == PSM_OK) rc = launch_sort(c, b->d_keys, b->d_idx, b->tri_count, b->d_small + SM_COUNT);
+    if (rc == PSM_OK) rc = launch_sort(c, b->d_keys, b->d_idx, b->tri_count, b->d_small + SM_COUNT, 63);
     if (rc == PSM_OK) rc = launch_bvh_emit(b);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(c->stream, &g);
@@ -526,7 +544,8 @@ int psm_bvh_build(psm_bvh* b, const double* opt) {
     if (!b) return PSM_ERR_INVALID;
     psm_ctx* c = b->ctx;
     // The graph belongs to (triangle count, sort algorithm, generation of the context's sort buffers).
-    if (b->graph_tris != b->tri_count || b->graph_algo != c->sort_algorithm || b->graph_sort_gen != c->sort_gen) {
+    const int algo = sort_effective_algorithm(c);   // (a hybrid sort that overflowed has fallen back to the eight passes: another graph)
+    if (b->graph_tris != b->tri_count || b->graph_algo != algo || b->graph_sort_gen != c->sort_gen) {
         bvh_drop_graph(b);
         b->plain_builds = 0;
     }
@@ -535,7 +554,7 @@ int psm_bvh_build(psm_bvh* b, const double* opt) {
     if (!b->use_graph || c->timing == 1 || b->tri_count == 0 || b->plain_builds == 0) {
         int rc = bvh_build_plain(b, opt);
         b->plain_builds = (rc == PSM_OK) ? b->plain_builds + 1 : 0;
-        b->graph_tris = b->tri_count, b->graph_algo = c->sort_algorithm, b->graph_sort_gen = c->sort_gen;
+        b->graph_tris = b->tri_count, b->graph_algo = algo, b->graph_sort_gen = c->sort_gen;
         return rc;
     }
     (void)hipSetDevice(c->device);

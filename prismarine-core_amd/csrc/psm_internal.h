@@ -138,7 +138,10 @@ struct psm_ctx {
     uint32_t* sort_hist = nullptr;
     size_t sort_cap = 0, sort_hist_cap = 0;
     uint32_t sort_gen = 0;              // bumped whenever a sort buffer is reallocated (captured build graphs hold the pointers)
-    int sort_algorithm = 0;             // 0: histogram / scan / scatter kernels per pass (default: measured faster); 1: one-sweep
+    int sort_algorithm = 2;             // 2 (default): hybrid -- two global passes over the top sixteen key bits, the rest in LDS; 0: histogram / scan / scatter kernels for all eight passes; 1: one-sweep
+    uint32_t* sort_overflow = nullptr;  // pinned host word a hybrid sort raises when a chunk did not fit LDS (sorted through global memory: correct, slow)
+    bool sort_demoted = false;          // ... seen raised: hybrid sorts of this context run as algorithm 0 from then on (psm_sort_set_algorithm clears it)
+    uint32_t sort_hybrid_s_small = 1024, sort_hybrid_s_large = 2048, sort_hybrid_threads = 1024;  // radix_local's stretch per workgroup and its width (psm_sort_tune)
     uint32_t* sort_error_word = nullptr; // device word the look-back raises on a spin timeout
 };
 
@@ -298,7 +301,9 @@ struct TimedScope {
 };
 
 // kernels (launch wrappers) ------------------------------------------------------------------------
-int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n);
+// key_bits: the key bits that can be set at all (64; 63 for Morton codes) -- what the hybrid sort's global passes split by
+int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n, int key_bits = 64);
+int sort_effective_algorithm(psm_ctx* c);
 int sort_check(psm_ctx* c);
 int sort_reserve(psm_ctx* c, size_t n_max);
 int launch_bvh_bounds(psm_bvh* b);

@@ -63,6 +63,33 @@ __global__ __launch_bounds__(256) void radix_hist_all(const uint64_t* __restrict
     }
 }
 
+// Stable ranks of one wave round (64 keys, one per lane): r = keys of this wave with the same digit in earlier rounds or in
+// lower lanes. `row`: the wave's own 256 digit counts in LDS, updated by the lowest lane of each group of equal digits.
+// Match-any by eight ballots; per bit the mask of lanes that agree with this lane is ~(ballot ^ s), s = the lane's bit spread
+// over a word, so a bit costs v_bfe_i32, v_cmp and one three-input v_bitop3_b32 per mask half: four instructions, by builtins (hipcc made
+// eleven of `peers &= bit ? m : ~m` and six of the same thing written with xor and and-not); `before` is v_mbcnt of the final mask. The counts are read and
+// written as LDS (address space 3) -- through a generic `volatile` pointer hipcc emitted flat_load / flat_store with sc0 sc1
+// and a full wait each (round 5: 8 of them per tile in radix_scatter).
+template <typename CT>
+PSM_D uint32_t wave_rank(uint32_t d, bool valid, CT* row) {
+    typedef __attribute__((address_space(3))) volatile CT lds_ct;
+    lds_ct* wc = (lds_ct*)row;
+    const uint64_t vm = __ballot(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);   // the lane's bit b, spread over the word
+        const uint64_t m = __builtin_amdgcn_uicmp(s, 0u, 33);                // ballot(s != 0) (33: ICMP_NE)
+        plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, s, 0x90);        // plo & ~(m ^ s)
+        phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), s, 0x90);
+    }
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    const uint32_t cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+    const uint32_t old = wc[d];
+    if (valid && before == 0u) wc[d] = (CT)(old + cnt);
+    return old + before;
+}
+
 template <int ITEMS>
 __global__ __launch_bounds__(256) void radix_onesweep(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                       uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -88,7 +115,6 @@ __global__ __launch_bounds__(256) void radix_onesweep(const uint64_t* __restrict
     if (base >= n) return;  // the launch is sized for n_max; tiles past the device-side count have nothing to do
     const uint32_t w = tid >> 6;
     const int l = lane_id();
-    const uint64_t lt = lanemask_lt();
 
     uint64_t k[ITEMS];
     uint32_t v[ITEMS], r[ITEMS];
@@ -99,24 +125,10 @@ __global__ __launch_bounds__(256) void radix_onesweep(const uint64_t* __restrict
         k[i] = valid ? kin[idx] : ~0ull;
         v[i] = valid ? vin[idx] : 0u;
     }
-    volatile uint32_t* wc = &wcount[w][0];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         uint32_t idx = base + w * (64 * ITEMS) + i * 64 + l;
-        bool valid = idx < n;
-        uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            bool bit = (d >> b) & 1u;
-            uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        uint32_t before = (uint32_t)__popcll(peers & lt);
-        uint32_t cnt = (uint32_t)__popcll(peers);
-        uint32_t old = valid ? wc[d] : 0u;
-        if (valid && before == 0) wc[d] = old + cnt;
-        r[i] = old + before;
+        r[i] = wave_rank((uint32_t)(k[i] >> shift) & 255u, idx < n, &wcount[w][0]);
     }
     __syncthreads();
     {   // thread tid owns digit tid
@@ -257,7 +269,6 @@ __global__ __launch_bounds__(THREADS) void radix_scatter(const uint64_t* __restr
     if (base >= n) return;
     uint32_t w = tid >> 6;
     int l = lane_id();
-    uint64_t lt = lanemask_lt();
     for (uint32_t q = tid; q < NW * 256u; q += THREADS) (&wcount[0][0])[q] = 0;
     __syncthreads();
 
@@ -270,24 +281,10 @@ __global__ __launch_bounds__(THREADS) void radix_scatter(const uint64_t* __restr
         k[i] = valid ? kin[idx] : ~0ull;
         v[i] = valid ? vin[idx] : 0u;
     }
-    volatile uint32_t* wc = &wcount[w][0];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         uint32_t idx = base + w * (64 * ITEMS) + i * 64 + l;
-        bool valid = idx < n;
-        uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            bool bit = (d >> b) & 1u;
-            uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        uint32_t before = (uint32_t)__popcll(peers & lt);
-        uint32_t cnt = (uint32_t)__popcll(peers);
-        uint32_t old = valid ? wc[d] : 0u;
-        if (valid && before == 0) wc[d] = old + cnt;
-        r[i] = old + before;
+        r[i] = wave_rank((uint32_t)(k[i] >> shift) & 255u, idx < n, &wcount[w][0]);
     }
     __syncthreads();
     {   // thread tid < 256 owns digit tid (the other threads of a wider workgroup only take part in the scans)
@@ -333,6 +330,296 @@ __global__ __launch_bounds__(THREADS) void radix_scatter(const uint64_t* __restr
     }
 }
 
+// ---- the hybrid sort (default, psm_sort_set_algorithm(ctx, 2)): two global passes, the rest in LDS ------------------------
+// The LSD sort above moves every key through HBM eight times and takes 24 dependent launches (0.12 ms for C3's 262 267 keys,
+// all of it launch latency; 0.73 ms for C5's 10 M, 0.34 of the HBM peak of its 200 B/key). The hybrid sort moves a key three
+// times in seven launches:
+//   1. the LSD passes of the TOP sixteen key bits first -- digit [pshift, pshift + 8) then [pshift + 8, pshift + 16), with the
+//      three kernels above, stable on the input order: the array is then partitioned into up to 65 536 bins by its top bits,
+//      bins in ascending order, input order inside a bin;
+//   2. radix_local: workgroup c takes the bins that START in [c S, (c + 1) S) -- whole bins, so chunks are ordered among
+//      themselves -- and sorts them by every remaining digit in LDS (stable LSD passes over the digits in which the chunk's
+//      keys differ at all, wave64 match-any ranks as in radix_scatter), then writes the chunk back where it lay.
+// A chunk is at most S keys plus the tail of its last bin; it fits the workgroup's LDS (CAP keys) as long as no bin is longer
+// than CAP - S. Morton codes of meshes spread well over sixteen bits (C3: longest bin 1 876 of 262 267 keys, C5: 723 of 10 M,
+// bits 47..62); for a bin that does not, the workgroup sorts its chunk through global memory on its own (local_slow: correct
+// for every input, slow) and raises `overflow`, a pinned host word launch_sort looks at: a context whose keys overflowed
+// goes back to the eight-pass sort for good. The result is the stable ascending order -- the same bits as the LSD sorts.
+//
+// In place: a workgroup reads the window [c S - 1, c S + CAP) of the keys -- beyond its own chunk on both sides, to find the
+// bin boundaries -- while its neighbours may already be writing their sorted chunks into the same array. What it looks at in
+// a neighbour's keys is the bin they belong to (key >> pshift), and sorting a chunk never moves a key out of the positions of
+// its bin: whichever version of a neighbour's key a load returns, its bin is the same (pshift >= 32: the bin bits lie in the
+// key's high dword, so even a load torn between two 32-bit halves would agree).
+
+PSM_D uint32_t key_bin(uint64_t k, int pshift) { return pshift >= 64 ? 0u : (uint32_t)(k >> pshift); }
+
+template <int CAP, int THREADS>
+struct LocalLds {
+    static constexpr int NW = THREADS / 64;
+    uint64_t sk[CAP];
+    uint32_t sv[CAP];
+    uint16_t wcount[NW][256];   // per wave and digit: count, then exclusive prefix over the waves (a tile has at most CAP < 65 536 keys)
+    uint32_t tpart[256];        // exclusive digit prefix inside each group of 64 digits
+    uint32_t wtot[4];           // totals of the four groups
+    uint32_t gbase[256];        // local_slow: where the next key of each digit goes
+    uint32_t diff[2];
+    uint32_t lo, hi;
+};
+
+// the chunk does not fit LDS: stable LSD passes over [gs, gs + m) through global memory, this workgroup alone, the scratch
+// arrays' own [gs, gs + m) as the other buffer
+template <int CAP, int THREADS>
+PSM_D void local_slow(LocalLds<CAP, THREADS>& S, uint64_t* keys, uint32_t* vals, uint64_t* altk, uint32_t* altv, uint32_t gs, uint32_t m) {
+    constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const int l = lane_id();
+    {
+        const uint64_t k0 = keys[gs];
+        uint64_t dif = 0;
+        for (uint32_t j = tid; j < m; j += THREADS) dif |= keys[gs + j] ^ k0;
+        if (dif) { atomicOr(&S.diff[0], (uint32_t)dif); atomicOr(&S.diff[1], (uint32_t)(dif >> 32)); }
+    }
+    __syncthreads();
+    const uint64_t diff = ((uint64_t)S.diff[1] << 32) | S.diff[0];
+    uint64_t* sk = keys; uint32_t* sv = vals;
+    uint64_t* dk = altk; uint32_t* dv = altv;
+    for (int p = 0; p < 8; p++) {
+        const int shift = 8 * p;
+        if (((diff >> shift) & 255ull) == 0ull) continue;
+        if (tid < 256) S.gbase[tid] = 0;
+        __syncthreads();
+        for (uint32_t j = tid; j < m; j += THREADS) atomicAdd(&S.gbase[(uint32_t)(sk[gs + j] >> shift) & 255u], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 256 digit counts
+            uint32_t c = tid < 256 ? S.gbase[tid] : 0u, inc = 0;
+            if (tid < 256) {
+                inc = wave_scan_incl(c);
+                if (l == 63) S.wtot[w] = inc;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t pre = 0;
+                for (uint32_t q = 0; q < w; q++) pre += S.wtot[q];
+                S.gbase[tid] = pre + inc - c;
+            }
+            __syncthreads();
+        }
+        for (uint32_t t0 = 0; t0 < m; t0 += CAP) {
+            const uint32_t tileN = min((uint32_t)CAP, m - t0);
+            uint64_t k[ITEMS];
+            uint32_t v[ITEMS], r[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t q = w * (64 * ITEMS) + i * 64 + l;
+                const bool valid = q < tileN;
+                k[i] = valid ? sk[gs + t0 + q] : 0ull;
+                v[i] = valid ? sv[gs + t0 + q] : 0u;
+            }
+            for (int j = l; j < 256; j += 64) S.wcount[w][j] = 0;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t q = w * (64 * ITEMS) + i * 64 + l;
+                r[i] = wave_rank((uint32_t)(k[i] >> shift) & 255u, q < tileN, &S.wcount[w][0]);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    const uint32_t t = S.wcount[q][tid];
+                    S.wcount[q][tid] = (uint16_t)run;
+                    run += t;
+                }
+                const uint32_t base = S.gbase[tid];
+                S.tpart[tid] = base;
+                S.gbase[tid] = base + run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t q = w * (64 * ITEMS) + i * 64 + l;
+                if (q < tileN) {
+                    const uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
+                    const uint32_t pos = gs + S.tpart[d] + S.wcount[w][d] + r[i];
+                    dk[pos] = k[i];
+                    dv[pos] = v[i];
+                }
+            }
+            __syncthreads();
+        }
+        // the next pass reads what other waves of this workgroup have just written: stores out to L2, no stale line in L1
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+        { uint64_t* t = sk; sk = dk; dk = t; }
+        { uint32_t* t = sv; sv = dv; dv = t; }
+    }
+    if (sk != keys) {
+        for (uint32_t j = tid; j < m; j += THREADS) { keys[gs + j] = sk[gs + j]; vals[gs + j] = sv[gs + j]; }
+    }
+}
+
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_local(uint64_t* keys, uint32_t* vals, uint64_t* altk, uint32_t* altv,
+                                                       uint32_t n_max, const uint32_t* __restrict__ d_n, uint32_t S, int pshift,
+                                                       uint32_t* overflow) {
+    constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
+    static_assert(CAP % THREADS == 0 && THREADS % 64 == 0 && THREADS >= 256 && CAP < 65536, "tile shape");
+    __shared__ LocalLds<CAP, THREADS> L;
+    const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
+    const uint32_t a = blockIdx.x * S;
+    if (a >= n) return;
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const int l = lane_id();
+    const uint32_t winN = min((uint32_t)CAP, n - a);   // the window: keys [a, a + winN)
+    // ... of which the first S + 1024 are loaded at once and the rest only when the chunk's last bin turns out to be longer than
+    // 1024 keys (C5: never; the second half of the window would be 8 B/key more of HBM reads for nothing)
+    const uint32_t win1 = min(winN, S + 1024u);
+    if (tid == 0) { L.lo = 0xFFFFFFFFu; L.hi = 0xFFFFFFFFu; L.diff[0] = 0; L.diff[1] = 0; }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const uint32_t j = i * THREADS + tid;
+        if (j < win1) L.sk[j] = keys[a + j];
+    }
+    const uint32_t bin_before = a > 0 ? key_bin(keys[a - 1], pshift) : 0u;
+    __syncthreads();
+    // the chunk: from the first bin boundary at or after a to the first one at or after a + S (a boundary: position 0, or a key
+    // whose bin differs from its predecessor's)
+    {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const uint32_t j = i * THREADS + tid;
+            if (j < win1) {
+                const bool edge = (a + j == 0u) || key_bin(L.sk[j], pshift) != (j == 0u ? bin_before : key_bin(L.sk[j - 1], pshift));
+                if (edge) {
+                    lo = min(lo, j);
+                    if (j >= S) hi = min(hi, j);
+                }
+            }
+        }
+        if (lo != 0xFFFFFFFFu) atomicMin(&L.lo, lo);
+        if (hi != 0xFFFFFFFFu) atomicMin(&L.hi, hi);
+    }
+    __syncthreads();
+    if (L.hi == 0xFFFFFFFFu && win1 < winN && L.lo < S) {   // (the same for every thread) the rest of the window
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const uint32_t j = i * THREADS + tid;
+            if (j >= win1 && j < winN) L.sk[j] = keys[a + j];
+        }
+        __syncthreads();
+        uint32_t hi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const uint32_t j = i * THREADS + tid;
+            if (j >= win1 && j < winN && key_bin(L.sk[j], pshift) != key_bin(L.sk[j - 1], pshift)) hi = min(hi, j);
+        }
+        if (hi != 0xFFFFFFFFu) atomicMin(&L.hi, hi);
+        __syncthreads();
+    }
+    const uint32_t js = L.lo;
+    if (js == 0xFFFFFFFFu || js >= S) return;   // no bin starts in [a, a + S): an earlier workgroup's chunk covers this stretch
+    uint32_t je = L.hi;
+    if (je == 0xFFFFFFFFu && a + winN >= n) je = winN;   // the array ends inside the window
+    if (je == 0xFFFFFFFFu) {
+        // the chunk's last bin runs past the window: its end is the first key of a later bin (the keys are ordered by bin)
+        const uint32_t bin = key_bin(L.sk[winN - 1], pshift);
+        uint32_t lo = a + winN, hi = n;   // first position with a later bin lies in [lo, hi]
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (key_bin(keys[mid], pshift) > bin) hi = mid; else lo = mid + 1u;
+        }
+        const uint32_t gs = a + js, m = lo - gs;
+        __syncthreads();
+        local_slow<CAP, THREADS>(L, keys, vals, altk, altv, gs, m);
+        if (tid == 0 && overflow) __hip_atomic_fetch_add(overflow, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const uint32_t size = je - js, gs = a + js;
+    // wave w works on slots [w per, (w + 1) per) of the chunk, 64 per round
+    const uint32_t rounds = (size + NW * 64u - 1u) / (NW * 64u), per = rounds * 64u;
+    uint64_t k[ITEMS];
+    uint32_t v[ITEMS], r[ITEMS];
+    uint64_t dif = 0;
+    const uint64_t k0 = L.sk[js];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const uint32_t q = w * per + i * 64 + l;
+        const bool valid = (uint32_t)i < rounds && q < size;
+        k[i] = valid ? L.sk[js + q] : k0;
+        v[i] = valid ? vals[gs + q] : 0u;
+        dif |= k[i] ^ k0;
+    }
+    {
+        uint32_t dl = (uint32_t)dif, dh = (uint32_t)(dif >> 32);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { dl |= __shfl_xor(dl, d, 64); dh |= __shfl_xor(dh, d, 64); }
+        if (l == 0 && (dl | dh)) { atomicOr(&L.diff[0], dl); atomicOr(&L.diff[1], dh); }
+    }
+    __syncthreads();
+    const uint64_t diff = ((uint64_t)L.diff[1] << 32) | L.diff[0];
+    if (diff == 0ull) return;   // one key value: the chunk is in order as it lies
+    for (int p = 0; p < 8; p++) {
+        const int shift = 8 * p;
+        if (((diff >> shift) & 255ull) == 0ull) continue;   // (the same for the whole workgroup)
+        for (int j = l; j < 256; j += 64) L.wcount[w][j] = 0;   // the wave's own row: nobody else touches it before the barrier
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            if ((uint32_t)i < rounds) {
+                const uint32_t q = w * per + i * 64 + l;
+                r[i] = wave_rank((uint32_t)(k[i] >> shift) & 255u, q < size, &L.wcount[w][0]);
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {   // thread d: exclusive prefix of digit d over the waves, then over the digits of its group of 64
+            uint32_t run = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const uint32_t t = L.wcount[q][tid];
+                L.wcount[q][tid] = (uint16_t)run;
+                run += t;
+            }
+            const uint32_t inc = wave_scan_incl(run);
+            L.tpart[tid] = inc - run;
+            if (l == 63) L.wtot[w] = inc;
+        }
+        __syncthreads();
+        {
+            const uint32_t t0 = L.wtot[0], t1 = t0 + L.wtot[1], t2 = t1 + L.wtot[2];
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                if ((uint32_t)i < rounds) {
+                    const uint32_t q = w * per + i * 64 + l;
+                    if (q < size) {
+                        const uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
+                        const uint32_t g = d >> 6;
+                        const uint32_t pos = (g == 0u ? 0u : g == 1u ? t0 : g == 2u ? t1 : t2) + L.tpart[d] + L.wcount[w][d] + r[i];
+                        L.sk[pos] = k[i];
+                        L.sv[pos] = v[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if ((diff >> shift) >> 8 == 0ull) break;   // the last pass: written out below, straight from LDS
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            if ((uint32_t)i < rounds) {
+                const uint32_t q = w * per + i * 64 + l;
+                if (q < size) { k[i] = L.sk[q]; v[i] = L.sv[q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const uint32_t q = i * THREADS + tid;
+        if (q < size) { keys[gs + q] = L.sk[q]; vals[gs + q] = L.sv[q]; }
+    }
+}
+
 // ping-pong buffers and histogram / status words of the sort, grown on demand. Every growth bumps sort_gen: a captured
 // build graph (psm_bvh_build) holds these pointers and is re-captured when the generation has moved on.
 static int sort_buffers(psm_ctx* c, size_t n_max, size_t E) {
@@ -355,6 +642,12 @@ static int sort_buffers(psm_ctx* c, size_t n_max, size_t E) {
     return PSM_OK;
 }
 
+// the algorithm a sort of this context runs: the one asked for (psm_sort_set_algorithm), except that a context whose keys have
+// overflowed a hybrid chunk (radix_local's slow path raised the pinned word) sorts with the eight-pass kernels from then on
+int sort_effective_algorithm(psm_ctx* c) {
+    if (c->sort_algorithm == 2 && !c->sort_demoted && c->sort_overflow && *(volatile uint32_t*)c->sort_overflow != 0u) c->sort_demoted = true;
+    return (c->sort_algorithm == 2 && c->sort_demoted) ? 0 : c->sort_algorithm;
+}
 static bool sort_uses_passes(const psm_ctx* c, size_t n_max) { return c->sort_algorithm != 1 || n_max >= (1u << 30); }
 // keys per tile of the three-kernel pass, measured on MI355X (round 3, tools/sort_bench.py, profiles/r03_sort_bench.txt):
 // the wider the workgroup over a tile the better -- 1024 threads x 4 keys against round 2's 256 x 16 over the same 4096
@@ -378,19 +671,25 @@ static size_t sort_words(const psm_ctx* c, size_t n_max) {
 int sort_reserve(psm_ctx* c, size_t n_max) {
     if (n_max == 0) return PSM_OK;
     if (n_max > 0xFFFFFFF0ull) return set_err(c, PSM_ERR_CAPACITY, "sort: n exceeds 32-bit indexing");
+    if (c->sort_algorithm == 2 && !c->sort_overflow) {   // the hybrid sort's pinned overflow word
+        PSM_HIP(c, hipHostMalloc((void**)&c->sort_overflow, sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
+        *c->sort_overflow = 0u;
+    }
     return sort_buffers(c, n_max, sort_words(c, n_max));
 }
 
+// passes [first_shift, first_shift + 8 * count) of the LSD sort, eight bits each, lowest first; the result lies in the caller's
+// buffers after an even number of passes, in the context's scratch buffers after an odd one
 template <int ITEMS, int THREADS>
-static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n) {
+static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n, int first_shift = 0, int count = 8) {
     constexpr uint32_t TILE = THREADS * ITEMS;
     uint32_t numTiles = (uint32_t)((n_max + TILE - 1) / TILE);
     size_t E = (size_t)256 * numTiles + 256;  // per-tile counts + 256 digit totals
     { int rc = sort_buffers(c, n_max, E); if (rc != PSM_OK) return rc; }
     uint64_t* kin = d_keys; uint32_t* vin = d_vals;
     uint64_t* kout = c->sort_keys_tmp; uint32_t* vout = c->sort_vals_tmp;
-    for (int pass = 0; pass < 8; pass++) {  // Radix.hpp:57: 64-bit keys, 8 passes
-        int shift = pass * 8;
+    for (int pass = 0; pass < count; pass++) {  // Radix.hpp:57: 64-bit keys, 8 passes
+        int shift = first_shift + pass * 8;
         radix_hist<ITEMS, THREADS><<<numTiles, THREADS, 0, c->stream>>>(kin, c->sort_hist, numTiles, (uint32_t)n_max, d_n, shift);
         uint32_t* totals = c->sort_hist + (size_t)256 * numTiles;
         if (numTiles > 512u) radix_scan<1024><<<256, 1024, 0, c->stream>>>(c->sort_hist, numTiles, totals);   // (10 M keys: 2442 tiles, 3 strips instead of 10)
@@ -400,6 +699,38 @@ static int sort_passes(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+// The hybrid sort (see radix_local): key_bits = the key bits that can be set at all (64; 63 for Morton codes) -- the two
+// global passes take the sixteen bits below that.
+static int sort_hybrid(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n, int key_bits) {
+    if (!c->sort_overflow) {
+        PSM_HIP(c, hipHostMalloc((void**)&c->sort_overflow, sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
+        *c->sort_overflow = 0u;
+    }
+    constexpr uint32_t CAP = 4096;
+    if (n_max <= CAP) {   // one chunk: no global pass (pshift 64: every key in bin 0)
+        { int rc = sort_buffers(c, n_max, 256); if (rc != PSM_OK) return rc; }
+        radix_local<CAP, 1024><<<1, 1024, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, CAP, 64, nullptr);
+        PSM_HIP(c, hipGetLastError());
+        return PSM_OK;
+    }
+    const int pshift = key_bits - 16;
+    int rc = n_max <= (1u << 19) ? sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n, pshift, 2)
+                                 : sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n, pshift, 2);
+    if (rc != PSM_OK) return rc;
+    // S: the stretch of bin starts a workgroup takes; a chunk fits LDS while no bin is longer than CAP - S. Small sorts take short
+    // stretches: as many workgroups as the chip has CUs matter more there than keys per workgroup
+    const uint32_t S = n_max <= (1u << 19) ? c->sort_hybrid_s_small : c->sort_hybrid_s_large;
+    const uint32_t grid = (uint32_t)((n_max + S - 1) / S);
+    if (c->sort_hybrid_threads == 256)
+        radix_local<CAP, 256><<<grid, 256, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow);
+    else if (c->sort_hybrid_threads == 512)
+        radix_local<CAP, 512><<<grid, 512, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow);
+    else
+        radix_local<CAP, 1024><<<grid, 1024, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }
@@ -431,12 +762,13 @@ static int sort_onesweep(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t 
     return PSM_OK;
 }
 
-int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n) {
+int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, const uint32_t* d_n, int key_bits) {
     if (n_max == 0) return PSM_OK;
     if (n_max > 0xFFFFFFF0ull) return set_err(c, PSM_ERR_CAPACITY, "sort: n exceeds 32-bit indexing");
     TimedScope ts(c, CAT_SORT);
     if (sort_uses_passes(c, n_max)) {  // (the one-sweep status words hold 30-bit counts)
         c->sort_error_word = nullptr;  // no look-back, nothing to time out (and the buffer it pointed into is reused)
+        if (sort_effective_algorithm(c) == 2) return sort_hybrid(c, d_keys, d_vals, n_max, d_n, key_bits);
         if (n_max <= (1u << 19)) return sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n);
         return sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n);
     }

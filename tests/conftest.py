@@ -31,7 +31,15 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
-def ctx(psm):
+def _session_ctx(psm):
     c = psm.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx(psm, _session_ctx):
+    # one context for the session; every test starts with the default sort (a hybrid sort that overflowed in an earlier
+    # test has sent the context back to the eight-pass sort: psm_sort_set_algorithm re-arms it)
+    psm.RadixSort(_session_ctx).setAlgorithm(2)
+    return _session_ctx

@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 C5_FRAME_RAYS = 14_756_576   # S-stress 9 999 616 tris, 3840x2160, seed of the test: rays handed to traverse in one frame
 
 
-@pytest.mark.parametrize("algo", [0, 1], ids=["three-kernel", "onesweep"])
+@pytest.mark.parametrize("algo", [0, 1, 2], ids=["three-kernel", "onesweep", "hybrid"])
 def test_sort_10m_keys_properties(psm, ctx, algo):
-    """C5-scale key count (reference cap: 2 Mi keys, Radix.hpp:34-35), both sort implementations."""
+    """C5-scale key count (reference cap: 2 Mi keys, Radix.hpp:34-35), every sort implementation (the hybrid sort meets a
+    bin of 2.2 M short keys here: the chunk that goes through global memory, at scale)."""
     n = 10_000_019
     rng = np.random.RandomState(5)
     keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
@@ -24,14 +25,36 @@ def test_sort_10m_keys_properties(psm, ctx, algo):
     rs.setAlgorithm(algo)
     try:
         gk, gv = rs.sort_arrays(keys, vals)
+        fell_back = rs.getAlgorithm() == (2, 0)
     finally:
-        rs.setAlgorithm(0)
+        rs.setAlgorithm(2)
+    assert fell_back == (algo == 2)
     assert (gk[1:] >= gk[:-1]).all()                                  # sorted
     ties = gk[1:] == gk[:-1]
     assert (gv[1:][ties] > gv[:-1][ties]).all()                      # stable
     assert np.array_equal(keys[gv], gk)                              # values still point at their keys
     assert int(gv.astype(np.uint64).sum()) == n * (n - 1) // 2       # a permutation
     assert np.bitwise_xor.reduce(gk) == np.bitwise_xor.reduce(keys)  # multiset checksum
+
+
+def test_hybrid_sort_10m_spread_keys_properties(psm, ctx):
+    """10 M keys that spread over the sixteen-bit bins as Morton codes do (and a tenth of them tied): every chunk is sorted
+    in LDS, the context stays on the hybrid sort."""
+    n = 9_999_616
+    rng = np.random.RandomState(6)
+    keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
+    src = rng.randint(0, n, n // 10)
+    keys[rng.randint(0, n, n // 10)] = keys[src]
+    vals = np.arange(n, dtype=np.uint32)
+    rs = psm.RadixSort(ctx)
+    gk, gv = rs.sort_arrays(keys, vals)
+    assert rs.getAlgorithm() == (2, 2)
+    assert (gk[1:] >= gk[:-1]).all()
+    ties = gk[1:] == gk[:-1]
+    assert ties.sum() > 100000 and (gv[1:][ties] > gv[:-1][ties]).all()
+    assert np.array_equal(keys[gv], gk)
+    assert int(gv.astype(np.uint64).sum()) == n * (n - 1) // 2
+    assert np.bitwise_xor.reduce(gk) == np.bitwise_xor.reduce(keys)
 
 
 def _invariants(nodes, n, keys):

@@ -52,11 +52,12 @@ def _scene(scenes, name):
 
 
 # ---------------------------------------------------------------------------- sort
-@pytest.mark.parametrize("algo", [0, 1], ids=["three-kernel", "onesweep"])
-@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 1024, 1025, 4097, 100003, 2 ** 17 + 1, 300007, 2 ** 19 + 3, 2 ** 21 + 77])
+@pytest.mark.parametrize("algo", [0, 1, 2], ids=["three-kernel", "onesweep", "hybrid"])
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 1024, 1025, 4095, 4096, 4097, 100003, 2 ** 17 + 1, 300007, 2 ** 19 + 3, 2 ** 21 + 77])
 def test_sort_matches_oracle(psm, ctx, oracle, n, algo):
-    """Both sort implementations (psm_sort_set_algorithm): one histogram sweep + look-back scatter, and the
-    histogram / scan / scatter kernels per pass."""
+    """Every sort implementation (psm_sort_set_algorithm): the histogram / scan / scatter kernels per pass, one histogram
+    sweep + look-back scatter, and the hybrid sort (two global passes, the rest in LDS; the short keys below all fall
+    into ONE of its sixteen-bit bins, so from 32 k keys on this also runs the chunk that does not fit LDS)."""
     rng = np.random.RandomState(n + 1)
     keys = rng.randint(0, 2 ** 63 - 1, size=n, dtype=np.int64).astype(np.uint64)
     if n > 10:
@@ -68,7 +69,7 @@ def test_sort_matches_oracle(psm, ctx, oracle, n, algo):
     try:
         gk, gv = rs.sort_arrays(keys, vals)
     finally:
-        rs.setAlgorithm(0)
+        rs.setAlgorithm(2)
     ok, ov = oracle.radix_sort(keys, vals.astype(np.int32))
     assert np.array_equal(gk, ok)
     assert np.array_equal(gv, ov.astype(np.uint32))
@@ -85,6 +86,78 @@ def test_sort_all_equal_and_sorted_inputs(psm, ctx):
     k = np.arange(n, dtype=np.uint64)[::-1].copy() << np.uint64(40)
     gk, gv = rs.sort_arrays(k, np.arange(n, dtype=np.uint32))
     assert np.array_equal(gk, np.sort(k)) and np.array_equal(gv, np.arange(n, dtype=np.uint32)[::-1])
+
+
+def _stable(keys, vals):
+    order = np.argsort(keys, kind="stable")
+    return keys[order], vals[order]
+
+
+def test_hybrid_sort_of_morton_codes_stays_hybrid(psm, ctx, oracle, scenes):
+    """The Morton codes of the Sponza-class scene through the generic entry point (bins = key bits 48..63): the longest bin
+    (1 977 keys) fits a chunk, nothing overflows, the context stays on the hybrid sort."""
+    ob = oracle.build_scene(scenes.sponza_like()["tris"])
+    keys = ob["keys_unsorted"]
+    vals = np.arange(keys.size, dtype=np.uint32)[::-1].copy()   # values need not be ascending: stability is by position
+    rs = psm.RadixSort(ctx)
+    gk, gv = rs.sort_arrays(keys, vals)
+    ek, ev = _stable(keys, vals)
+    assert np.array_equal(gk, ek) and np.array_equal(gv, ev)
+    assert np.array_equal(gk, ob["keys"])
+    assert rs.getAlgorithm() == (2, 2)
+
+
+@pytest.mark.parametrize("case", ["bin_of_3072", "bin_of_3073", "bin_spans_three_stretches", "bins_end_on_stretch_ends",
+                                  "all_equal", "two_values", "high_bit_set", "low_digits_only", "sorted", "reversed"])
+def test_hybrid_sort_chunk_edges(psm, ctx, case):
+    """radix_local's chunking (small sorts: stretches of S = 1 024 bin starts, 4 096 keys of LDS): a bin of exactly CAP - S
+    keys still fits, one key more goes through global memory (and sends the context back to the eight passes), a bin over
+    several stretches leaves workgroups without a chunk, bins that end exactly where a stretch ends, keys that differ in one
+    digit only."""
+    rng = np.random.RandomState(11)
+    n = 20000
+    low = rng.randint(0, 2 ** 48, size=n, dtype=np.int64).astype(np.uint64)
+    overflow = False
+    if case in ("bin_of_3072", "bin_of_3073"):
+        big = 3072 if case == "bin_of_3072" else 3073
+        # bins of 1 key up to position 1023, then the big bin starting exactly at 1023 (the last start of stretch 0)
+        bins = np.concatenate([np.arange(1023), np.full(big, 5000), 6000 + rng.randint(0, 3000, n - 1023 - big)])
+        overflow = case == "bin_of_3073"
+    elif case == "bin_spans_three_stretches":
+        bins = np.concatenate([np.arange(900), np.full(3000, 5000), 6000 + np.arange(n - 3900) // 7])
+    elif case == "bins_end_on_stretch_ends":
+        bins = np.arange(n) // 512
+    elif case == "all_equal":
+        bins = np.full(n, 77); low[:] = 12345
+        overflow = True     # one bin of 20 000 keys (nothing to sort in it, as the workgroup finds out: no digit differs)
+    elif case == "two_values":
+        bins = np.full(n, 77); low[:] = rng.randint(0, 2, n).astype(np.uint64) << np.uint64(23)
+        overflow = True
+    elif case == "high_bit_set":
+        bins = rng.randint(0, 65536, n)
+    elif case == "low_digits_only":
+        bins = np.zeros(n, np.int64); low = rng.randint(0, 256, n).astype(np.uint64)
+        overflow = True
+    elif case in ("sorted", "reversed"):
+        bins = np.sort(rng.randint(0, 65536, n)); low = np.sort(low)
+        if case == "reversed":
+            bins = bins[::-1].copy(); low = low[::-1].copy()
+    keys = (bins.astype(np.uint64) << np.uint64(48)) | low
+    if case not in ("sorted", "reversed", "bin_of_3072", "bin_of_3073", "bin_spans_three_stretches", "bins_end_on_stretch_ends"):
+        keys = keys[rng.permutation(n)]
+    elif case in ("bin_of_3072", "bin_of_3073", "bin_spans_three_stretches", "bins_end_on_stretch_ends"):
+        keys = keys[rng.permutation(n)]   # the global passes bring the bins back together, in this layout
+    vals = rng.randint(0, 2 ** 32, size=n, dtype=np.int64).astype(np.uint32)
+    rs = psm.RadixSort(ctx)
+    gk, gv = rs.sort_arrays(keys, vals)
+    ek, ev = _stable(keys, vals)
+    assert np.array_equal(gk, ek) and np.array_equal(gv, ev)
+    assert rs.getAlgorithm() == (2, 0 if overflow else 2)
+    if overflow:   # the context now sorts with the eight passes; asking for the hybrid sort again re-arms it
+        gk, gv = rs.sort_arrays(keys, vals)
+        assert np.array_equal(gk, ek) and np.array_equal(gv, ev)
+        rs.setAlgorithm(2)
+        assert rs.getAlgorithm() == (2, 2)
 
 
 # ---------------------------------------------------------------------------- build
@@ -204,12 +277,13 @@ def test_rebuild_replayed_as_captured_graph_is_bit_exact(psm, ctx, oracle, scene
         th.markDirty()
         th.build()
         _built_equals_oracle(psm, oracle, th, ob)
-    rs.setAlgorithm(1)           # the one-sweep sort: another graph
-    for _ in range(3):
-        th.markDirty()
-        th.build()
-        _built_equals_oracle(psm, oracle, th, ob)
-    rs.setAlgorithm(0)
+    for algo in (1, 0):          # the one-sweep sort, the eight-pass sort: another graph each
+        rs.setAlgorithm(algo)
+        for _ in range(3):
+            th.markDirty()
+            th.build()
+            _built_equals_oracle(psm, oracle, th, ob)
+    rs.setAlgorithm(2)
     th.setBuildGraph(False)
     th.markDirty()
     th.build()
