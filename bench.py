@@ -68,21 +68,13 @@ def parse():
                          "accumulating image in frame order; 1 = one frame after another; 0 (default) = 4 on one GPU, "
                          "12 per GPU on several, with 16 hardware queues (a tile's launches are small and latency-bound: more frames in "
                          "flight fill the chip; measured with --force-dist --emulate-tile R/W, profiles/r04_tile_emulation.txt)")
-    ap.add_argument("--split", type=int, default=1,
-                    help="one GPU: trace every frame with this many Pipelines that own its 8-row bands round-robin and run their "
-                         "bounce rounds independently (psm_lanes_render_split): a part's traversal tail overlaps the other parts' "
-                         "rounds inside the frame; with --lanes 1 this is one frame at a time, the reference's call pattern")
-    ap.add_argument("--group", type=int, default=0,
-                    help="one GPU: the frames in flight form groups of this many that trace every bounce round in ONE launch over all "
-                         "their queues (psm_lanes_render_grouped); --lanes must be a multiple. 0 = the default of the schedule")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous check only: every rank builds its communicator (gloo, no GPU), proves the group works "
                          "with one all-reduce, prints one line and exits")
     ap.add_argument("--diag-clock", action="store_true",
                     help="diagnosis only: a second pass of the timed region with the counting kernels on every lane; reports "
                          "the shader clock the traversal waves ran at (s_memtime / s_memrealtime) and their wave-steps to stderr")
-    ap.add_argument("--trav-refill", default="", help="refill: refill_min,waves_per_cu,min_rays")
-    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive", "refill"],
+    ap.add_argument("--traverse", default="auto", choices=["auto", "whole", "phased", "adaptive"],
                     help="tuning study: traversal kernel schedule (psm_rt_set_traverse_mode); results never depend on it")
     ap.add_argument("--trav-caps", default="96", help="phased: wave-step caps, comma separated")
     ap.add_argument("--trav-adaptive", default="", help="adaptive: min_live,min_steps,final_rays,max_launches,min_rays")
@@ -119,20 +111,9 @@ class Renderer:
             torch = dist.torch
             self.lane_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(self.lanes - 1)]
             streams = [st.cuda_stream for st in self.lane_streams]
-        assert args.split == 1 or not dist.active, "--split is the one-GPU schedule; tile-sharded runs keep frames in flight instead"
-        if (args.split > 1 or args.group > 1 or args.traverse == "refill") and not psm.has_experimental():
-            raise SystemExit("bench: --split / --group / --traverse refill are schedules that lost every measurement (DESIGN.md 5.3) and live in an "
-                             "experimental library only: make -C prismarine-core_amd/csrc experimental, then "
-                             "PSM_HIP_LIB=$PWD/prismarine-core_amd/csrc/variants/libpsm_experimental.so")
-        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams, split=args.split, group=max(args.group, 1))
-        self.batches = [self.batch]
-        if args.split > 1:   # the serial passes (counters, per-stage times) render whole frames on an unsplit lane of their own
-            self.serial = psm.FrameBatch(1, w, h, device=dist.device_index, seed=1000)
-            self.batches.append(self.serial)
-            self.ctx, self.th, self.rt = self.serial.lanes[0].ctx, self.serial.lanes[0].th, self.serial.lanes[0].rays
-        else:
-            self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
-        for b in self.batches:
+        self.batch = psm.FrameBatch(self.lanes, w, h, device=dist.device_index, seed=1000, streams=streams)
+        self.ctx, self.th, self.rt = self.batch.lanes[0].ctx, self.batch.lanes[0].th, self.batch.lanes[0].rays
+        for b in [self.batch]:
             b.allocate(scene["tris"].shape[0])
             if args.no_build_graph:
                 for ln in b.lanes:
@@ -146,15 +127,11 @@ class Renderer:
             for slot in sorted(scene["textures"]):
                 assert ts.loadTexture(scene["textures"][slot]) == slot
             self.ms.setTextureSet(ts)
-        for b in self.batches:
-            b.applyMaterials(self.ms)
+        self.batch.applyMaterials(self.ms)
         if args.solo >= 0:
-            for b in self.batches:
-                b.each(lambda r: r.setTraverseSolo(args.solo))
-        if args.traverse != "auto" or args.trav_adaptive or args.trav_refill:
+            self.batch.each(lambda r: r.setTraverseSolo(args.solo))
+        if args.traverse != "auto" or args.trav_adaptive:
             def tune(r):
-                if args.trav_refill:
-                    r.setTraverseRefill(*[int(v) for v in args.trav_refill.split(",")])
                 if args.trav_adaptive:
                     r.setTraverseAdaptive(*[int(v) for v in args.trav_adaptive.split(",")])
                 if args.traverse == "phased":
@@ -697,24 +674,18 @@ def main():
         min_rays = 1 << 19
         if args.trav_adaptive and len(args.trav_adaptive.split(",")) >= 5:
             min_rays = int(args.trav_adaptive.split(",")[4])
-        if args.traverse == "refill":
-            min_rays = int(args.trav_refill.split(",")[2]) if len(args.trav_refill.split(",")) >= 3 else 1 << 15
-        hand = args.traverse in ("phased", "adaptive", "refill") or (args.traverse == "auto" and R.lanes * args.split > 1)
-        # (a frame split over several Pipelines: every part traces about 1 / split of a round's rays)
-        ho_rounds = [r for r in round_log if hand and r[0] / args.split >= min_rays]
-        wh_rounds = [r for r in round_log if not (hand and r[0] / args.split >= min_rays)]
-        if args.split == 1 and args.group <= 1:
-            assert (ho_launches > 0) == (len(ho_rounds) > 0), (ho_launches, len(ho_rounds))
-        elif (ho_launches > 0) != (len(ho_rounds) > 0):   # parts near the threshold: price what was launched
-            ho_rounds, wh_rounds = (round_log, []) if ho_launches > 0 else ([], round_log)
+        hand = args.traverse in ("phased", "adaptive") or (args.traverse == "auto" and R.lanes > 1)
+        ho_rounds = [r for r in round_log if hand and r[0] >= min_rays]
+        wh_rounds = [r for r in round_log if not (hand and r[0] >= min_rays)]
+        assert (ho_launches > 0) == (len(ho_rounds) > 0), (ho_launches, len(ho_rounds))
         ms_step = elapsed / args.steps * 1e3
         how = ("the call of the timed region repeated with HIP events around every traversal launch on every lane's stream "
                "(%d frame(s) in flight: a launch shares the chip with the other frames' kernels); that pass ran at %.3f ms per "
                "step against %.3f timed" % (R.lanes, ev_elapsed / args.steps * 1e3, ms_step))
         sums = lambda rs: (sum(r[0] for r in rs), sum(r[1] for r in rs), sum(r[2] for r in rs))
-        whole_frame = not dist.active and not args.emulate_tile and args.split == 1
+        whole_frame = not dist.active and not args.emulate_tile
         if ho_rounds:
-            timed_k = price("rt_traverse_refill<false>" if args.traverse == "refill" else "rt_traverse<false, false, true>", ho_launches, ho_ms, *sums(ho_rounds), len(ho_rounds), args.steps,
+            timed_k = price("rt_traverse<false, false, true>", ho_launches, ho_ms, *sums(ho_rounds), len(ho_rounds), args.steps,
                             args.scene, args.width, args.height, how, whole_frame)
             if wh_launches:
                 timed_k["rounds_below_min_rays_run_single_launch"] = price(
@@ -770,12 +741,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
-                                   "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU%s" % (
-                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth,
-                                       R.lanes, ", each split over %d Pipelines" % args.split if args.split > 1 else
-                                       (", in groups of %d that share their traversal launches" % args.group if args.group > 1 else "")),
+                                   "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU" % (
+                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth, R.lanes),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "frame_split": args.split, "frames_per_traversal_launch": max(args.group, 1), "input": obj_note,
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "input": obj_note,
                        "band_weights": R.weights,
                        "collectives": ("none" if not dist.active else
                                        "psm_dist_* (transport %s%s)" % (R.native.transport, ": a REHEARSAL, the ranks share a GPU and exchange through host memory -- not a scaling measurement" if R.hoststaged else " from libpsm_hip.so")

@@ -176,7 +176,7 @@ enum {
     PSM_BVH_TEXCOORDS = 11,/* float[6][triangle_count] u,v per vertex */
     PSM_BVH_NODE32 = 12    /* uint32[8][leaf_count-1] the traversal record of internal node s as the build wrote it: 12 fp16 box
                               coordinates (left mn.xyz mx.xyz, right mn.xyz mx.xyz) + the two child links, which a node writes
-                              into its PARENT's record (for a hierarchy in an arena slot they count from the arena's start) */
+                              into its PARENT's record */
 };
 int psm_bvh_download(psm_bvh* bvh, int what, void* dst, size_t bytes);
 
@@ -263,8 +263,7 @@ int psm_rt_traverse(psm_rt* rt, psm_bvh* bvh);
  *               kernels fill the tails the extra launches add; +5 % on C3, +9 % on C5's scene), WHOLE for a frame on its own (it is bound
  *               by its longest ray, which extra launches serialise) and for intersections under min_rays rays.
  *               Further hierarchies of a multi-BVH queue always run WHOLE. */
-enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3,
-       PSM_TRAVERSE_REFILL = 4 /* an experimental library only: see the PSM_EXPERIMENTAL section at the end */ };
+enum { PSM_TRAVERSE_AUTO = 0, PSM_TRAVERSE_WHOLE = 1, PSM_TRAVERSE_PHASED = 2, PSM_TRAVERSE_ADAPTIVE = 3 };
 int psm_rt_set_traverse_mode(psm_rt* rt, int mode);
 /* PHASED: count caps (1..7) -> count + 1 launches, for intersections over at least min_rays rays; count = 0 selects
  * WHOLE. Selects PSM_TRAVERSE_PHASED. */
@@ -491,58 +490,6 @@ int psm_stats_reset(psm_ctx* ctx);
 int psm_stats_reference(psm_ctx* ctx, psm_ctx* origin);
 int psm_stats_traverse_intervals(psm_ctx* ctx, float* start_end_ms, uint32_t cap_launches, uint32_t* count);
 int psm_stats_get(psm_ctx* ctx, psm_stats* out); /* synchronises */
-
-/* ---- PSM_EXPERIMENTAL: schedules that were built, parity-tested, measured -- and lost ------------------------
- * Not in the default libpsm_hip.so: `make -C prismarine-core_amd/csrc experimental` builds csrc/variants/libpsm_experimental.so
- * (the product's sources with -DPSM_EXPERIMENTAL=1), against which their parity tests run; a host that wants them defines
- * PSM_EXPERIMENTAL before including this header and links that library. Borrowed device memory -- an arena's slots, an owner's
- * texel arrays -- has no lifetime tracking here: the arena must outlive its hierarchies, the owner its sharers. */
-#if defined(PSM_EXPERIMENTAL) && PSM_EXPERIMENTAL
-/* Several hierarchies whose traversal records share ONE allocation (new). psm_arena_create reserves the node records and
- * triangle records of `slots` hierarchies of up to max_tris triangles each (slots x max_tris <= 2^27);
- * psm_bvh_create_in_arena is psm_bvh_create(ctx, max_tris) with the hierarchy's traversal records in slot `slot`, its child
- * links and triangle ids counting from the start of the arena (what psm_bvh_download / psm_rt_download_hits hand out stays
- * relative to the hierarchy). Everything else about the hierarchy is unchanged; the arena must outlive it. The point:
- * psm_rt_traverse_group walks the current ray queues of up to 8 Pipelines -- each against its own hierarchy, e.g. several
- * frames in flight that each rebuilt theirs -- in ONE launch. A bounce round's launch cannot end before its longest ray, so a
- * launch over 4 frames' rays costs 18-28 % less than 4 launches (tools/merge_probe.py); per ray nothing changes (hits,
- * chains and counters bit-exact). The launch goes to `on`'s stream (NULL: rts[0]'s); the caller orders it after the queues'
- * writers and before the hits' readers. */
-typedef struct psm_arena psm_arena;
-int psm_arena_create(psm_ctx* ctx, uint32_t slots, size_t max_tris, psm_arena** out);
-int psm_arena_destroy(psm_arena* arena);
-int psm_bvh_create_in_arena(psm_ctx* ctx, psm_arena* arena, uint32_t slot, psm_bvh** out);
-int psm_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on);
-/* REFILL (round 3): one launch of persistent waves over the round's rays as a pool behind one atomic counter. A lane whose
- * ray has ended keeps its result in registers until at least refill_min lanes of its wave are idle (or nobody has work
- * left); then the idle lanes write their results, the wave takes that many new rays with ONE atomic and the idle lanes
- * run the ray set-up together -- so set-up and result writes run with a good part of the wave, the node steps with at
- * least 64 - refill_min + 1 lanes with work until the pool is dry, and nothing is handed over through memory.
- * waves_per_cu (even, 2..32): size of the persistent grid; intersections under min_rays rays run WHOLE. */
-int psm_rt_set_traverse_refill(psm_rt* rt, uint32_t refill_min, uint32_t waves_per_cu, uint32_t min_rays);
-/* One frame split over several Pipelines of ONE GPU (new): the frames-in-flight scheduler hides a round's traversal tail
- * behind OTHER frames; the reference's own call pattern is one frame at a time (Viewer.cpp:296-312). Here the frame's 8-row
- * bands are dealt to `split` Pipelines ("parts": rts[q * split + k] = part k of frame slot q, carrying
- * psm_rt_set_tile_interleaved(rt, k, split) and psm_rt_share_texels(rt, part 0 of the slot)), each with its own ray queue on
- * its own stream, all reading the slot's hierarchy bvhs[q] (on part 0's context, rebuilt once per frame). No part waits for
- * another part's round, so one part's tail runs under the others' next rounds; the `fewer than 32 rays -> stop` rule is
- * applied to the frame's total (the parts park on their local counts, psm_dist_decide on their (round, count) pairs, no
- * exchange: they are local). Up to `lanes` frames in flight (1: one frame at a time); results[f].rays sums the parts.
- * The image equals psm_lanes_render's for the same seeds (deposit counts exactly, radiance to float-atomic order). */
-int psm_rt_share_texels(psm_rt* rt, psm_rt* owner);
-int psm_lanes_render_split(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t split, const float cam_inv[16],
-                           const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
-                           int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
-/* Frames in flight whose traversal launches are shared (new): the lanes form lanes / group groups of `group` frames that
- * advance in lock step and trace each bounce round in ONE launch over all their queues (psm_rt_traverse_group; the
- * hierarchies of a group are slots of one psm_arena), so that a group pays one launch tail per round instead of `group`;
- * rebuild, camera, shade and the count read-back stay per frame on the lanes' own streams, and the groups run
- * asynchronously (one group's shading and rebuilds under another's traversal). Per frame the calls, and so the image,
- * the rounds and the rays, are psm_lanes_render's. rts[g * group + k] / bvhs[...]: lane k of group g. */
-int psm_lanes_render_grouped(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t group, const float cam_inv[16],
-                             const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
-                             int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results /* [frames] */);
-#endif /* PSM_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -38,25 +38,8 @@ EXPORTS = [
     "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile", "psm_dist_set_band_weights",
 ]
 
-# entry points of an EXPERIMENTAL library only (csrc/Makefile: `make experimental`; include/psm_hip.h's PSM_EXPERIMENTAL section): the
-# schedules that were measured and lost -- refill traversal, one traversal launch over several Pipelines, a frame split over
-# several Pipelines. PSM_HIP_LIB=<...>/variants/libpsm_experimental.so selects such a library; has_experimental() says which one is loaded.
-EXPERIMENTAL_EXPORTS = ['psm_arena_create', 'psm_arena_destroy', 'psm_bvh_create_in_arena', 'psm_rt_traverse_group', 'psm_rt_set_traverse_refill', 'psm_lanes_render_grouped', 'psm_lanes_render_split', 'psm_rt_share_texels']
-
-
-def has_experimental():
-    return all(hasattr(lib(), n) for n in EXPERIMENTAL_EXPORTS)
-
-
-def _need_experimental(what):
-    if not has_experimental():
-        raise PsmError("%s needs an experimental library (make -C prismarine-core_amd/csrc experimental; PSM_HIP_LIB=.../variants/"
-                       "libpsm_experimental.so): it lost every measurement and is not part of libpsm_hip.so (DESIGN.md 5.3)" % what)
-
-
-TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE, TRAVERSE_REFILL = range(5)
-TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE,
-                  "refill": TRAVERSE_REFILL}
+TRAVERSE_AUTO, TRAVERSE_WHOLE, TRAVERSE_PHASED, TRAVERSE_ADAPTIVE = range(4)
+TRAVERSE_MODES = {"auto": TRAVERSE_AUTO, "whole": TRAVERSE_WHOLE, "phased": TRAVERSE_PHASED, "adaptive": TRAVERSE_ADAPTIVE}
 
 (BVH_KEYS, BVH_INDICES, BVH_LEAF_BOX, BVH_LEAF_TRI, BVH_PAIR_BOX, BVH_LINK, BVH_RANGE,
  BVH_SORTED_TRI, BVH_POSITIONS, BVH_NORMALS, BVH_MATERIALS, BVH_TEXCOORDS, BVH_NODE32) = range(13)
@@ -257,23 +240,6 @@ class RadixSort:
             self.ctx.buf_free(hv)
 
 
-class Arena:
-    """psm_arena: the traversal records (node records, triangle records) of `slots` hierarchies of up to max_tris triangles
-    in one allocation, links arena-wide -- what lets one traversal launch walk the rays of several frames, each against its
-    own rebuilt hierarchy (psm_rt_traverse_group, FrameBatch(group=G))."""
-
-    def __init__(self, ctx, slots, max_tris):
-        self.ctx, self.slots, self.max_tris = ctx, slots, max_tris
-        self._h = C.c_void_p()
-        _need_experimental("psm_arena")
-        ctx.check(lib().psm_arena_create(ctx._h, C.c_uint32(slots), C.c_size_t(max_tris), C.byref(self._h)), "psm_arena_create")
-
-    def close(self):
-        if self._h:
-            lib().psm_arena_destroy(self._h)
-            self._h = C.c_void_p()
-
-
 class TriangleHierarchy:
     """psm::TriangleHierarchy (Include/Prismarine/TriangleHierarchy.hpp:75-94)."""
 
@@ -285,17 +251,11 @@ class TriangleHierarchy:
         self._dirty = False
         self.maxt = 0
 
-    def allocate(self, count, arena=None, slot=0):
-        """arena / slot: keep the traversal records in a slot of an Arena (count must be the arena's max_tris)"""
+    def allocate(self, count):
         if self._h:
             lib().psm_bvh_destroy(self._h)
             self._h = C.c_void_p()
-        if arena is not None:
-            assert count == arena.max_tris, "a hierarchy in an arena has the arena's capacity"
-            self.ctx.check(lib().psm_bvh_create_in_arena(self.ctx._h, arena._h, C.c_uint32(slot), C.byref(self._h)), "psm_bvh_create_in_arena")
-            self._node_off = self._tri_off = slot * count     # what the slot adds to the links / triangle ids of its traversal records
-        else:
-            self.ctx.check(lib().psm_bvh_create(self.ctx._h, C.c_size_t(count), C.byref(self._h)), "psm_bvh_create")
+        self.ctx.check(lib().psm_bvh_create(self.ctx._h, C.c_size_t(count), C.byref(self._h)), "psm_bvh_create")
         self.maxt = count
         self.clearTribuffer()
 
@@ -339,15 +299,18 @@ class TriangleHierarchy:
         """loadMesh for every description of `meshes`, in order. Descriptions that share a pool (the same numpy array: the
         primitives of one glTF buffer, gltf.read_gltf) share its upload, as the reference's primitives share a GL buffer
         (Viewer.cpp:133-139)."""
-        pools = {}   # id(array) -> (handle, contiguous array kept alive)
+        pools = {}   # (address, bytes) -> (handle, contiguous array kept alive): float and word views of one buffer share an upload
+        self.pool_uploads = 0   # device pools the last loadMeshes made: one per distinct stretch of memory, however many views name it
 
         def dev(a, dtype):
-            if id(a) not in pools:
-                c = np.ascontiguousarray(a, dtype)
+            c = np.ascontiguousarray(a, dtype)   # (a view of the right dtype comes back as itself: same memory, same key)
+            key = (c.__array_interface__["data"][0], c.nbytes)   # (both pool types are 4-byte words: the bytes are the same)
+            if key not in pools:
                 h = self.ctx.buf_alloc(max(c.nbytes, 4))
-                pools[id(a)] = (h, c, a)
+                pools[key] = (h, c, a)
                 self.ctx.buf_upload(h, c)
-            h, c, _ = pools[id(a)]
+                self.pool_uploads += 1
+            h, c, _ = pools[key]
             return self.ctx.buf_ptr(h)[0], c.size
 
         try:
@@ -623,12 +586,6 @@ class Pipeline:
                                                           C.c_uint32(final_rays), C.c_uint32(max_launches),
                                                           C.c_uint32(min_rays)), "psm_rt_set_traverse_adaptive")
 
-    def setTraverseRefill(self, refill_min=32, waves_per_cu=28, min_rays=1 << 15):
-        """psm_rt_set_traverse_refill: parameters of the "refill" schedule (does not select it)."""
-        _need_experimental("the refill schedule")
-        self.ctx.check(lib().psm_rt_set_traverse_refill(self._h, C.c_uint32(refill_min), C.c_uint32(waves_per_cu),
-                                                        C.c_uint32(min_rays)), "psm_rt_set_traverse_refill")
-
     def setTraverseSolo(self, solo_max=1):
         """psm_rt_set_traverse_solo: a traversal wave left with at most solo_max rays (0..4) walks them one at a time with all its
         lanes on one ray; 0 switches the gear off. Results never depend on it."""
@@ -760,18 +717,6 @@ def read_pfm(path):
     return data.copy()
 
 
-def traverse_group(pipelines, hierarchies, on=None):
-    """psm_rt_traverse_group: ONE traversal launch over the current queues of several Pipelines, each against its own
-    hierarchy (slots of one Arena), on `on`'s stream (default: the first Pipeline's context). The caller orders the streams."""
-    n = len(pipelines)
-    rts = (C.c_void_p * n)(*[r._h for r in pipelines])
-    bvhs = (C.c_void_p * n)(*[t._h for t in hierarchies])
-    ctx = on or pipelines[0].ctx
-    ctx.check(lib().psm_rt_traverse_group(rts, bvhs, C.c_uint32(n), ctx._h), "psm_rt_traverse_group")
-    for r, t in zip(pipelines, hierarchies):
-        r._obj = t
-
-
 def sharded_rounds(rays, intersector, materials, depth=16):
     """The bounce loop of Viewer.cpp:304-310 for one tile of a sharded frame, as a generator: yields
     the local ray count and is sent the GLOBAL count (sum over tiles), so the reference's
@@ -805,21 +750,9 @@ class FrameBatch:
         def __init__(self, ctx, th, rays):
             self.ctx, self.th, self.rays = ctx, th, rays
 
-    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None, split=1, group=1):
-        """group > 1: the lanes form lanes / group groups whose frames advance in lock step and trace every bounce round in
-        ONE launch over all their queues (psm_lanes_render_grouped); the hierarchies then live in one Arena.
-        split > 1: every frame is traced by `split` Pipelines ("parts") that own the frame's 8-row bands round-robin,
-        share one hierarchy and one set of texel arrays and run their rounds independently (psm_lanes_render_split), so
-        that a part's traversal tail overlaps the other parts' rounds INSIDE the frame; lanes = frames in flight."""
+    def __init__(self, lanes, width, height, device=0, seed=1, streams=None, display=None, master_stream=None):
         self.n = lanes
-        self.split = split
-        self.group = group
-        if split > 1 or group > 1:
-            _need_experimental("FrameBatch(split / group)")
-        assert group >= 1 and lanes % group == 0 and (group == 1 or split == 1)
-        self.arena = None
         self.lanes = []
-        self.parts = []          # parts 1..split-1 of every frame slot: (ctx, Pipeline)
         for s in range(lanes):
             ctx = Context(device, stream=None if streams is None else streams[s])
             th = TriangleHierarchy(ctx)
@@ -827,18 +760,6 @@ class FrameBatch:
             rt.resizeBuffers(width, height)
             rt.resize(*(display or (width, height)))
             self.lanes.append(FrameBatch.Lane(ctx, th, rt))
-            extra = []
-            for k in range(1, split):
-                pc = Context(device)
-                pr = Pipeline(pc, seed=seed)
-                pr.resizeBuffers(width, height)
-                pr.resize(*(display or (width, height)))
-                pr.ctx.check(lib().psm_rt_share_texels(pr._h, rt._h), "psm_rt_share_texels")
-                pr.setTileInterleaved(k, split)
-                extra.append((pc, pr))
-            if split > 1:
-                rt.setTileInterleaved(0, split)
-            self.parts.append(extra)
         # the accumulating Pipeline only samples: it has its own context so that folding a finished frame
         # never queues behind a lane's tracing kernels
         self.master_ctx = Context(device, stream=master_stream)
@@ -849,25 +770,12 @@ class FrameBatch:
         self.frames_rendered = 0
 
     def pipelines(self):
-        """every Pipeline that traces (all parts of all frame slots)"""
-        for ln, extra in zip(self.lanes, self.parts):
+        """every Pipeline that traces"""
+        for ln in self.lanes:
             yield ln.rays
-            for _, pr in extra:
-                yield pr
 
     # -- scene: every lane holds the same scene ------------------------------------------------------
     def allocate(self, n):
-        if self.group > 1:   # traversal records of all lanes' hierarchies in one allocation (one launch walks them all)
-            if self.arena is not None:
-                for ln in self.lanes:
-                    if ln.th._h:
-                        lib().psm_bvh_destroy(ln.th._h)
-                        ln.th._h = C.c_void_p()
-                self.arena.close()
-            self.arena = Arena(self.lanes[0].ctx, len(self.lanes), n)
-            for s, ln in enumerate(self.lanes):
-                ln.th.allocate(n, self.arena, s)
-            return
         for ln in self.lanes:
             ln.th.allocate(n)
 
@@ -906,26 +814,6 @@ class FrameBatch:
         k = len(seeds)
         if k == 0:
             return []
-        if self.split > 1:
-            return self._trace_split(cam_inv, proj_inv, seeds, depth, rebuild, optimization, fold)
-        if self.group > 1:
-            assert fold, "grouped frames always fold into the accumulating Pipeline"
-            n = self.n
-            rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes])
-            bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes])
-            sd = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
-            res = (LaneResult * k)()
-            ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
-            pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
-            opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
-            rc = lib().psm_lanes_render_grouped(rts, bvhs, C.c_uint32(n), C.c_uint32(self.group), _p(ci), _p(pi), sd, C.c_uint32(k),
-                                                C.c_uint32(depth), C.c_int(int(rebuild)), _p(opt) if opt is not None else None,
-                                                self.master._h, res)
-            self.lanes[0].ctx.check(rc, "psm_lanes_render_grouped")
-            for ln in self.lanes:
-                ln.th._dirty = False
-                ln.rays._obj = ln.th
-            return [(res[f].rounds, res[f].rays) for f in range(k)]
         n = min(self.n, k)
         rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes[:n]])
         bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
@@ -941,29 +829,6 @@ class FrameBatch:
         for ln in self.lanes[:n]:
             ln.th._dirty = False
             ln.rays._obj = ln.th
-        return [(res[f].rounds, res[f].rays) for f in range(k)]
-
-    def _trace_split(self, cam_inv, proj_inv, seeds, depth, rebuild, optimization, fold):
-        assert fold, "split frames always fold into the accumulating Pipeline"
-        k, n, sp = len(seeds), min(self.n, len(seeds)), self.split
-        hs = []
-        for ln, extra in list(zip(self.lanes, self.parts))[:n]:
-            hs += [ln.rays._h] + [pr._h for _, pr in extra]
-        rts = (C.c_void_p * (n * sp))(*hs)
-        bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
-        sd = (C.c_uint32 * k)(*[v & 0xFFFFFFFF for v in seeds])
-        res = (LaneResult * k)()
-        ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
-        pi = np.ascontiguousarray(proj_inv, np.float32).reshape(16)
-        opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
-        rc = lib().psm_lanes_render_split(rts, bvhs, C.c_uint32(n), C.c_uint32(sp), _p(ci), _p(pi), sd, C.c_uint32(k), C.c_uint32(depth),
-                                          C.c_int(int(rebuild)), _p(opt) if opt is not None else None, self.master._h, res)
-        self.lanes[0].ctx.check(rc, "psm_lanes_render_split")
-        for ln, extra in list(zip(self.lanes, self.parts))[:n]:
-            ln.th._dirty = False
-            ln.rays._obj = ln.th
-            for _, pr in extra:
-                pr._obj = ln.th
         return [(res[f].rounds, res[f].rays) for f in range(k)]
 
     def fold(self, k):
@@ -1050,10 +915,8 @@ class FrameBatch:
         self.master.clearSampler()
 
     def contexts(self):
-        for ln, extra in zip(self.lanes, self.parts):
+        for ln in self.lanes:
             yield ln.ctx
-            for pc, _ in extra:
-                yield pc
 
     def sync(self):
         for c in self.contexts():
@@ -1061,17 +924,9 @@ class FrameBatch:
         self.master_ctx.sync()
 
     def close(self):
-        for extra in self.parts:      # the parts borrow their slot's texel arrays: they go first
-            for pc, pr in extra:
-                pr.close()
-                pc.close()
-        self.parts = []
         for ln in self.lanes:
             ln.rays.close()
             ln.th.close()
-        if self.arena is not None:      # after the hierarchies that live in it, before the context that allocated it
-            self.arena.close()
-            self.arena = None
         for ln in self.lanes:
             ln.ctx.close()
         self.lanes = []

@@ -119,10 +119,12 @@ static int ctx_create(int device, void* ext_stream, bool use_ext, psm_ctx** out)
         delete c;
         return PSM_ERR_HIP;
     }
-    if (const char* t = std::getenv("PSM_SORT_TUNE")) {   // study knob (tools/sort_bench.py): "S_small,S_large,threads" of radix_local
-        unsigned a = 0, b = 0, th = 0;
-        if (std::sscanf(t, "%u,%u,%u", &a, &b, &th) == 3 && a >= 64 && a <= 4096 && b >= 64 && b <= 4096 && (th == 256 || th == 512 || th == 1024)) {
+    if (const char* t = std::getenv("PSM_SORT_TUNE")) {   // study knob (tools/sort_bench.py): "S_small,S_large,threads[,cap_small,cap_large]" of radix_local
+        unsigned a = 0, b = 0, th = 0, cs = 4096, cl = 4096;
+        const int got = std::sscanf(t, "%u,%u,%u,%u,%u", &a, &b, &th, &cs, &cl);
+        if (got >= 3 && a >= 64 && a < cs && b >= 64 && b < cl && (th == 512 || th == 1024)) {
             c->sort_hybrid_s_small = a; c->sort_hybrid_s_large = b; c->sort_hybrid_threads = th;
+            c->sort_hybrid_cap_small = cs; c->sort_hybrid_cap_large = cl;
         }
     }
     *out = c;
@@ -277,7 +279,6 @@ int psm_bvh_destroy(psm_bvh* b) {
     if (!b) return PSM_ERR_INVALID;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    if (b->arena) { b->d_tri48 = nullptr; b->d_node32 = nullptr; }   // slices of the arena
     dev_free(b->d_pos); dev_free(b->d_nrm); dev_free(b->d_mats); dev_free(b->d_tri48); dev_free(b->d_tex);
     dev_free(b->d_keys); dev_free(b->d_idx); dev_free(b->d_leafbox); dev_free(b->d_leaftri);
     dev_free(b->d_block); dev_free(b->d_small); dev_free(b->d_opt); dev_free(b->d_seg);
@@ -287,41 +288,7 @@ int psm_bvh_destroy(psm_bvh* b) {
     return PSM_OK;
 }
 
-#if PSM_EXPERIMENTAL
-int psm_arena_destroy(psm_arena* a) {
-    if (!a) return PSM_ERR_INVALID;
-    (void)hipSetDevice(a->ctx->device);
-    dev_free(a->d_node32); dev_free(a->d_tri48);
-    delete a;
-    return PSM_OK;
-}
-int psm_arena_create(psm_ctx* c, uint32_t slots, size_t max_tris, psm_arena** out) {
-    if (!c || !out || slots == 0 || max_tris == 0) return PSM_ERR_INVALID;
-    *out = nullptr;
-    // links and triangle ids count from the start of the arena: the same 2^27 limits as one hierarchy's, over all slots
-    if ((uint64_t)slots * max_tris > (1ull << 27)) return set_err(c, PSM_ERR_CAPACITY, "psm_arena_create: slots x max_tris exceeds 2^27");
-    (void)hipSetDevice(c->device);
-    psm_arena* a = new (std::nothrow) psm_arena();
-    if (!a) return PSM_ERR_INVALID;
-    a->ctx = c; a->slots = slots; a->max_tris = max_tris;
-    int rc = dev_alloc(c, &a->d_node32, (size_t)slots * 2 * max_tris);
-    if (rc == PSM_OK) rc = dev_alloc(c, &a->d_tri48, (size_t)slots * 3 * max_tris);
-    if (rc != PSM_OK) { psm_arena_destroy(a); return rc; }
-    *out = a;
-    return PSM_OK;
-}
-
-#endif
-static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t slot, psm_bvh** out);
-int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) { return bvh_create(c, max_tris, nullptr, 0, out); }
-#if PSM_EXPERIMENTAL
-int psm_bvh_create_in_arena(psm_ctx* c, psm_arena* arena, uint32_t slot, psm_bvh** out) {
-    if (!c || !arena || !out || slot >= arena->slots || c->device != arena->ctx->device) return PSM_ERR_INVALID;
-    return bvh_create(c, arena->max_tris, arena, slot, out);
-}
-#endif
-
-static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t slot, psm_bvh** out) {
+int psm_bvh_create(psm_ctx* c, size_t max_tris, psm_bvh** out) {
     if (!c || !out || max_tris == 0) return PSM_ERR_INVALID;
     // 2^27 triangles (the reference: ~4.19 M, TriangleHierarchy.inl:80): the traversal kernel addresses its 32-byte node
     // records with a 32-bit byte offset, and 9 floats per triangle stay below 2^31 elements
@@ -343,22 +310,14 @@ static int bvh_create(psm_ctx* c, size_t max_tris, psm_arena* arena, uint32_t sl
     int rc = PSM_OK;
     auto A = [&](int r) { if (rc == PSM_OK) rc = r; };
     A(dev_alloc(c, &b->d_pos, 9 * n)); A(dev_alloc(c, &b->d_nrm, 9 * n)); A(dev_alloc(c, &b->d_mats, n));
-    if (arena) {
-        b->arena = arena;
-        b->node_off = (uint32_t)((size_t)slot * n);   // in nodes (2 uint4 each)
-        b->tri_off = (uint32_t)((size_t)slot * n);
-        b->d_tri48 = arena->d_tri48 + (size_t)3 * b->tri_off;
-        b->d_node32 = arena->d_node32 + (size_t)2 * b->node_off;
-    } else {
-        A(dev_alloc(c, &b->d_tri48, 3 * n));
-    }
+    A(dev_alloc(c, &b->d_tri48, 3 * n));
     A(dev_alloc(c, &b->d_tex, 6 * n)); A(dev_alloc(c, &b->d_keys, n)); A(dev_alloc(c, &b->d_idx, n));
     A(dev_alloc(c, &b->d_leafbox, n)); A(dev_alloc(c, &b->d_leaftri, n));
     A(dev_alloc(c, &b->d_block, (n + 255) / 256 + 1)); A(dev_alloc(c, &b->d_small, (size_t)SM_WORDS));
     A(dev_alloc(c, &b->d_opt, (size_t)16)); A(dev_alloc(c, &b->d_seg, off));
     A(dev_alloc(c, &b->d_sorted_tri, n)); A(dev_alloc(c, &b->d_pairbox, 2 * n)); A(dev_alloc(c, &b->d_link, n));
     A(dev_alloc(c, &b->d_range, n));
-    if (!arena) A(dev_alloc(c, &b->d_node32, 2 * n));
+    A(dev_alloc(c, &b->d_node32, 2 * n));
     if (rc != PSM_OK) { psm_bvh_destroy(b); return rc; }
     if (hipMemsetAsync(b->d_small, 0, SM_WORDS * 4, c->stream) != hipSuccess ||
         hipMemsetAsync(b->d_tex, 0, 6 * n * sizeof(float), c->stream) != hipSuccess) { psm_bvh_destroy(b); return PSM_ERR_HIP; }
@@ -594,7 +553,6 @@ int psm_bvh_get_info(psm_bvh* b, psm_bvh_info* info) {
     info->triangle_count = b->tri_count;
     info->leaf_count = sm[SM_COUNT];
     info->root = (int32_t)sm[SM_ROOT];
-    if (info->root >= 0) info->root -= (int32_t)b->node_off;   // (the traversal records of an arena slot count from the arena's start)
     std::memcpy(info->transform, sm, 16 * sizeof(float));
     std::memcpy(info->bounds_min, sm + SM_BFLOAT, 4 * sizeof(float));
     std::memcpy(info->bounds_max, sm + SM_BFLOAT + 4, 4 * sizeof(float));
@@ -640,7 +598,6 @@ static void rt_free_grid(psm_rt* r) {
     for (int q = 0; q < 2; q++) { dev_free(r->qA[q]); dev_free(r->qB[q]); dev_free(r->qC[q]); dev_free(r->q_bases[q]); }
     dev_free(r->d_block);
     dev_free(r->hit0); dev_free(r->hitN); dev_free(r->pool);
-    if (r->texels_shared) { r->t_coord = nullptr; r->t_sum = nullptr; r->t_flag = nullptr; r->texels_shared = false; }
     dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag);
 }
 
@@ -694,7 +651,7 @@ int psm_rt_resize_buffers(psm_rt* r, uint32_t w, uint32_t h) {
     (void)hipSetDevice(c->device);
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     rt_free_grid(r);
-    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0; r->tile_root = true; r->texels_lent = false;
+    r->w = w; r->h = h; r->y0 = 0; r->y1 = h; r->tile_mode = 0; r->tile_root = true;
     uint64_t wr = (uint64_t)w * h;
     uint64_t lim = std::min<uint64_t>(wr * 4, 4096ull * 4096ull);  // Pipeline.inl:187-189
     r->limit = (uint32_t)lim;
@@ -758,34 +715,10 @@ int psm_rt_set_tile_weighted(psm_rt* r, uint32_t rank, uint32_t world, const uin
         return set_err(r->ctx, PSM_ERR_INVALID, "psm_rt_set_tile_weighted: at most 64 ranks, and the weights must add up to 1..64");
     r->bands = m;
     r->tile_mode = 1; r->tile_rank = rank; r->tile_world = world;
-    r->tile_root = rank == 0 && !r->texels_shared && !r->texels_lent;  // tiles are gathered to rank 0 (psm_rt_unpack_texels_dev), which runs sample()
+    r->tile_root = rank == 0;  // tiles are gathered to rank 0 (psm_rt_unpack_texels_dev), which runs sample()
     return PSM_OK;
 }
 int psm_rt_set_tile_interleaved(psm_rt* r, uint32_t rank, uint32_t world) { return psm_rt_set_tile_weighted(r, rank, world, nullptr); }
-#if PSM_EXPERIMENTAL
-// Several Pipelines that each trace a part of ONE frame (psm_lanes_render_split: the frame's bands dealt to `split`
-// Pipelines on one GPU, so that one part's traversal tail overlaps the other parts' rounds): they write the per-texel
-// results -- jitter position, radiance sum, flag -- of the texels they own into the SAME arrays, the owner's. Texels are
-// disjoint between the parts, so no two Pipelines touch the same texel. rt gives up its own arrays; camera() of every
-// sharing Pipeline (and of the owner) then touches its own texels only. Undone by rt's next resizeBuffers; to be
-// called again after the owner's.
-int psm_rt_share_texels(psm_rt* r, psm_rt* owner) {
-    if (!r || !owner || r == owner || !r->t_sum || !owner->t_sum) return PSM_ERR_INVALID;
-    psm_ctx* c = r->ctx;
-    if (r->w != owner->w || r->h != owner->h || c->device != owner->ctx->device)
-        return set_err(c, PSM_ERR_INVALID, "psm_rt_share_texels: the Pipelines differ in ray-grid size or device");
-    if (owner->texels_shared) return set_err(c, PSM_ERR_INVALID, "psm_rt_share_texels: the owner itself borrows its texels");
-    (void)hipSetDevice(c->device);
-    PSM_HIP(c, hipStreamSynchronize(c->stream));
-    if (!r->texels_shared) { dev_free(r->t_coord); dev_free(r->t_sum); dev_free(r->t_flag); }
-    r->t_coord = owner->t_coord; r->t_sum = owner->t_sum; r->t_flag = owner->t_flag;
-    r->texels_shared = true;
-    r->tile_root = false;
-    owner->tile_root = false;
-    owner->texels_lent = true;
-    return PSM_OK;
-}
-#endif
 int psm_rt_tile_texels(psm_rt* r, uint32_t* count) {
     if (!r || !count) return PSM_ERR_INVALID;
     *count = tile_texel_count(r);
@@ -900,8 +833,11 @@ int psm_rt_set_materials(psm_rt* r, const psm_material* mats, uint32_t count, in
     // it is NaN instead -- and the reference queues the ray -- where the specular colour is 0 / 0 (a black full-metal material:
     // albedo 0, metallic 1, both after their fp16 round trip) or a colour overflows or is not a number to begin with. Without
     // textures a surface is its material's constants (surface.comp:81-161), so the materials decide: `ordinary` = diffuse rgb in
-    // [0, 1] with one component of at least 1/1024, roughness and metallic in [0, 1]. (Residue: a shadow ray's weight is NaN
-    // where the hit point IS the light's centre, a set of measure zero.)
+    // [0, 1] with one component of at least 1/1024, roughness and metallic in [0, 1]. The constants' alpha plays no part: without a
+    // diffuse texture a hit's albedo is vec4(diffuse.xyz, 1) (fetchDiffuse, surface.comp:155-161), so an equal-distance chain of such
+    // hits never composites (rayshading.comp:60-116 stops at alpha > 0.99999) -- ADVICE r04 feared a transparent constant here;
+    // `+clearmetal` in tests/test_gpu_parity.py holds the case. (Residue: a shadow ray's weight is NaN where the hit point IS the
+    // light's centre, a set of measure zero.)
     r->mats_ordinary = true;
     for (uint32_t i = 0; i < count; i++) {
         const psm_material& m = mats[i];
@@ -946,26 +882,6 @@ int psm_rt_traverse(psm_rt* r, psm_bvh* b) {
     return launch_rt_traverse(r, b);
 }
 
-#if PSM_EXPERIMENTAL
-// One traversal launch over the current queues of n Pipelines, on `on`'s stream (NULL: rts[0]'s context). The caller orders
-// that stream after the queues' writers and the hits' readers after it (the grouped scheduler does it with events).
-static int traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
-int psm_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on) { return traverse_group(rts, bvhs, n, on, nullptr); }
-// (owner: the Pipeline whose schedule settings and continuation queues the launch uses; the grouped scheduler's lead lane)
-int psm_rt_traverse_group_owned(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner) { return traverse_group(rts, bvhs, n, on, owner); }
-static int traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner) {
-    if (!rts || !bvhs || n == 0) return PSM_ERR_INVALID;
-    for (uint32_t k = 0; k < n; k++) {
-        if (!rts[k] || !bvhs[k]) return PSM_ERR_INVALID;
-        int32_t cnt;
-        int rc = psm_rt_ray_count(rts[k], &cnt);   // synchronises only where the host does not know the count yet
-        if (rc != PSM_OK) return rc;
-    }
-    psm_ctx* c = on ? on : rts[0]->ctx;
-    (void)hipSetDevice(c->device);
-    return launch_rt_traverse_group(rts, bvhs, n, c, owner);
-}
-#endif
 
 int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
     if (!r) return PSM_ERR_INVALID;
@@ -974,7 +890,7 @@ int psm_rt_set_camera_mode(psm_rt* r, int enable360) {
 }
 
 int psm_rt_set_traverse_mode(psm_rt* r, int mode) {
-    if (!r || mode < PSM_TRAVERSE_AUTO || mode > (PSM_EXPERIMENTAL ? 4 /* REFILL */ : PSM_TRAVERSE_ADAPTIVE)) return PSM_ERR_INVALID;
+    if (!r || mode < PSM_TRAVERSE_AUTO || mode > PSM_TRAVERSE_ADAPTIVE) return PSM_ERR_INVALID;
     r->trav_mode = mode;
     return PSM_OK;
 }
@@ -1007,15 +923,6 @@ int psm_rt_set_traverse_solo(psm_rt* r, uint32_t solo_max) {
     return PSM_OK;
 }
 
-#if PSM_EXPERIMENTAL
-int psm_rt_set_traverse_refill(psm_rt* r, uint32_t refill_min, uint32_t waves_per_cu, uint32_t min_rays) {
-    if (!r || refill_min < 1 || refill_min > 64 || waves_per_cu < 2 || waves_per_cu > 32 || (waves_per_cu & 1u)) return PSM_ERR_INVALID;
-    r->refill_min = refill_min;
-    r->refill_waves_per_cu = waves_per_cu;
-    r->refill_min_rays = min_rays;
-    return PSM_OK;
-}
-#endif
 
 int psm_rt_reset_hits(psm_rt* r) {
     if (!r) return PSM_ERR_INVALID;
@@ -1160,12 +1067,6 @@ int psm_rt_download_hits(psm_rt* r, psm_hit* hits, int32_t* counts, uint32_t max
             if (k < n) {
                 v = (k == 0) ? h0[i] : pool[off + k - 1];
                 std::memcpy(&tri, &v.w, 4);
-                // a hierarchy in an arena slot records arena-wide triangle ids: hand out the hierarchy's own
-                if (tri >= 0) {
-                    const int obj = (tri >> OBJ_SHIFT) & (MAX_TRAV_OBJECTS - 1);
-                    const psm_bvh* hb = obj < MAX_TRAV_OBJECTS ? r->last_objs[obj] : nullptr;
-                    if (hb && hb->tri_off) tri = (((tri & ((1 << OBJ_SHIFT) - 1)) - (int)hb->tri_off) | (obj << OBJ_SHIFT));
-                }
             }
             o.u = v.x; o.v = v.y; o.t = v.z; o.tri = tri;
         }

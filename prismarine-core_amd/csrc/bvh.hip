@@ -445,10 +445,7 @@ template <bool RECORDS>
 __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ keys, const int32_t* __restrict__ sorted_tri,
                                                 SegTree st, uint32_t* __restrict__ sm, uint4* __restrict__ pairbox,
                                                 int2* __restrict__ link, int2* __restrict__ range,
-                                                uint4* __restrict__ node32, int node_off, int tri_off) {
-    // node_off / tri_off: the hierarchy's slot in an arena (psm_arena): the links and triangle ids of the TRAVERSAL records
-    // count from the start of the arena, so that one launch can walk several hierarchies from one base pointer; the
-    // reference-shaped records (RECORDS) and everything the parity tests download stay relative to the hierarchy
+                                                uint4* __restrict__ node32) {
     int count = (int)sm[SM_COUNT];
     int s = blockIdx.x * 256 + threadIdx.x;
     if (!RECORDS && s == 0 && count < 2) sm[SM_ROOT] = (uint32_t)-1;
@@ -630,11 +627,11 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
     uint32_t* rec = (uint32_t*)(node32 + 2 * (size_t)s);
     node32[2 * (size_t)s + 0] = make_uint4(lb.x, (lb.y & 0xffffu) | (lb.z << 16), (lb.z >> 16) | (lb.w << 16), rb.x);
     *(uint2*)(rec + 4) = make_uint2((rb.y & 0xffffu) | (rb.z << 16), (rb.z >> 16) | (rb.w << 16));
-    if (f == s) rec[6] = (uint32_t)~(sorted_tri[s] + tri_off);        // leaf children: the parent's to write
-    if (s + 1 == l) rec[7] = (uint32_t)~(sorted_tri[l] + tri_off);
+    if (f == s) rec[6] = (uint32_t)~sorted_tri[s];        // leaf children: the parent's to write
+    if (s + 1 == l) rec[7] = (uint32_t)~sorted_tri[l];
     // this node's own link, into its parent's record
     if (f == 0 && l == count - 1) {
-        sm[SM_ROOT] = (uint32_t)(s + node_off);
+        sm[SM_ROOT] = (uint32_t)s;
         return;
     }
     if (parent < 0) {
@@ -643,7 +640,7 @@ __global__ __launch_bounds__(256) void bvh_emit(const uint64_t* __restrict__ key
         is_left = dR > dL;
         parent = is_left ? l : f - 1;
     }
-    ((uint32_t*)(node32 + 2 * (size_t)parent))[is_left ? 6 : 7] = (uint32_t)(s + node_off);
+    ((uint32_t*)(node32 + 2 * (size_t)parent))[is_left ? 6 : 7] = (uint32_t)s;
 }
 
 // ---- launch wrappers ----------------------------------------------------------------------------
@@ -705,7 +702,7 @@ int launch_bvh_emit(psm_bvh* b) {
     st.nlev = (uint32_t)nlev;
     uint32_t grid = (n + 255u) / 256u;
     bvh_emit<false><<<grid, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
-                                                 b->d_range, b->d_node32, (int)b->node_off, (int)b->tri_off);
+                                                 b->d_range, b->d_node32);
     b->records_valid = false;
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
@@ -722,7 +719,7 @@ int launch_bvh_emit_records(psm_bvh* b) {
     for (int q = 0; q < 32; q++) st.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
     st.nlev = (uint32_t)nlev;
     bvh_emit<true><<<(n + 255u) / 256u, 256, 0, c->stream>>>(b->d_keys, b->d_sorted_tri, st, b->d_small, b->d_pairbox, b->d_link,
-                                                             b->d_range, b->d_node32, (int)b->node_off, (int)b->tri_off);
+                                                             b->d_range, b->d_node32);
     PSM_HIP(c, hipGetLastError());
     b->records_valid = true;
     return PSM_OK;

@@ -17,9 +17,6 @@
 
 #include <algorithm>
 
-#if PSM_EXPERIMENTAL
-extern "C" int psm_rt_traverse_group_owned(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
-#endif
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -511,324 +508,3 @@ extern "C" int psm_dist_render_frames(psm_dist* d, psm_rt* const* rts, psm_bvh* 
 }
 
 
-#if PSM_EXPERIMENTAL
-// ---- one frame split over several Pipelines of ONE GPU --------------------------------------------------------------
-//
-// The reference renders one frame at a time (Viewer.cpp:296-312), and a frame's bounce round cannot end before its
-// longest ray: a frame that runs alone leaves the chip almost idle for a third of every round. The
-// frames-in-flight scheduler above hides those tails behind OTHER frames. This one hides them inside a frame: the
-// frame's 8-row bands are dealt to `split` Pipelines ("parts") that share the frame's hierarchy and write into one set
-// of texel arrays (psm_rt_share_texels), each with its own ray queue on its own stream -- exactly the tile sharding of
-// the multi-GPU path, with the "ranks" living on one device. No part waits for another part's round, so one part's
-// traversal tail can run under the other parts' next rounds; rays never cross parts (radiance is per texel,
-// sampler.comp:53-66; secondary rays inherit their texel, rayslib.glsl:148). The `fewer than 32 rays -> stop` rule
-// (Pipeline.inl:459-461) looks at the frame's total, as in the sharded path: parts park on their local counts and
-// psm_dist_decide is applied to the parts' (round, count) pairs -- here without any exchange, the parts being local.
-// The image equals the unsplit one (deposit counts exactly, radiance to float-atomic order).
-//
-// MEASURED (round 3, C3): it does not pay. One frame at a time 3.74 ms unsplit against 4.17 / 4.03 / 3.84 /
-// 4.71 ms split over 2 / 3 / 4 / 6 parts: the parts start together and have equal work, so their tails coincide, and the
-// fold at the end of the frame puts them back in step every frame -- where two FRAMES in flight drift apart and reach
-// 2.9 ms per frame. Starting part k when part k-1's first traversal launch has ended (anti-phase on purpose) gave
-// 4.05-4.26 ms. Kept as a selectable, parity-tested schedule (bench.py --split), not a default.
-//
-// rts[q * split + k]: part k of frame slot q -- psm_rt_set_tile_interleaved(rt, k, split), texels shared with part 0 of
-// the slot; bvhs[q]: the slot's hierarchy, on part 0's context. Up to `lanes` frames are in flight (lanes = 1: one frame
-// at a time); frames fold into fold_into in frame order.
-extern "C" int psm_lanes_render_split(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t split, const float cam_inv[16],
-                                      const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
-                                      int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results) {
-    if (!rts || !bvhs || !cam_inv || !proj_inv || lanes == 0 || split == 0 || split > 16 || lanes * split > 64 || (frames && !frame_seeds))
-        return PSM_ERR_INVALID;
-    if (!fold_into) return PSM_ERR_INVALID;
-    const uint32_t total = lanes * split;
-    for (uint32_t q = 0; q < lanes; q++) {
-        if (!bvhs[q]) return PSM_ERR_INVALID;
-        for (uint32_t k = 0; k < split; k++) {
-            psm_rt* r = rts[q * split + k];
-            if (!r) return PSM_ERR_INVALID;
-            psm_ctx* c = r->ctx;
-            if (fold_into->w != r->w || fold_into->h != r->h) return set_err(c, PSM_ERR_INVALID, "psm_lanes_render_split: fold_into and the parts differ in ray-grid size");
-            if (split > 1 && (r->tile_mode != 1 || r->tile_world != split || r->tile_rank != k || r->tile_root))
-                return set_err(c, PSM_ERR_STATE, "psm_lanes_render_split: part k of a frame must carry psm_rt_set_tile_interleaved(k, split) and share part 0's texels");
-            if (k > 0 && (r->t_sum != rts[q * split]->t_sum || !r->texels_shared))
-                return set_err(c, PSM_ERR_STATE, "psm_lanes_render_split: the parts of a frame must share part 0's texels (psm_rt_share_texels)");
-            for (uint32_t p = 0; p < q * split + k; p++)
-                if (rts[p] == r || rts[p]->ctx->stream == c->stream)
-                    return set_err(c, PSM_ERR_INVALID, "psm_lanes_render_split: every part needs its own context (stream) and ray buffers");
-            int e = lane_resources(r);
-            if (e != PSM_OK) return e;
-        }
-        if (bvhs[q]->ctx != rts[q * split]->ctx)
-            return set_err(rts[q * split]->ctx, PSM_ERR_INVALID, "psm_lanes_render_split: a slot's hierarchy must live on the context of its part 0");
-    }
-    if (frames == 0) return PSM_OK;
-    (void)hipSetDevice(rts[0]->ctx->device);
-    for (uint32_t s = 0; s < total; s++) rts[s]->in_flight = total;
-    std::vector<uint32_t> state(total, 0u), rounds(total, 0u);
-    std::vector<psm_bvh*> lane_bvh(total);
-    for (uint32_t s = 0; s < total; s++) lane_bvh[s] = bvhs[s / split];
-    ShardedLanes L(rts, lane_bvh.data(), total, depth, state.data(), rounds.data());
-    struct Slot { LaneState state = IDLE; int frame = -1; };
-    std::vector<Slot> slots(lanes);
-    std::vector<int32_t> all(2 * (size_t)split), verdict(1);
-    std::vector<uint32_t> force(1);
-    int rc = PSM_OK;
-    auto start = [&](uint32_t q, uint32_t f) -> int {
-        psm_rt* r0 = rts[q * split];
-        psm_ctx* c0 = r0->ctx;
-        if (rebuild) {  // the slot's hierarchy, once, on part 0's stream; the other parts' streams wait for it
-            int e = psm_bvh_build(bvhs[q], opt);
-            if (e != PSM_OK) return e;
-        }
-        if (split > 1) {
-            PSM_HIP(c0, hipEventRecord(r0->ev_fold, c0->stream));
-            for (uint32_t k = 1; k < split; k++) PSM_HIP(c0, hipStreamWaitEvent(rts[q * split + k]->ctx->stream, r0->ev_fold, 0));
-        }
-        for (uint32_t k = 0; k < split; k++) L.begin(q * split + k, frame_seeds[f], cam_inv, proj_inv);
-        slots[q].state = RUNNING;
-        slots[q].frame = (int)f;
-        return L.rc;
-    };
-    uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
-    while (rc == PSM_OK && next_fold < frames) {
-        bool progressed = false;
-        for (uint32_t q = 0; q < lanes && rc == PSM_OK; q++) {
-            Slot& S = slots[q];
-            if (S.state == IDLE && next_frame < frames) {
-                rc = start(q, next_frame++);
-                progressed = true;
-            }
-            if (S.state != RUNNING || rc != PSM_OK) continue;
-            bool parked = true;
-            for (uint32_t k = 0; k < split; k++) {
-                const uint32_t s = q * split + k;
-                if (L.poll(s)) progressed = true;
-                parked = parked && L.st[s] == FINISHED;
-            }
-            rc = L.rc;
-            if (!parked || rc != PSM_OK) continue;
-            // every part stands parked: the stop rule on the frame's total (the parts are the "ranks" of psm_dist_decide)
-            for (uint32_t k = 0; k < split; k++) {
-                all[(size_t)k * 2 + 0] = (int32_t)rounds[q * split + k];
-                all[(size_t)k * 2 + 1] = (int32_t)rts[q * split + k]->ray_count;
-            }
-            rc = psm_dist_decide(split, 1u, all.data(), depth, verdict.data(), force.data());
-            if (rc != PSM_OK) break;
-            progressed = true;
-            if (verdict[0]) {
-                S.state = FINISHED;
-                if (results) {
-                    uint64_t rays = 0;
-                    for (uint32_t k = 0; k < split; k++) rays += L.traced[q * split + k];
-                    results[S.frame].rounds = rounds[q * split];
-                    results[S.frame].rays = rays;
-                }
-            } else {
-                for (uint32_t k = 0; k < split; k++) L.resume(q * split + k, force[0]);
-                rc = L.rc;
-            }
-        }
-        // sample() in frame order: the owner's texel arrays hold the whole frame once every part's stream has drained
-        for (bool again = true; again && rc == PSM_OK;) {
-            again = false;
-            for (uint32_t q = 0; q < lanes; q++) {
-                Slot& S = slots[q];
-                if (S.state != FINISHED || (uint32_t)S.frame != next_fold) continue;
-                psm_ctx* mc = fold_into->ctx;
-                for (uint32_t k = 1; k < split && rc == PSM_OK; k++) {  // parts 1.. -> the accumulating stream (part 0: inside fold())
-                    psm_rt* r = rts[q * split + k];
-                    if (hipEventRecord(r->ev_fold, r->ctx->stream) != hipSuccess || hipStreamWaitEvent(mc->stream, r->ev_fold, 0) != hipSuccess)
-                        rc = set_err(r->ctx, PSM_ERR_HIP, "psm_lanes_render_split: ordering a part before the fold");
-                }
-                if (rc == PSM_OK) rc = fold(fold_into, rts[q * split]);
-                for (uint32_t k = 1; k < split && rc == PSM_OK; k++) {  // the parts' next cameras wait for the fold (part 0 does already)
-                    psm_rt* r = rts[q * split + k];
-                    if (hipStreamWaitEvent(r->ctx->stream, rts[q * split]->ev_fold, 0) != hipSuccess)
-                        rc = set_err(r->ctx, PSM_ERR_HIP, "psm_lanes_render_split: ordering the fold before a part's next frame");
-                }
-                S.state = IDLE;
-                S.frame = -1;
-                next_fold++;
-                again = progressed = true;
-                break;
-            }
-        }
-        if (!progressed) {
-            if (++idle_spins > 256) std::this_thread::yield();
-        } else {
-            idle_spins = 0;
-        }
-    }
-    for (uint32_t s = 0; s < total; s++) {
-        (void)hipStreamSynchronize(rts[s]->ctx->stream);
-        rts[s]->in_flight = 1;
-    }
-    (void)hipStreamSynchronize(fold_into->ctx->stream);
-    return rc;
-}
-
-
-// ---- frames in flight whose traversal launches are shared --------------------------------------------------------------
-//
-// A bounce round's traversal launch cannot end before its longest ray, and a 2 M-ray launch spends a good part of its
-// time with a few waves on the chip; frames in flight hide those tails behind each other's kernels, but every launch still
-// pays its own. Here the lanes form groups of `group` frames that advance in lock step and trace each round in ONE launch
-// over all their queues (psm_rt_traverse_group: every frame against its own rebuilt hierarchy, the hierarchies being
-// slots of one psm_arena) -- one tail per round per group: 18-28 % less traversal time than the same launches apart
-// (tools/merge_probe.py). Everything else stays per frame and per lane stream: rebuild, camera, shade, the read-back of the
-// next count, and the fold in frame order; groups run asynchronously, so one group's shading and rebuilds run under another
-// group's traversal. A frame leaves its group's launches when its own count drops below 32 (Pipeline.inl:459-461) or
-// `depth` is reached; per frame the sequence of calls -- and so the image -- is exactly psm_lanes_render's.
-//
-// rts[g * group + k], bvhs[g * group + k]: lane k of group g (own context / stream each; the hierarchies of a group in
-// slots of one arena). lanes = groups x group.
-extern "C" int psm_lanes_render_grouped(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t lanes, uint32_t group, const float cam_inv[16],
-                                        const float proj_inv[16], const uint32_t* frame_seeds, uint32_t frames, uint32_t depth,
-                                        int rebuild, const double* opt, psm_rt* fold_into, psm_lane_result* results) {
-    if (!rts || !bvhs || !cam_inv || !proj_inv || lanes == 0 || lanes > 64 || group == 0 || group > 8 || lanes % group || (frames && !frame_seeds))
-        return PSM_ERR_INVALID;
-    if (!fold_into) return PSM_ERR_INVALID;
-    for (uint32_t s = 0; s < lanes; s++) {
-        if (!rts[s] || !bvhs[s]) return PSM_ERR_INVALID;
-        for (uint32_t q = 0; q < s; q++)
-            if (rts[q] == rts[s] || rts[q]->ctx->stream == rts[s]->ctx->stream)
-                return set_err(rts[s]->ctx, PSM_ERR_INVALID, "psm_lanes_render_grouped: every lane needs its own context (stream) and ray buffers");
-        if (rts[s]->ctx != bvhs[s]->ctx)
-            return set_err(rts[s]->ctx, PSM_ERR_INVALID, "psm_lanes_render_grouped: a lane's hierarchy must live on the lane's context");
-        if (fold_into->w != rts[s]->w || fold_into->h != rts[s]->h)
-            return set_err(rts[s]->ctx, PSM_ERR_INVALID, "psm_lanes_render_grouped: fold_into and the lanes differ in ray-grid size");
-        int e = lane_resources(rts[s]);
-        if (e != PSM_OK) return e;
-    }
-    if (frames == 0) return PSM_OK;
-    (void)hipSetDevice(rts[0]->ctx->device);
-    const uint32_t ngroups = lanes / group;
-    for (uint32_t s = 0; s < lanes; s++) rts[s]->in_flight = lanes;
-    struct LaneS { uint32_t rand = 0, round = 0; uint64_t rays = 0; bool active = false; };
-    struct Grp { LaneState state = IDLE; uint32_t f0 = 0, nf = 0; hipEvent_t ev_trav = nullptr; };
-    std::vector<LaneS> L(lanes);
-    std::vector<Grp> G(ngroups);
-    int rc = PSM_OK;
-    for (uint32_t g = 0; g < ngroups && rc == PSM_OK; g++)
-        if (hipEventCreateWithFlags(&G[g].ev_trav, hipEventDisableTiming) != hipSuccess) rc = set_err(rts[0]->ctx, PSM_ERR_HIP, "psm_lanes_render_grouped: event");
-    // one round of group g: ONE traversal launch over the queues of its frames that go on, then every such frame's shade
-    auto issue_round = [&](uint32_t g) -> int {
-        Grp& gr = G[g];
-        psm_rt* act_rt[8];
-        psm_bvh* act_bvh[8];
-        uint32_t act_s[8], na = 0;
-        for (uint32_t k = 0; k < gr.nf; k++) {
-            const uint32_t s = g * group + k;
-            LaneS& ln = L[s];
-            ln.active = ln.active && ln.round < depth && rts[s]->ray_count >= 32;   // Pipeline.inl:459-461, Viewer.cpp:304-310
-            if (ln.active) { act_rt[na] = rts[s]; act_bvh[na] = bvhs[s]; act_s[na] = s; na++; }
-        }
-        if (na == 0) {
-            gr.state = FINISHED;
-            if (results)
-                for (uint32_t k = 0; k < gr.nf; k++) { results[gr.f0 + k].rounds = L[g * group + k].round; results[gr.f0 + k].rays = L[g * group + k].rays; }
-            return PSM_OK;
-        }
-        psm_ctx* lead = rts[g * group]->ctx;   // the group's launches go to its first lane's stream
-        for (uint32_t a = 0; a < na; a++) {    // ... after the frames' cameras / shades
-            psm_rt* r = act_rt[a];
-            if (r->ctx == lead) continue;
-            PSM_HIP(lead, hipEventRecord(r->ev_fold, r->ctx->stream));
-            PSM_HIP(lead, hipStreamWaitEvent(lead->stream, r->ev_fold, 0));
-        }
-        int e = psm_rt_traverse_group_owned(act_rt, act_bvh, na, lead, rts[g * group]);
-        if (e != PSM_OK) return e;
-        PSM_HIP(lead, hipEventRecord(gr.ev_trav, lead->stream));
-        for (uint32_t a = 0; a < na; a++) {
-            psm_rt* r = act_rt[a];
-            LaneS& ln = L[act_s[a]];
-            ln.rays += r->ray_count;
-            if (r->ctx != lead) PSM_HIP(lead, hipStreamWaitEvent(r->ctx->stream, gr.ev_trav, 0));
-            e = psm_rt_shade(r, act_bvh[a], lcg_next(ln.rand));
-            if (e != PSM_OK) return e;
-            ln.round++;
-            PSM_HIP(r->ctx, hipEventRecord(r->ev_cnt, r->ctx->stream));   // rt_scan_blocks has put the next count into h_cnt
-        }
-        // the lead stream must not run the next round's launch before the other lanes' shades have read this round's hits:
-        // the next issue_round makes it wait for their streams again (events above), which covers it
-        gr.state = RUNNING;
-        return PSM_OK;
-    };
-    auto start = [&](uint32_t g, uint32_t f0, uint32_t nf) -> int {
-        Grp& gr = G[g];
-        gr.f0 = f0; gr.nf = nf;
-        for (uint32_t k = 0; k < nf; k++) {
-            const uint32_t s = g * group + k;
-            LaneS& ln = L[s];
-            ln.rand = frame_seeds[f0 + k];
-            ln.round = 0;
-            ln.rays = 0;
-            if (rebuild) {
-                int e = psm_bvh_build(bvhs[s], opt);
-                if (e != PSM_OK) return e;
-            }
-            int e = psm_rt_camera(rts[s], cam_inv, proj_inv, lcg_next(ln.rand));
-            if (e != PSM_OK) return e;
-            ln.active = depth > 0;
-        }
-        return issue_round(g);
-    };
-    uint32_t next_frame = 0, next_fold = 0, idle_spins = 0;
-    while (rc == PSM_OK && next_fold < frames) {
-        bool progressed = false;
-        for (uint32_t g = 0; g < ngroups && rc == PSM_OK; g++) {
-            Grp& gr = G[g];
-            if (gr.state == IDLE && next_frame < frames) {
-                const uint32_t nf = std::min(group, frames - next_frame);
-                rc = start(g, next_frame, nf);
-                next_frame += nf;
-                progressed = true;
-            } else if (gr.state == RUNNING) {
-                bool ready = true;
-                for (uint32_t k = 0; k < gr.nf && ready; k++) {
-                    const uint32_t s = g * group + k;
-                    if (!L[s].active) continue;
-                    hipError_t q = hipEventQuery(rts[s]->ev_cnt);
-                    if (q == hipErrorNotReady) ready = false;
-                    else if (q != hipSuccess) { rc = set_err(rts[s]->ctx, PSM_ERR_HIP, "hipEventQuery", q); ready = false; }
-                }
-                if (!ready || rc != PSM_OK) continue;
-                for (uint32_t k = 0; k < gr.nf; k++) {
-                    const uint32_t s = g * group + k;
-                    if (!L[s].active) continue;
-                    rts[s]->ray_count = *rts[s]->h_cnt;   // what reloadQueuedRays learns (Pipeline.inl:325-359)
-                    rts[s]->count_valid = true;
-                }
-                rc = issue_round(g);
-                progressed = true;
-            }
-        }
-        // sample() in frame order
-        for (bool again = true; again && rc == PSM_OK;) {
-            again = false;
-            for (uint32_t g = 0; g < ngroups && rc == PSM_OK; g++) {
-                Grp& gr = G[g];
-                if (gr.state != FINISHED || gr.f0 != next_fold) continue;
-                for (uint32_t k = 0; k < gr.nf && rc == PSM_OK; k++) rc = fold(fold_into, rts[g * group + k]);
-                next_fold += gr.nf;
-                gr.state = IDLE;
-                again = progressed = true;
-            }
-        }
-        if (!progressed) {
-            if (++idle_spins > 256) std::this_thread::yield();
-        } else {
-            idle_spins = 0;
-        }
-    }
-    for (uint32_t s = 0; s < lanes; s++) {
-        (void)hipStreamSynchronize(rts[s]->ctx->stream);
-        rts[s]->in_flight = 1;
-    }
-    (void)hipStreamSynchronize(fold_into->ctx->stream);
-    for (uint32_t g = 0; g < ngroups; g++)
-        if (G[g].ev_trav) (void)hipEventDestroy(G[g].ev_trav);
-    return rc;
-}
-#endif   // PSM_EXPERIMENTAL (split frames, grouped launches)

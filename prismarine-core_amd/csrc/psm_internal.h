@@ -141,26 +141,12 @@ struct psm_ctx {
     int sort_algorithm = 2;             // 2 (default): hybrid -- two global passes over the top sixteen key bits, the rest in LDS; 0: histogram / scan / scatter kernels for all eight passes; 1: one-sweep
     uint32_t* sort_overflow = nullptr;  // pinned host word a hybrid sort raises when a chunk did not fit LDS (sorted through global memory: correct, slow)
     bool sort_demoted = false;          // ... seen raised: hybrid sorts of this context run as algorithm 0 from then on (psm_sort_set_algorithm clears it)
-    uint32_t sort_hybrid_s_small = 1024, sort_hybrid_s_large = 2048, sort_hybrid_threads = 1024;  // radix_local's stretch per workgroup and its width (psm_sort_tune)
+    uint32_t sort_hybrid_s_small = 1024, sort_hybrid_s_large = 2048, sort_hybrid_threads = 1024, sort_hybrid_cap_small = 4096, sort_hybrid_cap_large = 4096;  // radix_local's stretch per workgroup, its width and its LDS capacity in keys (PSM_SORT_TUNE)
     uint32_t* sort_error_word = nullptr; // device word the look-back raises on a spin timeout
-};
-
-// Traversal records of several hierarchies in ONE allocation (psm_arena_create): slot k holds the node records and the
-// triangle records of one hierarchy, and the links / triangle ids inside the node records count from the start of the
-// arena. One traversal launch can then walk rays of several hierarchies -- several frames in flight, each with its own
-// rebuilt hierarchy -- from two scalar base pointers (psm_rt_traverse_group, trace.hip).
-struct psm_arena {
-    psm_ctx* ctx = nullptr;
-    uint32_t slots = 0;
-    size_t max_tris = 0;
-    uint4* d_node32 = nullptr;   // slots x 2 * max_tris
-    float4* d_tri48 = nullptr;   // slots x 3 * max_tris
 };
 
 struct psm_bvh {
     psm_ctx* ctx = nullptr;
-    psm_arena* arena = nullptr;   // d_node32 / d_tri48 are slices of this arena (not freed with the hierarchy)
-    uint32_t node_off = 0, tri_off = 0;  // what the slot adds to child links / triangle ids in the node records
     size_t cap = 0;
     uint32_t tri_count = 0;
     bool built = false, bounds_done = false, morton_done = false, sort_done = false;
@@ -202,8 +188,6 @@ struct psm_rt {
     uint32_t tile_mode = 0, tile_rank = 0, tile_world = 1;  // 0: rows [y0,y1); 1: the 8-row bands `bands` deals to tile_rank
     psm::BandMap bands;           // mode 1: the dealing (psm_rt_set_tile_interleaved / _weighted)
     bool tile_root = true;        // this Pipeline samples the whole image: camera() also fills the texels it does not own
-    bool texels_shared = false;   // t_coord / t_sum / t_flag belong to another Pipeline (psm_rt_share_texels): not freed here
-    bool texels_lent = false;     // ... or are written by other Pipelines too: camera() leaves the texels it does not own alone
     uint32_t limit = 0;           // currentRayLimit
     int cur = 0;                  // current queue index
     uint32_t ray_count = 0;       // host mirror of the current queue length (valid after sync points)
@@ -250,7 +234,6 @@ struct psm_rt {
     int phase_caps_n = 1;
     int trav_mode = 0;              // PSM_TRAVERSE_* (psm_rt_set_traverse_mode); 0 = automatic
     uint32_t adapt_min_live = 12, adapt_min_steps = 8, adapt_final_rays = 65536, adapt_max_launches = 4;  // tuned on C3, 4 frames in flight (its 2 M-ray rounds plan three launches either way; C5's 8 M-ray rounds take the fourth: -1.3 %)
-    uint32_t refill_min = 32, refill_waves_per_cu = 28, refill_min_rays = 1u << 15;  // PSM_TRAVERSE_REFILL (trace.hip)
     bool mats_ordinary = true;      // no material whose dropped lobe's colour can be NaN (psm_rt_set_materials): rt_shade builds one lobe per hit
     uint32_t solo_max = 1;          // a traversal wave with at most this many rays left walks them one by one, all lanes on one ray (trace.hip: solo_ray); 0: never. 1: a frame alone 3.37 -> 3.20 ms, a 1/8 tile 0.633 -> 0.611, 4 frames in flight 2.21 -> 2.19; 2: 3.24 / 0.620 / 2.19 (profiles/r04_solo_gear.txt)
     uint32_t in_flight = 1;         // lanes this Pipeline is currently scheduled with (lanes.hip)
@@ -314,7 +297,6 @@ int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
 int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views);
 int launch_rt_camera(psm_rt* r, const float* cam_inv, const float* proj_inv, uint32_t time);
 int launch_rt_traverse(psm_rt* r, psm_bvh* b);
-int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner);
 int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time);
 int launch_rt_sample(psm_rt* r, psm_rt* src);
 // pack / unpack the dense tile of rows [a, b) (bands == NULL) or of rank a in the dealing `bands`

@@ -899,10 +899,7 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
     ShadeArgs a;
     a.q = current_queue(r);
     a.hit0 = r->hit0; a.hitN = r->hitN; a.pool = r->pool;
-    // hits of a hierarchy in an arena slot carry arena-wide triangle ids: the arrays are handed over shifted back by the slot's
-    // first triangle, so that the kernel indexes them with the id as recorded
-    const size_t t0 = b->tri_off;
-    a.src.tri48 = b->d_tri48 - 3 * t0; a.src.nrm = b->d_nrm - 9 * t0; a.src.tri_mats = b->d_mats - t0; a.src.uv = b->d_tex - 6 * t0;
+    a.src.tri48 = b->d_tri48; a.src.nrm = b->d_nrm; a.src.tri_mats = b->d_mats; a.src.uv = b->d_tex;
     a.src.mats = r->d_mats; a.src.tex = r->d_tex_table; a.lights = r->d_lights;
     const int nxt_q = r->cur ^ 1;
     a.sA = r->qA[nxt_q]; a.sB = r->qB[nxt_q]; a.sC = r->qC[nxt_q];  // every workgroup writes its own segment of the next queue
@@ -920,8 +917,7 @@ int launch_rt_shade(psm_rt* r, psm_bvh* b, uint32_t time) {
         for (int i = 0; i < r->trav_n; i++)
         {
             const psm_bvh* o = r->trav_objs[i];
-            const size_t o0 = o->tri_off;
-            g[i] = ObjGeom{o->d_tri48 - 3 * o0, o->d_nrm - 9 * o0, o->d_mats - o0, o->d_tex - 6 * o0};
+            g[i] = ObjGeom{o->d_tri48, o->d_nrm, o->d_mats, o->d_tex};
         }
         PSM_HIP(c, hipMemcpyAsync(r->d_geoms, g, sizeof(g), hipMemcpyHostToDevice, c->stream));
         PSM_HIP(c, hipStreamSynchronize(c->stream));

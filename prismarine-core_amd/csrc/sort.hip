@@ -460,8 +460,9 @@ PSM_D void local_slow(LocalLds<CAP, THREADS>& S, uint64_t* keys, uint32_t* vals,
     }
 }
 
+// (second launch bound: waves per SIMD such that two workgroups share a CU while their LDS allows it -- CAP <= 5120 keys)
 template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void radix_local(uint64_t* keys, uint32_t* vals, uint64_t* altk, uint32_t* altv,
+__global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) void radix_local(uint64_t* keys, uint32_t* vals, uint64_t* altk, uint32_t* altv,
                                                        uint32_t n_max, const uint32_t* __restrict__ d_n, uint32_t S, int pshift,
                                                        uint32_t* overflow) {
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
@@ -710,29 +711,31 @@ static int sort_hybrid(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
         PSM_HIP(c, hipHostMalloc((void**)&c->sort_overflow, sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
         *c->sort_overflow = 0u;
     }
-    constexpr uint32_t CAP = 4096;
-    if (n_max <= CAP) {   // one chunk: no global pass (pshift 64: every key in bin 0)
+    if (n_max <= 4096u) {   // one chunk: no global pass (pshift 64: every key in bin 0)
         { int rc = sort_buffers(c, n_max, 256); if (rc != PSM_OK) return rc; }
-        radix_local<CAP, 1024><<<1, 1024, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, CAP, 64, nullptr);
+        radix_local<4096, 1024><<<1, 1024, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, 4096u, 64, nullptr);
         PSM_HIP(c, hipGetLastError());
         return PSM_OK;
     }
     const int pshift = key_bits - 16;
-    int rc = n_max <= (1u << 19) ? sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n, pshift, 2)
-                                 : sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n, pshift, 2);
+    const bool small = n_max <= (1u << 19);
+    int rc = small ? sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n, pshift, 2)
+                   : sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n, pshift, 2);
     if (rc != PSM_OK) return rc;
-    // S: the stretch of bin starts a workgroup takes; a chunk fits LDS while no bin is longer than CAP - S. Small sorts take short
-    // stretches: as many workgroups as the chip has CUs matter more there than keys per workgroup
-    const uint32_t S = n_max <= (1u << 19) ? c->sort_hybrid_s_small : c->sort_hybrid_s_large;
+    // S: the stretch of bin starts a workgroup takes; a chunk fits LDS (CAP keys) while no bin is longer than CAP - S. Small sorts
+    // take short stretches: as many workgroups as the chip has CUs matter more there than keys per workgroup
+    const uint32_t S = small ? c->sort_hybrid_s_small : c->sort_hybrid_s_large;
+    const uint32_t cap = small ? c->sort_hybrid_cap_small : c->sort_hybrid_cap_large, threads = c->sort_hybrid_threads;
     const uint32_t grid = (uint32_t)((n_max + S - 1) / S);
-    if (c->sort_hybrid_threads == 256)
-        radix_local<CAP, 256><<<grid, 256, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow);
-    else if (c->sort_hybrid_threads == 512)
-        radix_local<CAP, 512><<<grid, 512, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow);
-    else
-        radix_local<CAP, 1024><<<grid, 1024, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow);
-    PSM_HIP(c, hipGetLastError());
-    return PSM_OK;
+#define PSM_LOCAL(CAP_, TH_) \
+    if (cap == CAP_ && threads == TH_) { \
+        radix_local<CAP_, TH_><<<grid, TH_, 0, c->stream>>>(d_keys, d_vals, c->sort_keys_tmp, c->sort_vals_tmp, (uint32_t)n_max, d_n, S, pshift, c->sort_overflow); \
+        PSM_HIP(c, hipGetLastError()); \
+        return PSM_OK; \
+    }
+    PSM_LOCAL(4096, 1024) PSM_LOCAL(4096, 512) PSM_LOCAL(5120, 1024) PSM_LOCAL(5120, 512) PSM_LOCAL(6144, 1024) PSM_LOCAL(6144, 512) PSM_LOCAL(8192, 1024)
+#undef PSM_LOCAL
+    return set_err(c, PSM_ERR_INVALID, "hybrid sort: no radix_local of this shape");
 }
 
 template <int ITEMS>

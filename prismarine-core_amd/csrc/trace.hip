@@ -307,23 +307,7 @@ PSM_D void solo_ray(const int L, const uint32_t* __restrict__ node_dw, const flo
 // the rest -- result arrays, counters, the hand-over state -- are read where they are used, through the kernarg
 // segment, behind an opaque move (cold_args): held in scalar registers from the kernel's entry they would cost the
 // loop ~30 SGPRs, whose spills take two VGPRs from a kernel that is allowed 64 (8 waves per SIMD).
-// GROUP: one launch over the current ray queues of several Pipelines (several frames in flight, each with its own rebuilt
-// hierarchy in a slot of one psm_arena, so that the node and triangle records of all of them hang off the same two base
-// pointers and their links are arena-wide). The rays of queue k are the launch's rays first[k] .. first[k] + nrays[k] - 1;
-// a ray finds its queue, its hierarchy's small block (transform, root) and its result arrays through this table -- in the
-// set-up and in the result write only; the node steps and triangle tests do not know about it.
 constexpr size_t MAX_PHASES = 16;   // launches of a hand-over round at most; two sets of continuation counts alternate between rounds
-constexpr int MAX_GROUP = 8;
-struct GroupQueue {
-    const float4 *qA, *qB;
-    const uint32_t* qbases;
-    const uint32_t* sm;
-    float4* hit0;
-    uint32_t* hitN;
-    float4* pool;
-    uint32_t* cnt;
-    uint32_t qnb, nrays, first, pool_cap;
-};
 
 struct TravArgs {
     const float4 *qA, *qB;        // hot
@@ -347,8 +331,6 @@ struct TravArgs {
     TravState in, out;
     uint32_t* out_count;
     uint32_t* zero_cnt;           // the last launch of a hand-over round clears the OTHER set of continuation counts (next round's)
-    uint32_t gn;                  // GROUP: queues in the table
-    GroupQueue gq[MAX_GROUP];
 };
 
 PSM_D const TravArgs* cold_args() {
@@ -357,7 +339,7 @@ PSM_D const TravArgs* cold_args() {
     return (const TravArgs*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + zero);
 }
 
-template <bool COUNT, bool CHAIN, bool PHASED, bool GROUP = false>
+template <bool COUNT, bool CHAIN, bool PHASED>
 __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const float4* __restrict__ qA = ka.qA;
     const float4* __restrict__ qB = ka.qB;
@@ -365,7 +347,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     const uint32_t qnb = ka.qnb;
     // never past what the queue holds: a host-supplied count (psm_rt_set_ray_count) larger than the queue's total would
     // resolve to slots beyond its last segment
-    const uint32_t nrays = GROUP ? ka.nrays : min(ka.nrays, qbases[qnb]);   // (GROUP: clamped per queue below)
+    const uint32_t nrays = min(ka.nrays, qbases[qnb]);
     const uint4* __restrict__ node32 = ka.node32;
     const float4* __restrict__ tri48 = ka.tri48;
     const uint32_t* __restrict__ sm = ka.sm;
@@ -393,7 +375,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
         uint32_t* z = cold_args()->zero_cnt;
         if (z) z[tid] = 0u;
     }
-    int root = GROUP ? -1 : (int)sm[SM_ROOT];
+    const int root = (int)sm[SM_ROOT];
     // fresh rays: one ray per thread of the grid. Workgroups b and b + 8 of a grid share an XCD (round-robin dispatch,
     // observed, a speed matter only) and each XCD has its own 4 MB L2: the grid is dealt so that an XCD walks runs of
     // XCD_RUN consecutive workgroups' rays (4096 rays: two rows of texels, neighbouring parts of the tree), the runs
@@ -413,25 +395,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
 
     float4 A = make_float4(0, 0, 0, 0), B = make_float4(1, 0, 0, 0);
     float M[16];
-    if (GROUP) {
-        // the ray's queue: the last k with first[k] <= i (the table is in the kernarg segment; per-lane reads of it). `i`
-        // stays the ray's index in the LAUNCH (what a hand-over records); the result write looks the queue up again, so
-        // that nothing but `i` lives across the loop
-        const TravArgs* K = cold_args();
-        uint32_t gq_k = 0;
-        for (uint32_t k = 1; k < K->gn; k++) gq_k += (i >= K->gq[k].first) ? 1u : 0u;
-        const GroupQueue* Q = &K->gq[gq_k];
-        const uint32_t* __restrict__ qsm = Q->sm;
-        if (alive && (i - Q->first) >= Q->qbases[Q->qnb]) alive = false;   // never past what the ray's queue holds
-        if (alive) {
-            const uint32_t loc = queue_loc(Q->qbases, Q->qnb, min(Q->nrays, Q->qbases[Q->qnb]), i - Q->first);
-            A = Q->qA[loc];
-            B = Q->qB[loc];
-            root = (int)qsm[SM_ROOT];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) M[k] = alive ? u2f(qsm[SM_M + k]) : 0.f;
-    } else {
+    {
         const uint32_t loc = alive ? queue_loc(qbases, qnb, nrays, i) : 0u;  // the queue is segmented (psm_common.h)
         if (alive) { A = ld_stream(&qA[loc]); B = ld_stream(&qB[loc]); }
 #pragma unroll
@@ -680,17 +644,12 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     }
     if (PHASED && suspendedFlag) alive = false;  // handed over
     const TravArgs* K = cold_args();
-    uint32_t gq_k = 0;
-    if (GROUP) {   // the ray's own Pipeline again, and its index there
-        for (uint32_t k = 1; k < K->gn; k++) gq_k += (i >= K->gq[k].first) ? 1u : 0u;
-        i -= alive ? K->gq[gq_k].first : 0u;
-    }
-    float4* __restrict__ hit0 = GROUP ? K->gq[gq_k].hit0 : K->hit0;
-    uint32_t* __restrict__ hitN = GROUP ? K->gq[gq_k].hitN : K->hitN;
-    float4* __restrict__ pool = GROUP ? K->gq[gq_k].pool : K->pool;
-    uint32_t* __restrict__ cnt = GROUP ? K->gq[gq_k].cnt : K->cnt;
+    float4* __restrict__ hit0 = K->hit0;
+    uint32_t* __restrict__ hitN = K->hitN;
+    float4* __restrict__ pool = K->pool;
+    uint32_t* __restrict__ cnt = K->cnt;
     DevCounters* __restrict__ ctr = K->ctr;
-    const uint32_t pool_cap = GROUP ? K->gq[gq_k].pool_cap : K->pool_cap, obj_tag = K->obj_tag;
+    const uint32_t pool_cap = K->pool_cap, obj_tag = K->obj_tag;
 
     if (CHAIN) {
         if (alive && bakedCount > 0) {
@@ -802,281 +761,15 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     }
 }
 
-#if PSM_EXPERIMENTAL
-// ---- REFILL: persistent waves that take new rays in batches --------------------------------------------------------
-//
-// The schedules above fix which 64 rays a wave traces; a wave64 then steps as long as its slowest ray and half of every
-// issued vector instruction is masked off (VALU lane utilisation 0.37 single launch, 0.50 with the hand-over). Here the
-// grid is a fixed set of waves and the round's rays are a pool behind one atomic counter: a lane whose ray has ended
-// waits -- its result in registers -- until at least `refill_min` lanes of its wave are idle (or nobody has work left);
-// then the idle lanes write their results, the wave takes that many new rays from the pool with ONE atomic, and the
-// idle lanes run the ray set-up together. So the set-up and the result write always run with a good part of the wave
-// (the first persistent kernel of round 1 refilled lane by lane: its set-up passes ran with a handful of lanes, and it
-// lost), the box steps run with at least 64 - refill_min + 1 lanes with work until the pool is dry, and no state is
-// ever written to memory as the hand-over does. Per ray nothing changes: the same set-up, node steps and triangle tests
-// in the same order (same code: ray_setup / the step / ray_result below are the pieces of rt_traverse), so hits, chains
-// and counters are bit-exact (test_every_traversal_schedule_is_bit_exact).
-//
-// MEASURED (round 3, C3): it loses. 3.24 ms per frame with 4 frames in flight (refill_min 32-40) against
-// 2.48 for the hand-over schedule; 4.9 against 3.74 ms for a frame alone. The counters say why: wave-steps per frame
-// drop by 18 % against the single launch (the hand-over: 28 %) -- lanes wait idle until 32 are idle, and a quarter of the
-// lanes with work are parked for a leaf test at any time whatever the schedule, so the ceiling of the node steps' lane
-// utilisation is ~0.75 x the live share -- while every wave-step gets slower (1.43 G wave-steps/s against 1.74: more
-// live lanes per load, a refill's chain of dependent loads -- counter, segment search, ray -- stalls the wave, and the
-// state carried across the refill costs one wave per SIMD: 72 VGPRs). A lower threshold refills more often and is
-// slower still (16: 4.3 ms, 8: 6.8 ms). Kept selectable and under the parity tests; not a default.
-struct RayLane {          // one lane's ray in flight
-    v3 origin, direct;    // world space (triangle tests)
-    v3 divident, norig;   // slab test constants
-    float dirlenInv, hitMax, toffset, predist;
-    Baked head;
-    int lastTri, bakedCount, cur, sp, it;
-};
-
-// the part of rt_traverse between the queue read and the loop, :333-378
-PSM_D bool ray_setup(RayLane& s, const float4 A, const float4 B, const uint32_t* __restrict__ sm, int root) {
-    s.origin = mk3(A.x, A.y, A.z);
-    s.direct = normalize3(mk3(B.x, B.y, B.z));  // :350
-    float M[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M[k] = u2f(sm[SM_M + k]);
-    float to4[4], td4[4];
-    mat_vec(M, s.origin.x, s.origin.y, s.origin.z, 1.0f, to4);   // :353
-    matT_vec(M, s.direct.x, s.direct.y, s.direct.z, 1.0f, td4);  // :354
-    v3 torig = mk3(to4[0], to4[1], to4[2]);
-    v3 tdir = mk3(td4[0], td4[1], td4[2]);
-    float dirlen = len3(tdir) / pmax(len3(s.direct), 0.000001f);
-    s.dirlenInv = 1.f / pmax(dirlen, 0.000001f);
-    s.hitMax = hit_limit(s.dirlenInv);
-    v3 dirproj = normalize3(tdir);
-    float rootNear, rootD;
-    {   // root slab test, intersectCubeSingle (mathlib.glsl:107-126) against [-1e-5, 1+1e-5]^3, :365
-        v3 dr = mk3(1.0f / dirproj.x, 1.0f / dirproj.y, 1.0f / dirproj.z);
-        v3 no = mk3(-torig.x * dr.x, -torig.y * dr.y, -torig.z * dr.z);
-        const float lo = -0.00001f, hi = 1.00001f;
-        float a0 = fmaf(lo, dr.x, no.x), a1 = fmaf(hi, dr.x, no.x);
-        float b0 = fmaf(lo, dr.y, no.y), b1 = fmaf(hi, dr.y, no.y);
-        float c0 = fmaf(lo, dr.z, no.z), c1 = fmaf(hi, dr.z, no.z);
-        float tNear = smaxf(smaxf(sminf(a0, a1), sminf(b0, b1)), sminf(c0, c1));
-        float tFar = sminf(sminf(smaxf(a0, a1), smaxf(b0, b1)), smaxf(c0, c1));
-        bool isCube = greaterEqualF(tFar, tNear) && greaterEqualF(tFar, 0.0f);
-        float nr = isCube ? sminf(tNear, tFar) : INF;
-        float fr = isCube ? smaxf(tNear, tFar) : INF;
-        rootNear = nr;
-        rootD = isCube ? (lessF(nr, 0.0f) ? fr : nr) : INF;
-    }
-    s.toffset = smaxf(rootNear, 0.f);
-    v3 origined = mk3(torig.x + dirproj.x * s.toffset, torig.y + dirproj.y * s.toffset, torig.z + dirproj.z * s.toffset);
-    s.divident = mk3(1.f / dirproj.x, 1.f / dirproj.y, 1.f / dirproj.z);
-    s.norig = mk3(-origined.x * s.divident.x, -origined.y * s.divident.y, -origined.z * s.divident.z);
-    s.predist = INF;
-    s.lastTri = -1;
-    s.bakedCount = 0;
-    s.head = Baked{0.f, 0.f, INF, -1};
-    s.cur = root;
-    s.sp = 0;
-    s.it = 0;
-    return root >= 0 && lessF(rootD, INF) && lessF(rootD * s.dirlenInv, INF) && greaterEqualF(rootD, 0.0f);
-}
-
-// the end of rt_traverse for a first traversal (no CHAIN): reorderTriangles (:74-112) + the hit record
-template <bool COUNT>
-PSM_D void ray_result(uint32_t i, Baked head, const Baked* extra, int bakedCount, float4* __restrict__ hit0, uint32_t* __restrict__ hitN,
-                      float4* __restrict__ pool, uint32_t* __restrict__ cnt, DevCounters* __restrict__ ctr, uint32_t pool_cap) {
-    uint32_t count = 0, off = 0;
-    if (bakedCount <= 1) {
-        count = (uint32_t)bakedCount;  // reorderTriangles is the identity on 0/1 entries
-    } else {
-        Baked bk[BAKED_CAP];
-        int n = bakedCount > BAKED_CAP ? BAKED_CAP : bakedCount;
-        bk[0] = head;
-        for (int k = 1; k < n; k++) bk[k] = extra[k - 1];
-        for (int iround = 1; iround < n; iround++) {
-            for (int index = 0; index < n - iround; index++) {
-                Baked a = bk[index], b = bk[index + 1];
-                bool lessIdx = a.tri <= b.tri;
-                bool deeper = lessF(a.t, b.t);
-                if (lessIdx || deeper) { bk[index] = b; bk[index + 1] = a; }
-            }
-        }
-        int clean = 0;
-        for (int iround = 0; iround < BAKED_CAP; iround++) {
-            if (iround >= n - 1) break;
-            if (bk[iround + 1].tri != bk[iround].tri) bk[clean++] = bk[iround];
-        }
-        if (n > 0 && clean <= BAKED_CAP) bk[clean++] = bk[n - 1];
-        head = bk[0];
-        count = (uint32_t)clean;
-        if (count > 1) {
-            off = atomicAdd(&cnt[2], count - 1);
-            if (off + (count - 1) > pool_cap) {
-                if (COUNT) atomicAdd(&ctr->chain_pool_drops, 1ull);
-                count = 1;
-            } else {
-                for (uint32_t k = 1; k < count; k++)
-                    pool[off + k - 1] = make_float4(bk[k].u, bk[k].v, bk[k].t, __int_as_float(bk[k].tri));
-            }
-        }
-    }
-    if (count == 0) hit0[i] = make_float4(0.f, 0.f, INF, __int_as_float(-1));
-    else hit0[i] = make_float4(head.u, head.v, head.t, __int_as_float(head.tri));
-    hitN[i] = count | (off << 4);
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(TRAV_BLOCK, 7) void rt_traverse_refill(TravArgs ka) {
-    // hot: what the node step and the triangle tests read. Everything a refill needs (queue, counter, result arrays, the
-    // hierarchy's small block) is read there through the kernarg segment (cold_args), so that it does not occupy scalar
-    // registers -- and, spilled, vector registers -- across the loop.
-    const uint4* __restrict__ node32 = ka.node32;
-    const float4* __restrict__ tri48 = ka.tri48;
-    const uint32_t refill_min = ka.min_live;     // idle lanes that trigger a refill
-    __shared__ int stack[STACK_CAP][TRAV_BLOCK];
-    const int tid = threadIdx.x;
-    uint32_t nV = 0, nT = 0, nDrop = 0, nCap = 0, nBakedDrop = 0;
-    unsigned long long dg_t0 = 0, dg_r0 = 0, dg_steps = 0;
-    if (COUNT) { dg_t0 = __builtin_amdgcn_s_memtime(); dg_r0 = __builtin_amdgcn_s_memrealtime(); }
-
-    RayLane s = {};
-    Baked extra[BAKED_CAP - 1];
-    int ray = -1;                 // index of the lane's ray in the queue; -1: the lane holds none
-    bool validBox = false;        // the ray has node steps left
-    bool parkedNow = false;       // ... or waits for its leaf tests
-    bool pLeftNear = false;
-    int pl = 0, pr = 0;
-    bool exhausted = false;       // wave-uniform: the pool has nothing left for this wave
-    for (;;) {
-        const bool working = validBox || parkedNow;
-        const unsigned long long idle = lane_mask(!working);
-        const uint32_t nidle = (uint32_t)__popcll(idle);
-        if ((!exhausted && nidle >= refill_min) || nidle == 64u) {
-            const TravArgs* K = cold_args();
-            if (!working && ray >= 0) {   // results of the rays that have ended since the last refill
-                ray_result<COUNT>((uint32_t)ray, s.head, extra, s.bakedCount, K->hit0, K->hitN, K->pool, K->cnt, K->ctr, K->pool_cap);
-                ray = -1;
-            }
-            if (exhausted) break;         // nobody has work and the pool is dry
-            const uint32_t* __restrict__ qbases = K->qbases;
-            const uint32_t qnb = K->qnb;
-            const uint32_t total = min(K->nrays, qbases[qnb]);   // never past what the queue holds
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)idle) - 1;
-            if (lane_id() == leader) base = atomicAdd(K->out_count, nidle);
-            base = __shfl(base, leader);
-            exhausted = base + nidle >= total;    // wave-uniform: this batch reaches the end of the pool
-            const uint32_t mine = base + (uint32_t)__popcll(idle & lanemask_lt());
-            if (!working && mine < total) {
-                const uint32_t loc = queue_loc(qbases, qnb, total, mine);  // the queue is segmented (psm_common.h)
-                const float4 A = K->qA[loc], B = K->qB[loc];
-                const uint32_t* __restrict__ sm = K->sm;
-                ray = (int)mine;
-                validBox = ray_setup(s, A, B, sm, (int)sm[SM_ROOT]);
-                pl = 0; pr = 0;
-            }
-            continue;   // (a batch of rays that all miss the root box: straight to the next refill)
-        }
-        if (validBox && !parkedNow) {   // the node step: rt_traverse's, field for field
-            const bool lastIter = s.it >= MAX_ITERS - 1;  // :383
-            s.it++;
-            const uint4* np = (const uint4*)((const char*)node32 + ((uint32_t)s.cur << 5));
-            uint4 n0 = np[0], n1 = np[1];
-            int2 lk = make_int2((int)n1.z, (int)n1.w);
-            if (COUNT) nV++;
-            Slab L = slab_child(s.divident, s.norig, half_lo(n0.x), half_hi(n0.x), half_lo(n0.y), half_hi(n0.y), half_lo(n0.z), half_hi(n0.z));
-            Slab R = slab_child(s.divident, s.norig, half_lo(n0.w), half_hi(n0.w), half_lo(n1.x), half_hi(n1.x), half_lo(n1.y), half_hi(n1.y));
-            const bool leftNear = lessEqualF(L.near, R.near);  // :414
-            const bool ogL = child_ok(L, s.hitMax, s.dirlenInv, s.toffset, s.predist), ogR = child_ok(R, s.hitMax, s.dirlenInv, s.toffset, s.predist);
-            const bool lfL = lk.x < 0, lfR = lk.y < 0;
-            const bool leafL = ogL && lfL, leafR = ogR && lfR;
-            pl = leafL ? lk.x : 0;   // accepted leaves, :441-448
-            pr = leafR ? lk.y : 0;
-            pLeftNear = leftNear;
-            parkedNow = leafL || leafR;
-            const bool intL = ogL != leafL, intR = ogR != leafR;
-            const bool leftFirst = intL && (leftNear || !intR);  // :451-462
-            const int first = leftFirst ? lk.x : lk.y, second = leftFirst ? lk.y : lk.x;
-            if (intL && intR && (lk.x != lk.y)) {
-                if (s.sp < STACK_CAP) stack[s.sp++][tid] = second;
-                else if (COUNT) nDrop++;
-            }
-            s.cur = first;
-            if (!(intL || intR)) {    // :467-476
-                s.sp--;
-                if (s.sp >= 0) s.cur = stack[s.sp][tid];
-                else validBox = false;
-            }
-            const bool capped = validBox && lastIter;
-            validBox = validBox && !capped;
-            if (COUNT) nCap += capped ? 1u : 0u;
-        }
-        const uint32_t npk = (uint32_t)__popcll(lane_mask(parkedNow));
-        const uint32_t nl = npk + (uint32_t)__popcll(lane_mask(validBox && !parkedNow));
-        if (COUNT) dg_steps++;
-        // keep stepping the others while fewer than half of the lanes with work wait for a leaf test
-        if (2u * npk < nl) continue;
-        if (parkedNow) {  // testIntersectionPacked, :261-309
-            const bool lo = (pl < 0) && (pLeftNear || pr >= 0);
-            const int tx = ~(lo ? pl : pr), ty = ~(lo ? pr : pl);
-            const bool validx = (tx >= 0) && (tx != s.lastTri);
-            const bool validy = (ty >= 0) && (ty != s.lastTri) && (tx != ty);
-            int tri = validx ? tx : ty;
-            bool valid = validx || validy;
-            bool again = validx && validy;
-#pragma unroll 1
-            for (int pass = 0; pass < 2; pass++) {
-                if (valid) {
-                    float u = 0.f, v = 0.f;
-                    float d = tri_test(tri48, tri, s.origin, s.direct, u, v);
-                    if (COUNT) nT++;
-                    bool near = lessF(d, INF) && lessEqualF(d, s.predist) && greaterEqualF(d, 0.0f);
-                    if (near) {
-                        if (!equalF(d, s.predist)) s.bakedCount = 0;
-                        s.predist = d;
-                        s.lastTri = tri;
-                        int at = s.bakedCount++;
-                        if (at == 0) { s.head.u = u; s.head.v = v; s.head.t = d; s.head.tri = tri; }
-                        else if (at < BAKED_CAP) { extra[at - 1].u = u; extra[at - 1].v = v; extra[at - 1].t = d; extra[at - 1].tri = tri; }
-                        else if (COUNT) nBakedDrop++;
-                    }
-                }
-                tri = ty;
-                valid = again;
-                again = false;
-            }
-            pl = 0; pr = 0;
-            parkedNow = false;
-        }
-    }
-    if (COUNT) {
-        DevCounters* ctr = cold_args()->ctr;
-        uint32_t v = wave_sum(nV), t = wave_sum(nT), d = wave_sum(nDrop), c = wave_sum(nCap), b = wave_sum(nBakedDrop);
-        if (lane_id() == 0) {
-            atomicAdd(&ctr->wave_clock_ticks, (unsigned long long)(__builtin_amdgcn_s_memtime() - dg_t0));
-            atomicAdd(&ctr->wave_real_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dg_r0));
-            atomicAdd(&ctr->wave_steps, dg_steps);
-            atomicAdd(&ctr->waves, 1ull);
-            if (v) atomicAdd(&ctr->node_visits, (unsigned long long)v);
-            if (t) atomicAdd(&ctr->tri_tests, (unsigned long long)t);
-            if (d) atomicAdd(&ctr->stack_drops, (unsigned long long)d);
-            if (c) atomicAdd(&ctr->iter_caps, (unsigned long long)c);
-            if (b) atomicAdd(&ctr->baked_drops, (unsigned long long)b);
-        }
-    }
-}
-
-#endif   // PSM_EXPERIMENTAL (REFILL)
 
 constexpr uint32_t RESUME_GRID_CAP = 256 * 32 / (TRAV_BLOCK / 64);  // 256 CUs x 32 resident waves: a resume launch never needs more blocks
 
-// continuation queues of the hand-over schedules: `need` entries at least (a launch over several Pipelines' queues can hold
-// more rays than one Pipeline's currentRayLimit)
-static int ensure_phase_buffers(psm_rt* r, size_t need = 0) {
+// continuation queues of the hand-over schedules: one entry per ray of the Pipeline's currentRayLimit
+static int ensure_phase_buffers(psm_rt* r) {
     psm_ctx* c = r->ctx;
-    const size_t want = std::max<size_t>(r->limit, need);
-    if (r->d_phase_mem && r->phase_cap >= want && (need || r->phase_cap == r->limit)) return PSM_OK;
-    // (a group launch runs on another context's stream than r's: nothing on the device may still use the old queues)
-    if (r->d_phase_mem) { (void)(need ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream)); (void)hipFree(r->d_phase_mem); r->d_phase_mem = nullptr; }
-    const size_t L = want;
+    if (r->d_phase_mem && r->phase_cap == r->limit) return PSM_OK;
+    if (r->d_phase_mem) { (void)hipStreamSynchronize(c->stream); (void)hipFree(r->d_phase_mem); r->d_phase_mem = nullptr; }
+    const size_t L = r->limit;
     const size_t per = L * (4 * 5 + 16 + 4 * STACK_CAP);  // idx, cur, misc, predist, lastTri, head, stack
     PSM_HIP(c, hipMalloc(&r->d_phase_mem, 2 * per + 2 * sizeof(uint32_t) * MAX_PHASES));
     char* base = (char*)r->d_phase_mem;
@@ -1105,9 +798,6 @@ static int plan_traverse(const psm_rt* r, uint32_t n, bool chain, std::vector<Ph
     // kernels fill the tails its extra launches add); a frame on its own is bound by its longest ray, which the extra
     // launches serialise, so it runs one launch; so do rounds under phase_min_rays rays (tiles).
     if (mode == PSM_TRAVERSE_AUTO) mode = r->in_flight > 1 ? PSM_TRAVERSE_ADAPTIVE : PSM_TRAVERSE_WHOLE;
-#if PSM_EXPERIMENTAL
-    if (mode == PSM_TRAVERSE_REFILL) return n >= r->refill_min_rays ? PSM_TRAVERSE_REFILL : PSM_TRAVERSE_WHOLE;
-#endif
     if (mode == PSM_TRAVERSE_WHOLE || n < r->phase_min_rays) return PSM_TRAVERSE_WHOLE;
     if (mode == PSM_TRAVERSE_PHASED) {
         for (int k = 0; k < r->phase_caps_n; k++) plan.push_back(PhasePlan{r->phase_caps[k], 0u});
@@ -1141,29 +831,13 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
         uint32_t grid = ((n + TRAV_BLOCK - 1) / TRAV_BLOCK + (8u * XCD_RUN - 1u)) & ~(8u * XCD_RUN - 1u);  // a multiple of 8 XCDs x XCD_RUN (rt_traverse: vblock)
         TravArgs ta = {};
         ta.qA = r->qA[r->cur]; ta.qB = r->qB[r->cur]; ta.qbases = r->q_bases[r->cur]; ta.qnb = r->q_nb[r->cur]; ta.nrays = n;
-        // (a hierarchy in an arena slot: links and triangle ids in its records count from the arena's start)
-        ta.node32 = b->d_node32 - (size_t)2 * b->node_off; ta.tri48 = b->d_tri48 - (size_t)3 * b->tri_off; ta.sm = b->d_small;
+        ta.node32 = b->d_node32; ta.tri48 = b->d_tri48; ta.sm = b->d_small;
         ta.hit0 = r->hit0; ta.hitN = r->hitN; ta.pool = r->pool; ta.cnt = r->d_cnt; ta.ctr = c->d_counters;
         ta.pool_cap = r->pool_cap; ta.obj_tag = tag;
         ta.cap = 0xFFFFFFFFu;
         ta.solo_max = r->solo_max;
 #if PSM_EXP_WAVELOG
         { const char* e = getenv("PSM_EXP_WAVELOG_PTR"); ta.wavelog = e ? (uint32_t*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr; }
-#endif
-#if PSM_EXPERIMENTAL
-        if (mode == PSM_TRAVERSE_REFILL) {
-            // persistent waves over a pool of rays: at most refill_waves waves per CU, never more lanes than rays
-            const uint32_t per_block = TRAV_BLOCK;
-            uint32_t blocks = (n + per_block - 1) / per_block;
-            const uint32_t cap_blocks = 256u * r->refill_waves_per_cu / (TRAV_BLOCK / 64);
-            if (blocks > cap_blocks) blocks = cap_blocks;
-            PSM_HIP(c, hipMemsetAsync(r->d_cnt + 4, 0, sizeof(uint32_t), c->stream));   // the pool's cursor
-            ta.out_count = r->d_cnt + 4;
-            ta.min_live = r->refill_min;
-            TimedScope ts(c, CAT_TRAVERSE_HANDOVER);
-            if (c->counting) rt_traverse_refill<true><<<blocks, TRAV_BLOCK, 0, c->stream>>>(ta);
-            else rt_traverse_refill<false><<<blocks, TRAV_BLOCK, 0, c->stream>>>(ta);
-        } else
 #endif
         if (mode == PSM_TRAVERSE_WHOLE) {
             TimedScope ts(c, CAT_TRAVERSE);
@@ -1218,97 +892,5 @@ int launch_rt_traverse(psm_rt* r, psm_bvh* b) {
     return PSM_OK;
 }
 
-#if PSM_EXPERIMENTAL
-// One traversal launch over the current queues of n Pipelines (psm_rt_traverse_group). Every Pipeline's hierarchy must sit in
-// a slot of the same psm_arena (or n == 1); the launch goes to `on`'s stream, and the caller has ordered that stream
-// after whatever wrote the queues and before whatever reads the hits. Schedule as launch_rt_traverse chooses it for rts[0]
-// and the launch's total ray count.
-int launch_rt_traverse_group(psm_rt* const* rts, psm_bvh* const* bvhs, uint32_t n, psm_ctx* on, psm_rt* owner) {
-    psm_ctx* c = on;
-    if (n == 0 || n > (uint32_t)MAX_GROUP) return set_err(c, PSM_ERR_INVALID, "psm_rt_traverse_group: 1..8 Pipelines");
-    TravArgs ta = {};
-    uint64_t total = 0;
-    const uint4* nbase = bvhs[0]->d_node32 - (size_t)2 * bvhs[0]->node_off;
-    const float4* tbase = bvhs[0]->d_tri48 - (size_t)3 * bvhs[0]->tri_off;
-    for (uint32_t k = 0; k < n; k++) {
-        psm_rt* r = rts[k];
-        psm_bvh* b = bvhs[k];
-        if (r->ctx->device != c->device) return set_err(c, PSM_ERR_INVALID, "psm_rt_traverse_group: Pipelines of another device");
-        if (!b->built) return set_err(c, PSM_ERR_STATE, "traverse before build");
-        if (r->trav_n != 0) return set_err(c, PSM_ERR_STATE, "psm_rt_traverse_group: a queue that has been traversed already (multi-BVH chains go through psm_rt_traverse)");
-        if (!r->count_valid) return set_err(c, PSM_ERR_STATE, "psm_rt_traverse_group: a Pipeline's ray count is not known to the host yet");
-        if (b->d_node32 - (size_t)2 * b->node_off != nbase || b->d_tri48 - (size_t)3 * b->tri_off != tbase)
-            return set_err(c, PSM_ERR_INVALID, "psm_rt_traverse_group: the hierarchies must be slots of one psm_arena");
-        GroupQueue& q = ta.gq[k];
-        q.qA = r->qA[r->cur]; q.qB = r->qB[r->cur]; q.qbases = r->q_bases[r->cur]; q.qnb = r->q_nb[r->cur];
-        q.nrays = r->ray_count; q.first = (uint32_t)total; q.sm = b->d_small;
-        q.hit0 = r->hit0; q.hitN = r->hitN; q.pool = r->pool; q.cnt = r->d_cnt; q.pool_cap = r->pool_cap;
-        total += r->ray_count;
-    }
-    if (total == 0) return PSM_OK;
-    if (total > 0xFFFFFF00ull) return set_err(c, PSM_ERR_CAPACITY, "psm_rt_traverse_group: more than 2^32 rays in one launch");
-    const uint32_t N = (uint32_t)total;
-    psm_rt* r0 = owner ? owner : rts[0];   // whose schedule settings and continuation queues the launch uses
-    ta.gn = n;
-    ta.nrays = N;
-    ta.node32 = nbase; ta.tri48 = tbase;
-    ta.ctr = c->d_counters;
-    ta.cap = 0xFFFFFFFFu;
-    ta.solo_max = r0->solo_max;
-    std::vector<PhasePlan> plan;
-    const int mode = plan_traverse(r0, N, false, plan);
-    const uint32_t grid = ((N + TRAV_BLOCK - 1) / TRAV_BLOCK + (8u * XCD_RUN - 1u)) & ~(8u * XCD_RUN - 1u);
-    if (mode == PSM_TRAVERSE_WHOLE || mode == PSM_TRAVERSE_REFILL) {
-        TimedScope ts(c, CAT_TRAVERSE);
-        if (c->counting) rt_traverse<true, false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
-        else rt_traverse<false, false, false, true><<<grid, TRAV_BLOCK, 0, c->stream>>>(ta);
-    } else {
-        int rc = ensure_phase_buffers(r0, N + N / 4);   // (headroom: the next round of the same frames may be a little larger)
-        if (rc != PSM_OK) return rc;
-        const size_t np = plan.size() + 1;
-        if (r0->phase_dirty) PSM_HIP(c, hipMemsetAsync(r0->d_phase_cnt, 0, 2 * sizeof(uint32_t) * MAX_PHASES, c->stream));
-        r0->phase_dirty = true;
-        uint32_t* const pcnt = r0->d_phase_cnt + r0->phase_set * MAX_PHASES;
-        uint32_t* const pother = r0->d_phase_cnt + (r0->phase_set ^ 1u) * MAX_PHASES;
-        r0->phase_set ^= 1u;
-        uint64_t bound = N;
-        for (size_t p = 0; p < np; p++) {
-            TravArgs ph = ta;
-            ph.zero_cnt = p + 1 == np ? pother : nullptr;
-            ph.cap = p < plan.size() ? plan[p].cap : 0xFFFFFFFFu;
-            ph.min_live = p < plan.size() ? plan[p].min_live : 0u;
-            ph.min_steps = r0->adapt_min_steps;
-            ph.final_rays = mode == PSM_TRAVERSE_ADAPTIVE ? r0->adapt_final_rays : 0u;
-            ph.in_count = p == 0 ? nullptr : pcnt + (p - 1);
-            ph.in = r0->phase_state[(p + 1) & 1];
-            ph.out = r0->phase_state[p & 1];
-            ph.out_count = pcnt + p;
-            uint32_t g = grid;
-            if (p > 0) {
-                uint64_t need = (bound + TRAV_BLOCK - 1) / TRAV_BLOCK;
-                g = (uint32_t)(need < RESUME_GRID_CAP ? need : RESUME_GRID_CAP);
-                if (g == 0) g = 1;
-            }
-            TimedScope ts(c, CAT_TRAVERSE_HANDOVER);
-            if (c->counting) rt_traverse<true, false, true, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
-            else rt_traverse<false, false, true, true><<<g, TRAV_BLOCK, 0, c->stream>>>(ph);
-            if (ph.min_live > 0 && ph.cap == 0xFFFFFFFFu) bound = ((bound + 63) / 64) * (ph.min_live - 1);
-        }
-        PSM_HIP(c, hipGetLastError());
-        r0->phase_dirty = false;
-    }
-    PSM_HIP(c, hipGetLastError());
-    for (uint32_t k = 0; k < n; k++) {
-        psm_rt* r = rts[k];
-        if (r->ray_count == 0) continue;
-        r->last_objs[0] = bvhs[k];
-        r->trav_objs[0] = bvhs[k];
-        r->trav_n = 1;
-        r->ctx->rays_traced += r->ray_count;
-    }
-    return PSM_OK;
-}
-
-#endif   // PSM_EXPERIMENTAL (one launch over several Pipelines)
 
 }  // namespace psm

@@ -188,6 +188,10 @@ def _read_gltf(path, mscale, as_viewer):
         ignored[what] = ignored.get(what, 0) + n
 
     buffers = [_read_buffer(b, i, base, path) for i, b in enumerate(g.get("buffers", []))]
+    # one float view and one word view per buffer, shared by every primitive that reads it (TriangleHierarchy.loadMeshes uploads
+    # a pool once per distinct memory: the reference's primitives share a GL buffer the same way, Viewer.cpp:133-139)
+    fviews = [b.view(_F32) for b in buffers]
+    wviews = [b.view(np.uint32) for b in buffers]
     gviews = g.get("bufferViews", [])
     gacc = g.get("accessors", [])
     for i, bv in enumerate(gviews):
@@ -280,7 +284,7 @@ def _read_gltf(path, mscale, as_viewer):
                 key = {"POSITION": "vertex_accessor", "NORMAL": "normal_accessor", "TEXCOORD_0": "texcoord_accessor"}[name]
                 geom[key] = len(geom["accessors"]) - 1
                 if name == "POSITION":
-                    geom["vertices"] = buffers[bv["buffer"]].view(_F32)
+                    geom["vertices"] = fviews[bv["buffer"]]
                     geom["_vertex_count"] = int(a.get("count", 0))
             if geom["vertices"] is None:
                 raise ValueError("%s: %s has no POSITION" % (path, what))
@@ -296,7 +300,7 @@ def _read_gltf(path, mscale, as_viewer):
                 elif ct not in (_SHORT, _USHORT, _UINT):
                     raise ValueError("%s: %s: index component type %r" % (path, what, ct))
                 geom["node_count"] = int(a.get("count", 0)) // 3
-                geom["indices"] = buffers[bv["buffer"]].view(np.uint32)
+                geom["indices"] = wviews[bv["buffer"]]
                 geom["index16"] = int(is16)
                 geom["loading_offset"] = (int(bv.get("byteOffset", 0)) + int(a.get("byteOffset", 0))) // (2 if is16 else 4)
             elif as_viewer:

@@ -11,14 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "psm_hip.h")
 
 
-def declared_symbols(experimental=False):
-    """the entry points of the default library (or, experimental=True, of the header's PSM_EXPERIMENTAL section)"""
+def declared_symbols():
+    """the entry points include/psm_hip.h declares"""
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    m = re.search(r"#if defined\(PSM_EXPERIMENTAL\) && PSM_EXPERIMENTAL\n(.*?)#endif", src, flags=re.S)
-    assert m
-    part = m.group(1) if experimental else src.replace(m.group(1), "")
-    return sorted(set(re.findall(r"\b(psm_[a-z0-9_]+)\s*\(", part)))
+    return sorted(set(re.findall(r"\b(psm_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_compiles_as_c_and_cpp(tmp_path):
@@ -38,12 +35,11 @@ def test_library_exports_every_declared_symbol(psm):
         assert hasattr(lib, s), "libpsm_hip.so does not export %s" % s
     # and the python binding lists exactly the header's entry points
     assert sorted(psm.EXPORTS) == syms
-    # the schedules that lost are fenced out of the product: declared under PSM_EXPERIMENTAL, exported by
-    # `make experimental`'s library only
-    exp = declared_symbols(experimental=True)
-    assert sorted(psm.EXPERIMENTAL_EXPORTS) == exp and len(exp) == 8
-    if os.environ.get("PSM_HIP_LIB") is None:
-        assert not any(hasattr(lib, s) for s in exp) and not psm.has_experimental()
+    # the schedules that lost (the tag experimental-r04 still has them) are gone from the sources
+    assert "EXPERIMENTAL" not in open(HEADER).read()
+    for gone in ("psm_arena_create", "psm_rt_traverse_group", "psm_rt_set_traverse_refill", "psm_lanes_render_grouped",
+                 "psm_lanes_render_split", "psm_rt_share_texels"):
+        assert not hasattr(lib, gone), gone
 
 
 def test_every_entry_point_cites_the_reference():

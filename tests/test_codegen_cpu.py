@@ -30,7 +30,7 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
     ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
     seen = 0
     for (st, name), en in zip(starts, ends):
-        if "rt_traverseILb0ELb0ELb1ELb0E" not in name and "rt_traverseILb0ELb0ELb0ELb0E" not in name:
+        if "rt_traverseILb0ELb0ELb1E" not in name and "rt_traverseILb0ELb0ELb0E" not in name:
             continue   # the timed kernels: hand-over and single launch, plain
         body = lines[st:en]
         first = [i for i, l in enumerate(body) if "v_fma_mix_f32" in l][0]
@@ -47,7 +47,7 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
     assert seen == 2
     # occupancy: 64 VGPRs at most (8 waves per SIMD), nothing spilled
     meta = open(path).read()
-    for kern in ("_ZN3psm11rt_traverseILb0ELb0ELb1ELb0EEEvNS_8TravArgsE", "_ZN3psm11rt_traverseILb0ELb0ELb0ELb0EEEvNS_8TravArgsE"):
+    for kern in ("_ZN3psm11rt_traverseILb0ELb0ELb1EEEvNS_8TravArgsE", "_ZN3psm11rt_traverseILb0ELb0ELb0EEEvNS_8TravArgsE"):
         blk = meta[meta.index(".name:           " + kern):]
         blk = blk[:blk.index(".wavefront_size")]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 64, kern
@@ -70,7 +70,7 @@ def test_solo_gear_step_is_short(tmp_path):
     ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
     seen = 0
     for (st, name), en in zip(starts, ends):
-        if "rt_traverseILb0ELb0ELb1ELb0E" not in name and "rt_traverseILb0ELb0ELb0ELb0E" not in name:
+        if "rt_traverseILb0ELb0ELb1E" not in name and "rt_traverseILb0ELb0ELb0E" not in name:
             continue
         body = lines[st:en]
         dpp = [i for i, l in enumerate(body) if "quad_perm:" in l]

@@ -14,13 +14,6 @@ from util import bits, canonical_nodes
 pytestmark = pytest.mark.gpu
 
 
-def _experimental(psm):
-    """The schedules that were measured and lost (refill traversal, grouped launches, split frames: DESIGN.md 5.3) live in
-    `make -C prismarine-core_amd/csrc experimental`'s library only; their parity tests run where PSM_HIP_LIB points at it."""
-    if not psm.has_experimental():
-        pytest.skip("needs the experimental library (PSM_HIP_LIB=.../csrc/variants/libpsm_experimental.so)")
-
-
 def _load(psm, ctx, scene):
     th = psm.TriangleHierarchy(ctx)
     th.allocate(scene["tris"].shape[0])
@@ -39,6 +32,20 @@ def _scene(scenes, name):
         sc["materials"] = list(sc["materials"])
         sc["materials"][0] = dict(sc["materials"][0], diffuse=(0.0, 0.0, 0.0, 1.0), specular=(0.0, 0.3, 1.0, 0.0))
         sc["materials"][1] = dict(sc["materials"][1], diffuse=(1.5, 0.2, 0.1, 1.0))
+        return sc
+    if name.endswith("+clearmetal"):
+        # every fourth triangle twice, both copies a full-metal material whose diffuse constant says alpha 0 (would the
+        # equal-distance chain composite to albedo 0 and the dropped lobe's colour be NaN, against the `ordinary material` rule of
+        # psm_rt_set_materials?). It does not: without a diffuse texture a hit's albedo is vec4(diffuse.xyz, 1) (fetchDiffuse,
+        # surface.comp:155-161), the chain's head is opaque and nothing composites. The case holds that: 500-1000 chains of two
+        # hits per round, queues slot for slot as the oracle's.
+        sc = dict(_scene(scenes, name[:-11]))
+        sc["materials"] = list(sc["materials"]) + [dict(sc["materials"][0], diffuse=(0.8, 0.8, 0.8, 0.0), specular=(0.0, 0.3, 1.0, 0.0))]
+        dup = np.arange(0, sc["tris"].shape[0], 4)
+        sc["tris"] = np.ascontiguousarray(np.concatenate([sc["tris"], sc["tris"][dup]], 0))
+        sc["normals"] = np.ascontiguousarray(np.concatenate([sc["normals"], sc["normals"][dup]], 0))
+        sc["mats"] = np.ascontiguousarray(np.concatenate([sc["mats"], np.full(dup.size, len(sc["materials"]) - 1, np.int32)]))
+        sc["mats"][dup] = len(sc["materials"]) - 1
         return sc
     if name == "cornell":
         return scenes.cornell()
@@ -559,10 +566,6 @@ TRAVERSE_SCHEDULES = [
     ("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 256, "max_launches": 8, "solo": 4}),
     ("adaptive", {"min_live": 12, "min_steps": 8, "final_rays": 65536, "max_launches": 3, "solo": 0}),
     ("phased", {"caps": [24, 24], "solo": 3}),
-    ("refill", {"refill_min": 16, "waves_per_cu": 32}),
-    ("refill", {"refill_min": 1, "waves_per_cu": 2}),     # every idle lane refills at once; a small persistent grid
-    ("refill", {"refill_min": 64, "waves_per_cu": 8}),    # a wave refills only when all its lanes are idle
-    ("refill", {"refill_min": 33, "waves_per_cu": 4}),
 ]
 
 
@@ -574,8 +577,6 @@ def _select_schedule(rt, mode, kw):
         rt.setTraversePhases(kw["caps"], min_rays=0)
     elif mode == "adaptive":
         rt.setTraverseAdaptive(min_rays=0, **kw)
-    elif mode == "refill":
-        rt.setTraverseRefill(min_rays=0, **kw)
     rt.setTraverseMode(mode)
 
 
@@ -584,8 +585,6 @@ def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, k
     """psm_rt_set_traverse_mode: every kernel schedule that ships -- one launch, fixed-cap phases, ballot-triggered
     hand-over with persistent resume waves -- gives the hits, chains and
     V / T counters of the oracle's uninterrupted per-ray loop (directTraverse.comp:333-484)."""
-    if mode == "refill":
-        _experimental(psm)
     scene = scenes.sponza_like(n_tris=20011)
     w, h = 160, 90
     th, rt, ms, cam = _setup_frame(psm, ctx, scenes, scene, w, h)
@@ -609,14 +608,11 @@ def test_every_traversal_schedule_is_bit_exact(psm, ctx, oracle, scenes, mode, k
     th.close()
 
 
-@pytest.mark.parametrize("mode,kw", [("refill", {"refill_min": 16, "waves_per_cu": 4}), ("refill", {"refill_min": 3, "waves_per_cu": 32}),
-                                     ("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 64, "max_launches": 8}),
-                                     ("phased", {"caps": [5, 9]})], ids=["refill-16", "refill-3", "adaptive", "phased"])
+@pytest.mark.parametrize("mode,kw", [("adaptive", {"min_live": 16, "min_steps": 8, "final_rays": 64, "max_launches": 8}),
+                                     ("phased", {"caps": [5, 9]})], ids=["adaptive", "phased"])
 def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes, mode, kw):
     """Rays that carry an equal-distance chain of two or more hits cannot hand over (their chain lives in registers):
     they finish in the launch they are in. Duplicated coplanar triangles make thousands of them."""
-    if mode == "refill":
-        _experimental(psm)
     rng = np.random.RandomState(5)
     base = scenes.sponza_like(n_tris=6007)["tris"]
     tris = np.ascontiguousarray(np.concatenate([base, base[:1500]], 0))
@@ -653,6 +649,7 @@ def test_traversal_schedules_keep_equal_distance_chains(psm, ctx, oracle, scenes
 @pytest.mark.parametrize("name,w,h", [("cornell_open", 96, 96), ("sponza_small", 160, 90),
                                       ("cornell_open+tex", 96, 96), ("sponza_small+tex", 160, 90),
                                       ("cornell_open+blackmetal", 96, 96), ("sponza_small+blackmetal", 160, 90),
+                                      ("cornell_open+clearmetal", 96, 96),
                                       ("cornell_open", 97, 61), ("cornell", 33, 17)])   # ragged: no multiple of a wave, a workgroup or a band
 def test_shade_rounds_bit_exact_queues(psm, ctx, oracle, scenes, name, w, h):
     """+tex: SURVEY f2 -- texcoords, the sampler table and every texture part of surface.comp:100-161."""
@@ -836,6 +833,10 @@ def test_gltf_scene_from_file_to_image(psm, ctx, oracle, scenes):
     ms = psm.MaterialSet()
     ts = gltf.load_into(gs, th, ms)
     assert th.triangleCount == n == scene["tris"].shape[0] and ms.getMaterialCount() == 5 and len(ts.textures) == 3
+    # the primitives of one glTF buffer share ONE device pool (a fresh view per primitive used to mean an upload each)
+    addr = lambda a: a.__array_interface__["data"][0]
+    used = {addr(g["vertices"]) for g in gs["instances"]} | {addr(g["indices"]) for g in gs["instances"] if g.get("indices") is not None}
+    assert th.pool_uploads == len(used) <= 2, (th.pool_uploads, len(used))
     assert np.array_equal(bits(th.download(psm.BVH_POSITIONS, np.float32, 9 * n)), bits(scene["tris"].reshape(-1)))
     assert np.array_equal(bits(th.download(psm.BVH_NORMALS, np.float32, 9 * n)), bits(scene["normals"].reshape(-1)))
     assert np.array_equal(bits(th.download(psm.BVH_TEXCOORDS, np.float32, 6 * n)), bits(scene["texcoords"].reshape(-1)))
@@ -1359,40 +1360,6 @@ def test_frame_batch_lanes_equal_sequential_frames(psm, oracle, scenes):
     batch.close()
 
 
-@pytest.mark.parametrize("name,w,h,lanes,split,frames", [("cornell_open", 64, 48, 1, 4, 3), ("sponza_small", 160, 90, 1, 3, 3),
-                                                         ("sponza_small", 128, 72, 2, 2, 5), ("cornell_open", 64, 16, 1, 4, 2)])
-def test_frame_split_over_parts_equals_unsplit_frames(psm, oracle, scenes, name, w, h, lanes, split, frames):
-    """psm_lanes_render_split: every frame is traced by `split` Pipelines that own the frame's bands round-robin, share
-    the slot's hierarchy and one set of texel arrays and run their bounce rounds independently (one part's traversal
-    tail under the others' rounds), with the `fewer than 32 rays -> stop` rule applied to the frame's total. The image,
-    the rounds and the rays traced per frame equal psm_lanes_render's for the same seeds; one frame at a time
-    (lanes = 1) and two frames in flight; 64x16 = two bands on four parts (parts without a band)."""
-    _experimental(psm)
-    scene = _scene(scenes, name)
-    ms = psm.MaterialSet()
-    for m in scene["materials"]:
-        ms.addSubmat(m)
-
-    def run(sp, ln):
-        b = psm.FrameBatch(ln, w, h, seed=41, split=sp)
-        b.allocate(scene["tris"].shape[0])
-        b.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
-        b.applyMaterials(ms)
-        res = b.render(frames, scene["eye"], scene["view"])
-        img = b.snapHdr()
-        b.close()
-        return img, res
-    want, wres = run(1, lanes)
-    got, gres = run(split, lanes)
-    assert gres == wres, (gres, wres)                  # rounds and rays per frame
-    assert np.array_equal(got[..., 3], want[..., 3])
-    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
-    assert want[..., :3].max() > 0.05
-    if name == "cornell_open" and h == 48:             # and against the oracle's frames
-        ref, _ = oracle.render_frames(scene, w, h, frames=frames, seed=41, frame_streams=True)
-        np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
-
-
 @pytest.mark.parametrize("lanes,frames,w,h,depth,rebuild", [
     (1, 3, 48, 32, 16, True),     # one frame at a time: every frame's rebuild is queued while the frame before folds
     (2, 1, 48, 32, 16, True),     # fewer frames than lanes
@@ -1425,92 +1392,6 @@ def test_lane_scheduler_edge_cases_equal_the_oracle(psm, oracle, scenes, lanes, 
     assert len(per_frame) == frames
     assert sum(r for _, r in per_frame) == st["rays"] and sum(n for n, _ in per_frame) == len(st["rounds"])
     batch.close()
-
-
-@pytest.mark.parametrize("mode,kw", [("whole", {}), ("adaptive", {"min_live": 16, "min_steps": 4, "final_rays": 64, "max_launches": 4}),
-                                     ("phased", {"caps": [3, 9]})], ids=["whole", "adaptive", "phased"])
-@pytest.mark.parametrize("counting", [True, False], ids=["counting", "plain"])
-def test_one_traversal_launch_over_several_pipelines_is_bit_exact(psm, ctx, oracle, scenes, mode, kw, counting):
-    """psm_rt_traverse_group: three Pipelines with different ray sets, each against ITS OWN hierarchy -- three different
-    scenes in the slots of one Arena, whose traversal records carry arena-wide links and triangle ids -- traced by ONE launch
-    (every schedule: the hand-over mixes rays of all three in its resume waves). Per Pipeline the hits, chains, V and T are
-    the oracle's for its scene; what the hierarchies hand out (topology, boxes, root) is unchanged by the arena."""
-    _experimental(psm)
-    rng = np.random.RandomState(11)
-    sc = [scenes.sponza_like(n_tris=6007), scenes.cornell(open_top=True), scenes.sponza_like(n_tris=20011)]
-    cap = max(s_["tris"].shape[0] for s_ in sc)
-    arena = psm.Arena(ctx, 3, cap)
-    ths, rts, rays_l, built = [], [], [], []
-    for k, s_ in enumerate(sc):
-        th = psm.TriangleHierarchy(ctx)
-        th.allocate(cap, arena, k)
-        th.loadTriangles(s_["tris"], s_["normals"], s_["mats"])
-        th.build()
-        ob = oracle.build_scene(s_["tris"])
-        _built_equals_oracle(psm, oracle, th, ob)          # arena slot 1, 2: links offset inside, relative outside
-        n = [30000, 777, 50001][k]
-        tri = s_["tris"]
-        tid = rng.randint(0, tri.shape[0], n)
-        wgt = rng.dirichlet((1, 1, 1), n).astype(np.float32)
-        target = (tri[tid] * wgt[:, :, None]).sum(1)
-        origin = (target + rng.normal(0, 1, (n, 3)) * 2.0 + np.array([0, 2, 0])).astype(np.float32)
-        rays = np.zeros(n, psm.RAY_DT)
-        rays["origin"], rays["direct"], rays["color"] = origin, (target - origin).astype(np.float32), 1.0
-        rays["bitfield"] = 1 | (3 << 8)
-        rays["texel"] = np.arange(n) % 100
-        rays["pkey"] = np.arange(n)
-        rt = psm.Pipeline(ctx)
-        rt.resizeBuffers(128, 128)
-        _select_schedule(rt, mode, kw)
-        rt.upload_rays(rays)
-        ths.append(th); rts.append(rt); rays_l.append(rays); built.append(ob)
-    ctx.stats_enable(False, counting)   # (the counting and the plain kernels are different instantiations)
-    ctx.stats_reset()
-    psm.traverse_group(rts, ths)
-    st = ctx.stats()
-    ctx.stats_enable(False, False)
-    V = T = 0
-    for k, s_ in enumerate(sc):
-        oh, oc, ostat = oracle.traverse(built[k]["nodes"], s_["tris"], built[k]["M"], rays_l[k]["origin"], rays_l[k]["direct"], 8)
-        gh, gc = rts[k].download_hits(rays_l[k].shape[0])
-        _hits_equal(gh, gc, oh, oc)
-        V += int(ostat.node_visits); T += int(ostat.tri_tests)
-    if counting:
-        assert (st.node_visits, st.tri_tests) == (V, T)
-    for rt in rts:
-        rt.close()
-    for th in ths:
-        th.close()
-    arena.close()
-
-
-@pytest.mark.parametrize("name,w,h,lanes,group,frames", [("cornell_open", 64, 48, 2, 2, 5), ("sponza_small", 160, 90, 4, 2, 7),
-                                                         ("sponza_small", 128, 72, 4, 4, 6), ("sponza_small", 96, 54, 3, 3, 4)])
-def test_grouped_frames_equal_ungrouped_frames(psm, oracle, scenes, name, w, h, lanes, group, frames):
-    """psm_lanes_render_grouped: the lanes form groups whose frames trace every bounce round in one launch over all their
-    queues (each frame against its own rebuilt hierarchy in the batch's arena) -- image, rounds and rays per frame equal
-    psm_lanes_render's for the same seeds; a short last batch (7 frames on groups of 2), one group of all lanes, groups of 3."""
-    _experimental(psm)
-    scene = _scene(scenes, name)
-    ms = psm.MaterialSet()
-    for m in scene["materials"]:
-        ms.addSubmat(m)
-
-    def run(gr):
-        b = psm.FrameBatch(lanes, w, h, seed=19, group=gr)
-        b.allocate(scene["tris"].shape[0])
-        b.loadTriangles(scene["tris"], scene["normals"], scene["mats"])
-        b.applyMaterials(ms)
-        res = b.render(frames, scene["eye"], scene["view"])
-        img = b.snapHdr()
-        b.close()
-        return img, res
-    want, wres = run(1)
-    got, gres = run(group)
-    assert gres == wres, (gres, wres)
-    assert np.array_equal(got[..., 3], want[..., 3])
-    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
-    assert want[..., :3].max() > 0.05
 
 
 def _three_lights(oracle):
