@@ -15,13 +15,17 @@ PSM_D uint64_t lanemask_lt() {
     return l == 0 ? 0ull : (~0ull >> (64 - l));
 }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive scan across the 64 lanes of a wave: DPP moves inside the vector unit -- row_shr:1,2,4,8 scan each row of 16 lanes,
+// row_bcast:15 carries a row's total into rows 1 and 3, row_bcast:31 the lower half's into rows 2 and 3 -- six v_add_u32 with a DPP
+// operand. (Round 5: the __shfl_up this used to be is ds_bpermute_b32, a trip through the LDS crossbar per step: six of them were a
+// quarter of radix_local's prefix phase, tools/sort_log.py.)
 PSM_D uint32_t wave_scan_incl(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, WAVE);
-        if (lane_id() >= d) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1 (lanes without a source read 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 PSM_D uint32_t wave_sum(uint32_t v) {

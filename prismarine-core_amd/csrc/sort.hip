@@ -90,6 +90,10 @@ PSM_D uint32_t wave_rank(uint32_t d, bool valid, CT* row) {
     return old + before;
 }
 
+// (Round 5 also tried the match through LDS -- every lane ORs its lane bit into a per-wave mask word of its digit with ds_or_b64 and
+// reads the word back: 12 vector instructions a round instead of 45 -- and it LOST: C5's sort 0.52 against 0.41 ms, C3's 0.052
+// against 0.049, profiles/r05_sort_sweep.txt: LDS atomics are slower than the ballots they replace. Not kept.)
+
 template <int ITEMS>
 __global__ __launch_bounds__(256) void radix_onesweep(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                       uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
@@ -352,6 +356,16 @@ __global__ __launch_bounds__(THREADS) void radix_scatter(const uint64_t* __restr
 // its bin: whichever version of a neighbour's key a load returns, its bin is the same (pshift >= 32: the bin bits lie in the
 // key's high dword, so even a load torn between two 32-bit halves would agree).
 
+#ifndef PSM_EXP_SORTLOG
+#define PSM_EXP_SORTLOG 0   // 1: an experiment build (make sortlog) whose radix_local workgroups log s_memtime at their phase boundaries (tests/studies/sort_log.py)
+#endif
+#if PSM_EXP_SORTLOG
+__device__ unsigned long long* g_sortlog = nullptr;   // 32 stamps per workgroup (set by psm_sortlog_set, an export of the experiment build only)
+#define SORT_STAMP(k) do { if (g_sortlog && threadIdx.x == 0 && (k) < 32) g_sortlog[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SORT_STAMP(k) do { } while (0)
+#endif
+
 PSM_D uint32_t key_bin(uint64_t k, int pshift) { return pshift >= 64 ? 0u : (uint32_t)(k >> pshift); }
 
 template <int CAP, int THREADS>
@@ -460,9 +474,9 @@ PSM_D void local_slow(LocalLds<CAP, THREADS>& S, uint64_t* keys, uint32_t* vals,
     }
 }
 
-// (second launch bound: waves per SIMD such that two workgroups share a CU while their LDS allows it -- CAP <= 5120 keys)
+// (second launch bound: waves per SIMD such that two workgroups share a CU while their LDS -- 160 KB a CU -- allows it)
 template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) void radix_local(uint64_t* keys, uint32_t* vals, uint64_t* altk, uint32_t* altv,
+__global__ __launch_bounds__(THREADS, (2 * sizeof(LocalLds<CAP, THREADS>) <= 160 * 1024 ? 2 : 1) * THREADS / 256) void radix_local(uint64_t* keys, uint32_t* vals, uint64_t* altk, uint32_t* altv,
                                                        uint32_t n_max, const uint32_t* __restrict__ d_n, uint32_t S, int pshift,
                                                        uint32_t* overflow) {
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
@@ -473,6 +487,7 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
     if (a >= n) return;
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     const int l = lane_id();
+    SORT_STAMP(0);
     const uint32_t winN = min((uint32_t)CAP, n - a);   // the window: keys [a, a + winN)
     // ... of which the first S + 1024 are loaded at once and the rest only when the chunk's last bin turns out to be longer than
     // 1024 keys (C5: never; the second half of the window would be 8 B/key more of HBM reads for nothing)
@@ -521,6 +536,7 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
         if (hi != 0xFFFFFFFFu) atomicMin(&L.hi, hi);
         __syncthreads();
     }
+    SORT_STAMP(1);
     const uint32_t js = L.lo;
     if (js == 0xFFFFFFFFu || js >= S) return;   // no bin starts in [a, a + S): an earlier workgroup's chunk covers this stretch
     uint32_t je = L.hi;
@@ -562,7 +578,10 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
     }
     __syncthreads();
     const uint64_t diff = ((uint64_t)L.diff[1] << 32) | L.diff[0];
+    SORT_STAMP(2);
     if (diff == 0ull) return;   // one key value: the chunk is in order as it lies
+    int stamp = 3;
+    (void)stamp;
     for (int p = 0; p < 8; p++) {
         const int shift = 8 * p;
         if (((diff >> shift) & 255ull) == 0ull) continue;   // (the same for the whole workgroup)
@@ -575,6 +594,7 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
             }
         }
         __syncthreads();
+        SORT_STAMP(stamp); stamp++;
         if (tid < 256) {   // thread d: exclusive prefix of digit d over the waves, then over the digits of its group of 64
             uint32_t run = 0;
 #pragma unroll
@@ -588,6 +608,7 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
             if (l == 63) L.wtot[w] = inc;
         }
         __syncthreads();
+        SORT_STAMP(stamp); stamp++;
         {
             const uint32_t t0 = L.wtot[0], t1 = t0 + L.wtot[1], t2 = t1 + L.wtot[2];
 #pragma unroll
@@ -605,6 +626,7 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
             }
         }
         __syncthreads();
+        SORT_STAMP(stamp); stamp++;
         if ((diff >> shift) >> 8 == 0ull) break;   // the last pass: written out below, straight from LDS
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
@@ -619,7 +641,16 @@ __global__ __launch_bounds__(THREADS, (CAP <= 5120 ? 2 : 1) * THREADS / 256) voi
         const uint32_t q = i * THREADS + tid;
         if (q < size) { keys[gs + q] = L.sk[q]; vals[gs + q] = L.sv[q]; }
     }
+#if PSM_EXP_SORTLOG
+    if (g_sortlog && tid == 0) { g_sortlog[(size_t)blockIdx.x * 32 + 30] = size; g_sortlog[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
+
+#if PSM_EXP_SORTLOG
+extern "C" int psm_sortlog_set(unsigned long long* d_log) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sortlog), &d_log, sizeof(d_log)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ping-pong buffers and histogram / status words of the sort, grown on demand. Every growth bumps sort_gen: a captured
 // build graph (psm_bvh_build) holds these pointers and is re-captured when the generation has moved on.
@@ -723,7 +754,10 @@ static int sort_hybrid(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
                    : sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n, pshift, 2);
     if (rc != PSM_OK) return rc;
     // S: the stretch of bin starts a workgroup takes; a chunk fits LDS (CAP keys) while no bin is longer than CAP - S. Small sorts
-    // take short stretches: as many workgroups as the chip has CUs matter more there than keys per workgroup
+    // take short stretches (1 024 of 4 096): as many workgroups as the chip has CUs matter more there than keys per workgroup.
+    // Large ones 3 072 of 5 120: a pass costs a workgroup ~5 000 cycles of barriers and LDS round trips whatever the chunk holds
+    // (tools/sort_log.py), so longer chunks are cheaper per key; 5 120 keys are what two workgroups per CU leave room for
+    // (profiles/r05_sort_sweep.txt: C5 0.465 ms with 2 048 of 4 096, 0.408 with 3 072 of 5 120, 0.406 with 4 096 of 6 144 x 512 threads)
     const uint32_t S = small ? c->sort_hybrid_s_small : c->sort_hybrid_s_large;
     const uint32_t cap = small ? c->sort_hybrid_cap_small : c->sort_hybrid_cap_large, threads = c->sort_hybrid_threads;
     const uint32_t grid = (uint32_t)((n_max + S - 1) / S);
@@ -733,7 +767,7 @@ static int sort_hybrid(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
         PSM_HIP(c, hipGetLastError()); \
         return PSM_OK; \
     }
-    PSM_LOCAL(4096, 1024) PSM_LOCAL(4096, 512) PSM_LOCAL(5120, 1024) PSM_LOCAL(5120, 512) PSM_LOCAL(6144, 1024) PSM_LOCAL(6144, 512) PSM_LOCAL(8192, 1024)
+    PSM_LOCAL(4096, 1024) PSM_LOCAL(4096, 512) PSM_LOCAL(5120, 1024) PSM_LOCAL(5120, 512) PSM_LOCAL(6144, 512)
 #undef PSM_LOCAL
     return set_err(c, PSM_ERR_INVALID, "hybrid sort: no radix_local of this shape");
 }
