@@ -301,6 +301,70 @@ class Renderer:
             self.rt.unpack_tiles_dev(dist.world, 0, self.all_dev.data_ptr(), self.per)  # the other ranks' tiles, one launch
 
 
+def sharded_self_check(psm, scenes, dist, R):
+    """A run on several ranks proves itself before it is timed: a small frame set -- S-sponza-like with 20 011 triangles, 160 x 90
+    (12 bands, the last one two rows: padded tiles), 3 frames on 2 lanes -- through the SAME communicator, dealing and entry
+    point as the timed region (psm_dist_render_frames), and on rank 0 the same frames unsharded (psm_lanes_render); the two
+    images must agree -- deposit counts exactly, radiance to float-atomic order (1e-5) -- and every rank must have run the
+    unsharded rounds per frame. A wrong dealing, a rank that idles, a gather that delivers another frame's tile cannot then pass
+    for a plausible Mrays/s: every rank leaves with exit code 4. Returns what the JSON line reports.
+    (PSM_BENCH_SABOTAGE_RANK=r: that rank looks at the scene from somewhere else -- the test of this check.)"""
+    w, h, frames, lanes, seed = 160, 90, 3, 2, 4242
+    sc = scenes.sponza_like(n_tris=20011)
+    ms = psm.MaterialSet()
+    for m in sc["materials"]:
+        ms.addSubmat(m)
+
+    def batch(tiled):
+        b = psm.FrameBatch(lanes, w, h, device=dist.device_index, seed=seed)
+        b.allocate(sc["tris"].shape[0])
+        b.loadTriangles(sc["tris"], sc["normals"], sc["mats"])
+        b.applyMaterials(ms)
+        if tiled:
+            b.each(lambda r: r.setTileInterleaved(dist.rank, dist.world, R.weights))
+        return b
+
+    eye = np.asarray(sc["eye"], np.float32).copy()
+    if os.environ.get("PSM_BENCH_SABOTAGE_RANK") == str(dist.rank):
+        eye[0] += 0.75
+    cam = scenes.camera_matrices(eye, sc["view"], w, h)
+    ok, why, img, rounds = 1, "", None, None
+    b = batch(True)
+    try:
+        rounds = b.render_frames_sharded(R.native, b.frame_seeds(frames), cam[0], cam[1], depth=16)
+        if dist.rank == 0:
+            img = b.snapHdr()
+    except psm.PsmError as e:
+        ok, why = 0, "rank %d: %s" % (dist.rank, e)
+    b.close()
+    worst = None
+    want_r = [0] * frames
+    if dist.rank == 0 and ok:
+        u = batch(False)
+        want_r = [int(r) for r, _ in u.render(frames, sc["eye"], sc["view"], depth=16)]
+        want = u.snapHdr()
+        u.close()
+        worst = float((np.abs(img[..., :3] - want[..., :3]) / np.maximum(np.abs(want[..., :3]), 0.1)).max())
+        if not np.array_equal(img[..., 3], want[..., 3]):
+            ok, why = 0, "deposit counts of the sharded image differ from the unsharded one in %d texels" % int((img[..., 3] != want[..., 3]).sum())
+        elif not np.allclose(img[..., :3], want[..., :3], rtol=1e-5, atol=1e-6):
+            ok, why = 0, "radiance of the sharded image differs from the unsharded one (largest difference relative to max(|value|, 0.1): %.3g)" % worst
+        elif not want[..., :3].max() > 0.05:
+            ok, why = 0, "the check frames are black"
+    want_r = [int(v) for v in dist.sum_ints(want_r)]          # rank 0's unsharded rounds per frame, to everybody
+    if ok and rounds is not None and dist.min_int(1) == 1 and [int(v) for v in rounds] != want_r and sum(want_r) > 0:
+        ok, why = 0, "rank %d ran %s rounds per frame, the unsharded frames %s" % (dist.rank, [int(v) for v in rounds], want_r)
+    if dist.min_int(ok) == 0:
+        if not ok:
+            print("bench: the sharded self-check FAILED: %s" % why, file=sys.stderr, flush=True)
+        dist.close()
+        sys.exit(4)
+    return {"result": "ok", "what": "S-sponza-like 20011 tris, %dx%d, %d frames on %d lanes through psm_dist_render_frames on %d ranks "
+                                    "against psm_lanes_render on rank 0: deposit counts equal, radiance within 1e-5, rounds per frame %s on every rank"
+                                    % (w, h, frames, lanes, dist.world, want_r),
+            "largest_difference": worst}
+
+
 def cpu_baseline(scene, ray_sets, args):
     """CPU oracle traversal (scalar C restatement, OpenMP over rays) on a bounded sample of the GPU's ray set, on every
     hardware thread of the box; best of 3 after a warm-up."""
@@ -372,21 +436,52 @@ VALU_QUAD_CYCLES = 4.0       # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MI
 SIMDS = 1024
 
 
-def pmc_entry(scene, width, height, kernel):
-    """Per-launch PMC figures of `kernel` for this workload from the committed rocprofv3 passes (profiles/collect.sh ->
-    profiles/make_traffic.py): bench.py cannot run the profiler on itself."""
-    for name in ("traffic_r04.json", "traffic_r03.json"):
+KERNEL_SOURCES = ("prismarine-core_amd/csrc/trace.hip", "prismarine-core_amd/csrc/shade.hip", "prismarine-core_amd/csrc/psm_common.h",
+                  "prismarine-core_amd/csrc/psm_math.h", "prismarine-core_amd/csrc/psm_internal.h")
+TRAFFIC_FILES = ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json")
+
+
+def traffic_provenance(root=None):
+    """The newest committed counter file and whether its counters still describe the kernels this run executes: the file
+    carries the sha256 of the traversal / shading sources its rocprofv3 passes ran with (profiles/collect.sh,
+    make_traffic.py); they are compared with the sources beside this bench.py. Returns (path, provenance, stale, why)."""
+    import hashlib
+    root = root or ROOT
+    for name in TRAFFIC_FILES:
+        path = os.path.join(root, "profiles", name)
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        for e in d.get("entries", []):
-            if (e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel):
-                return e, "profiles/" + name
+        prov = d.get("provenance") or {}
+        want = prov.get("sources_sha256") or {}
+        if not want:
+            return path, prov, True, "profiles/%s carries no source hashes (collected before round 5): its counters cannot be tied to the kernels of this run" % name
+        for rel in KERNEL_SOURCES:
+            try:
+                have = hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest()
+            except OSError:
+                return path, prov, True, "%s is not beside bench.py" % rel
+            if want.get(rel) != have:
+                return path, prov, True, "%s has changed since the counters of profiles/%s were collected (commit %s)" % (rel, name, prov.get("commit"))
+        return path, prov, False, None
+    return None, {}, True, "no committed counter file"
+
+
+def pmc_entry(scene, width, height, kernel, root=None):
+    """Per-launch PMC figures of `kernel` for this workload from the committed rocprofv3 passes (profiles/collect.sh ->
+    profiles/make_traffic.py): bench.py cannot run the profiler on itself. None when the newest counter file is stale
+    (traffic_provenance): a replayed counter that describes another kernel is worse than none."""
+    path, prov, stale, _ = traffic_provenance(root)
+    if path is None or stale:
+        return None, None
+    for e in json.load(open(path)).get("entries", []):
+        if (e.get("scene"), e.get("width"), e.get("height")) == (scene, width, height) and e.get("kernel", "").endswith(kernel):
+            return e, "profiles/" + os.path.basename(path)
     return None, None
 
 
-def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, height, how, use_pmc=True):
+def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, height, how, use_pmc=True, root=None):
     """One traversal kernel priced over `launches` launches that took `total_ms` (HIP events on the launching streams) and
     traced R rays with V node visits and T triangle tests in `rounds` intersections."""
     launches = max(int(launches), 1)
@@ -399,7 +494,7 @@ def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, heig
            "own_record_bytes_per_launch": own / launches, "own_record_gbs": own / sec / 1e9 if sec > 0 else 0.0,
            "node_visits_per_s": V / sec if sec > 0 else None, "R": int(R), "V": int(V), "T": int(T)}
     # the committed counter passes are of whole frames on one GPU: a tile's launches are smaller, their traffic is not these
-    e, src = pmc_entry(scene, width, height, kernel) if use_pmc else (None, None)
+    e, src = pmc_entry(scene, width, height, kernel, root) if use_pmc else (None, None)
     if e is not None and sec > 0:
         traffic = e.get("traffic_bytes_per_launch")
         out["traffic"] = traffic
@@ -423,7 +518,7 @@ def price(kernel, launches, total_ms, R, V, T, rounds, steps, scene, width, heig
     return out
 
 
-def roofline(timed, whole, bytes_per_step, ms_per_step, copy_gbs):
+def roofline(timed, whole, bytes_per_step, ms_per_step, copy_gbs, root=None):
     """What bounds the dominant kernel of the TIMED region: `timed` = price() of the traversal kernel the timed schedule
     launches (HIP events on every lane's stream while the frames are in flight), `whole` = the single-launch kernel of a
     frame running alone, for comparison. The counters' figures lead; `achieved` / `frac` keep SURVEY 8(d)'s algorithmic
@@ -437,7 +532,16 @@ def roofline(timed, whole, bytes_per_step, ms_per_step, copy_gbs):
         bound = "cache/VALU: records served by L2 + Infinity Cache, VALU issue under divergence"
     else:
         bound = "unknown: no committed PMC pass for this kernel and workload"
-    out = {"bound": bound, "hbm_frac": t.get("hbm_frac"), "valu_issue_frac_of_step": t.get("valu_issue_frac_of_step"),
+    tpath, tprov, tstale, twhy = traffic_provenance(root)
+    # what binds the timed region, first, so that nobody takes `frac` below for an HBM figure: the chip's VALU issue slots, of which
+    # the step's traversal + shading launches use `frac`, at `lane_utilisation` live lanes per issued vector instruction
+    binding = ({"roof": "valu_issue", "frac": t.get("valu_issue_frac_of_step"), "lane_utilisation": t.get("valu_lane_utilisation"),
+                "hbm_frac": t.get("hbm_frac")} if not tstale and t.get("valu_issue_frac_of_step") is not None else
+               {"roof": "valu_issue (DESIGN.md 5.2; the counters that say so are not quoted: traffic_stale)" if tstale else "unknown: no PMC pass for this workload",
+                "frac": None, "lane_utilisation": None, "hbm_frac": None})
+    out = {"binding": binding, "traffic_commit": tprov.get("commit"), "traffic_stale": bool(tstale), "traffic_stale_why": twhy,
+           "traffic_file": ("profiles/" + os.path.basename(tpath)) if tpath else None,
+           "bound": bound, "hbm_frac": t.get("hbm_frac"), "valu_issue_frac_of_step": t.get("valu_issue_frac_of_step"),
            "valu_issue_utilisation": t.get("valu_issue_utilisation"),
            "timed_schedule_valu_lane_utilisation": t.get("valu_lane_utilisation"),
            "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t["achieved"] / HBM_PEAK_GBS,
@@ -489,14 +593,22 @@ def spawn_ranks(n):
 
 
 def dry_run(world):
+    """Every rank reaches its communicator (gloo, no GPU) and the group proves itself with the collectives the real line's
+    multi-rank fields come from (all-reduce, all-gather of per-rank figures); rank 0 prints those fields as the real line names them."""
     pdist = importlib.import_module("prismarine-core_amd.dist")
     comm = pdist.Comm(world, backend="gloo")
     total = comm.sum_int(1)
+    rows = comm.gather_floats([float(comm.rank), 0.0, 0.0, 0.0, -1.0])
     comm.barrier()
     print("bench.py dry run: rank %d of %d reached its communicator; all-reduce over the group = %d" % (comm.rank, world, total),
           flush=True)
+    if comm.rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "value": None,
+                          "ranks": {"world": world, "transport": "gloo (dry run: no GPU, no RCCL)", "comm_ranks": total,
+                                    "rays_traced_per_rank": [0] * len(rows), "ranks_heard_from": [int(r[0]) for r in rows]},
+                          "rccl_ranks": None, "sharded_check": "not run: dry run", "sharded_check_detail": None}), flush=True)
     comm.close()
-    return 0 if total == world else 1
+    return 0 if total == world and [int(r[0]) for r in rows] == list(range(world)) else 1
 
 
 def main():
@@ -551,6 +663,9 @@ def main():
         dist.close()
         sys.exit(3)
     ctx = R.ctx
+    check = None
+    if dist.active and dist.world > 1 and R.native is not None:
+        check = sharded_self_check(psm, scenes, dist, R)   # exits non-zero (every rank) unless sharded == unsharded
 
     def run_steps(k):
         if dist.active:
@@ -666,6 +781,20 @@ def main():
                              tick / max(real, 1) * 0.1, real / 100e6 / d_el))
         reseed()
 
+    per_rank = None
+    if dist.active:
+        # what every rank did, to rank 0's line: a rank that idles or a tile that costs twice the others' shows here
+        gather_ms = -1.0
+        if R.native is not None:   # one frame's gather, timed on its own: 5 x (pack, gather, unpack on rank 0), drained by a barrier on the communicator
+            dist.barrier()
+            g0 = time.perf_counter()
+            for _ in range(5):
+                R._gather()
+            R.native.barrier()
+            ctx.sync()
+            gather_ms = (time.perf_counter() - g0) / 5 * 1e3
+        per_rank = dist.gather_floats([float(Rr), kst.build_ms / args.steps, kst.traverse_ms / args.steps, kst.shade_ms / args.steps, gather_ms])
+
     if dist.rank == 0:
         img = R.batch.snapHdr()
         copy_gbs = ctx.copy_bandwidth(1 << 30, 5)  # the box's achievable ceiling next to the vendor peak
@@ -764,6 +893,19 @@ def main():
             "roofline": roof,
             "image_mean": float(img[..., :3].mean()),
         }
+        if dist.active:
+            mm = lambda col: {"min": min(r[col] for r in per_rank), "max": max(r[col] for r in per_rank)}
+            out["ranks"] = {
+                "world": world, "transport": R.native.transport if R.native is not None else "torch.distributed " + dist.backend,
+                "comm_ranks": R.native.comm_ranks if R.native is not None else None,
+                "frames_in_flight_per_rank": R.lanes, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "rays_traced_per_rank": [int(r[0]) for r in per_rank],
+                "per_frame_ms_over_ranks": {"what": "serial kernel pass of every rank (its tile's frames one after another); gather: pack + gather + rank 0's unpack, 5 in a row",
+                                            "build": mm(1), "traverse": mm(2), "shade": mm(3), "gather": mm(4) if R.native is not None else None}}
+            # the communicator's own count (ncclCommCount) next to n_gpus: what proves that N ranks took part
+            out["rccl_ranks"] = R.native.comm_ranks if (R.native is not None and R.native.transport == "rccl") else None
+            out["sharded_check"] = check["result"] if check else ("not run: one rank" if world == 1 else "not run: no native communicator")
+            out["sharded_check_detail"] = check
         if dist.active and R.hoststaged:
             # ranks that share one GPU and exchange through host memory: a rehearsal of the scheduler, never a scaling
             # measurement -- the line says so at the top level and carries no value a driver could ingest as one

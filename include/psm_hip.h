@@ -414,6 +414,10 @@ const char* psm_dist_transport_name(const psm_dist* dist);     /* NULL while not
 int psm_dist_destroy(psm_dist* dist);
 int psm_dist_rank(const psm_dist* dist);
 int psm_dist_world(const psm_dist* dist);
+/* the ranks the TRANSPORT itself counts in the communicator -- RCCL: ncclCommCount (psm_dist_connect fails unless it equals `world`
+ * and ncclCommUserRank equals `rank`); host-staged: the processes attached to the segment; 0 while not connected. What a bench line
+ * should print next to n_gpus. */
+int psm_dist_comm_ranks(const psm_dist* dist);
 /* pack rt's owned texels, ncclGather them to rank 0, and there unpack the tiles of ranks 1..world-1 into rt's image
  * (rt must carry psm_rt_set_tile_interleaved(rank, world) of this communicator). 16 B per texel; 1080p: 33 MB in all. */
 int psm_dist_gather_tiles(psm_dist* dist, psm_rt* rt);

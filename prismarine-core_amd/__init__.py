@@ -34,7 +34,7 @@ EXPORTS = [
     "psm_rt_upload_rays", "psm_rt_download_texels",
     "psm_stats_enable", "psm_stats_reset", "psm_stats_get", "psm_stats_reference", "psm_stats_traverse_intervals",
     "psm_dist_unique_id", "psm_dist_init", "psm_dist_prepare", "psm_dist_connect", "psm_dist_connect_transport", "psm_dist_connect_hoststaged",
-    "psm_dist_transport_name", "psm_dist_agree", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_gather_tiles",
+    "psm_dist_transport_name", "psm_dist_agree", "psm_dist_destroy", "psm_dist_rank", "psm_dist_world", "psm_dist_comm_ranks", "psm_dist_gather_tiles",
     "psm_dist_allgather_i32", "psm_dist_barrier", "psm_dist_decide", "psm_dist_render_batch", "psm_dist_render_frames", "psm_dist_emulate_tile", "psm_dist_set_band_weights",
 ]
 

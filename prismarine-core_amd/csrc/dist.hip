@@ -144,6 +144,7 @@ int psm_dist_connect_transport(psm_dist* d, const psm_dist_transport* t) {
     if (d->connected) return set_err(d->ctx, PSM_ERR_STATE, "psm_dist_connect: the communicator already has a transport");
     d->tr = *t;
     d->connected = true;
+    d->comm_ranks = d->world;   // (a caller's own transport: taken at its word; RCCL and the host-staged one overwrite it with what they count)
     return PSM_OK;
 }
 
@@ -161,8 +162,19 @@ int psm_dist_connect(psm_dist* d, const uint8_t id[128]) {
         delete t;
         return PSM_ERR_HIP;
     }
+    // what RCCL itself says about the communicator: its size and this process's rank in it (a launcher that handed two
+    // processes the same rank, or a world the id was not made for, must not pass for an 8-GPU run)
+    int cnt = -1, ur = -1;
+    if (ncclCommCount(t->comm, &cnt) != ncclSuccess || ncclCommUserRank(t->comm, &ur) != ncclSuccess || cnt != d->world || ur != d->rank) {
+        d->ctx->err = "psm_dist_connect: the RCCL communicator reports " + std::to_string(cnt) + " ranks, this one as " + std::to_string(ur) +
+                      " (asked for rank " + std::to_string(d->rank) + " of " + std::to_string(d->world) + ")";
+        rccl_destroy(t);
+        return PSM_ERR_STATE;
+    }
     psm_dist_transport tr = {t, rccl_gather_f32, rccl_allgather_i32, rccl_destroy, rccl_last_error, "rccl"};
-    return psm_dist_connect_transport(d, &tr);
+    int rc = psm_dist_connect_transport(d, &tr);
+    if (rc == PSM_OK) d->comm_ranks = cnt;
+    return rc;
 }
 
 int psm_dist_init(psm_ctx* ctx, int rank, int world, const uint8_t id[128], psm_dist** out) {
@@ -176,6 +188,7 @@ int psm_dist_init(psm_ctx* ctx, int rank, int world, const uint8_t id[128], psm_
 
 int psm_dist_rank(const psm_dist* d) { return d ? d->rank : -1; }
 int psm_dist_world(const psm_dist* d) { return d ? d->world : -1; }
+int psm_dist_comm_ranks(const psm_dist* d) { return d ? d->comm_ranks : -1; }
 const char* psm_dist_transport_name(const psm_dist* d) { return (d && d->connected) ? d->tr.name : nullptr; }
 
 // One-GPU rehearsal of another rank's share (bench.py --emulate-tile R/W --force-dist): the communicator keeps its real

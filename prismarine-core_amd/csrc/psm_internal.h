@@ -257,6 +257,7 @@ struct psm_dist {
     void (*idle_fn)(void*) = nullptr;
     void* idle_user = nullptr;
     int rank = 0, world = 1;
+    int comm_ranks = 0;                 // ranks the TRANSPORT says it joins (RCCL: ncclCommCount; host-staged: the processes attached to the segment); 0 while not connected
     int tile_rank = 0, tile_world = 1;  // the tile geometry gathers use: (rank, world) unless psm_dist_emulate_tile changed it
     psm::BandMap bands;                 // the dealing of the bands (psm_dist_set_band_weights); default round-robin over tile_world
     float* d_send = nullptr;   // per_floats

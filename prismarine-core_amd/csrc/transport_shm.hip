@@ -205,5 +205,6 @@ extern "C" int psm_dist_connect_hoststaged(psm_dist* d, const char* shm_name, si
     psm_dist_transport tr = {t, shm_gather_f32, shm_allgather_i32, shm_destroy, shm_last_error, "host-staged"};
     int rc = psm_dist_connect_transport(d, &tr);
     if (rc != PSM_OK) shm_destroy(t);
+    else d->comm_ranks = (int)t->hdr->attached.load(std::memory_order_acquire);   // the processes that attached to the segment
     return rc;
 }

@@ -68,6 +68,11 @@ class NativeDist:
         v = self._lib.psm_dist_transport_name(self._h)
         return v.decode() if v else None
 
+    @property
+    def comm_ranks(self):
+        """ranks the transport itself counts (RCCL: ncclCommCount); 0 while not connected"""
+        return int(self._lib.psm_dist_comm_ranks(self._h))
+
     def agree(self, local_rc=0):
         """psm_dist_agree: 0 when every rank passed 0, this rank's code when it failed, PSM_ERR_PEER when only others did."""
         return self._lib.psm_dist_agree(self._h, self._C.c_int(local_rc))
@@ -224,6 +229,15 @@ class Comm:
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_floats(self, values):
+        """every rank's short list of floats, on every rank: [world][len(values)] (host path)"""
+        if not self.active or self.world <= 1:
+            return [[float(v) for v in values]]
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[float(v) for v in o.cpu().tolist()] for o in out]
 
     def sum_ints(self, values):
         """Element-wise sum over ranks of a short list of ints (host path)."""

@@ -16,6 +16,9 @@ EXTRA=${2:-}
 STEPS=${STEPS:-8}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
+# what the counters belong to: the sources of the traversal and shading kernels as they are NOW (make_traffic.py puts these into the
+# json; bench.py compares them with the sources it runs from and marks replayed counters stale when a kernel has changed since)
+( cd $REPO && sha256sum prismarine-core_amd/csrc/trace.hip prismarine-core_amd/csrc/shade.hip prismarine-core_amd/csrc/psm_common.h prismarine-core_amd/csrc/psm_math.h prismarine-core_amd/csrc/psm_internal.h ) > $OUT/${TAG}_sources.sha256
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # the profiler initialises the runtime before bench.py can set it
 B="python3 $REPO/bench.py --no-cpu-baseline --no-obj-roundtrip --repeats 1"

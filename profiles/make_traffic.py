@@ -25,10 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def norm(k):
-    """rt_traverse<COUNT, CHAIN, PHASED, GROUP>: the single-Pipeline instantiations (GROUP = false) keep their three-argument
-    names of rounds 1-2"""
-    k = k.replace("void ", "").split("(")[0]
-    return k.replace(", false>", ">") if k.count(",") == 3 and k.endswith(", false>") else k
+    """rt_traverse<COUNT, CHAIN, PHASED>"""
+    return k.replace("void ", "").split("(")[0]
 
 
 def per_kernel(tag, sub, want):
@@ -106,7 +104,24 @@ def main():
                 entries.append({"scene": scene, "width": w, "height": h, "kernel": k, "launches_sampled": c["SQ_INSTS_VALU"][0],
                                 "sq_per_launch": {n: a[1] / a[0] for n, a in c.items()},
                                 "source": "rocprofv3 --pmc SQ_* pass of profiles/collect.sh %s (bench as timed)" % tag})
-    json.dump({"entries": entries}, open(out_path, "w"), indent=1)
+    # provenance: the kernel sources the passes ran with (collect.sh wrote their hashes on the GPU box) and the commit this is
+    # filed under; bench.py recomputes the hashes from the sources it runs from and flags a replay of stale counters
+    prov = {"sources_sha256": {}, "commit": None, "tags": sorted({args[q] for q in range(0, len(args), 4)})}
+    for tag in prov["tags"]:
+        path = os.path.join(ROOT, "gpurun_out", "%s_sources.sha256" % tag)
+        if os.path.exists(path):
+            for line in open(path):
+                h, name = line.split()
+                if prov["sources_sha256"].setdefault(name, h) != h:
+                    raise SystemExit("make_traffic: %s differs between the tags' passes" % name)
+    try:
+        import subprocess
+        prov["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+        prov["commit_note"] = "HEAD when make_traffic.py ran" + ("; the tree had uncommitted changes in csrc/" if subprocess.check_output(
+            ["git", "-C", ROOT, "status", "--porcelain", "prismarine-core_amd/csrc"], text=True).strip() else "")
+    except Exception:
+        pass
+    json.dump({"provenance": prov, "entries": entries}, open(out_path, "w"), indent=1)
     print("wrote %d entries to %s" % (len(entries), out_path))
 
 

@@ -305,6 +305,13 @@ def test_bench_under_the_drivers_launcher_command():
     # (the ranks share the launcher's stdout: two lines written at the same moment can arrive as one)
     seen = re.findall(r"bench\.py dry run: rank (\d+) of (\d+) reached its communicator; all-reduce over the group = (\d+)", out.stdout)
     assert sorted(seen) == [("0", "2", "2"), ("1", "2", "2")], out.stdout[-1000:]
+    # rank 0's line carries the multi-rank fields of the real line (a scaling line must say how many ranks the
+    # communicator saw, what each rank traced and that sharded == unsharded was checked): here from gloo's collectives
+    import json
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["value"] is None
+    assert line["ranks"]["comm_ranks"] == 2 and line["ranks"]["ranks_heard_from"] == [0, 1] and len(line["ranks"]["rays_traced_per_rank"]) == 2
+    assert "rccl_ranks" in line and line["sharded_check"].startswith("not run")
 
 
 def test_native_decide_equals_python_protocol():

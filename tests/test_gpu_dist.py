@@ -163,12 +163,14 @@ def test_c4_sponza_1080p_16_frames_tile_sharded_over_4_ranks(psm, scenes, tmp_pa
 
 
 def test_c5_stress_2160p_tile_sharded_over_2_ranks(psm, scenes, tmp_path):
-    """BASELINE C5's scene and resolution sharded: S-stress (9 999 616 triangles, rebuilt per frame on every rank), 3840x2160,
-    2 frames, world 2 with the default 11 : 12 dealing. Same bar as above."""
+    """BASELINE C5's scene, resolution and sample count sharded: S-stress (9 999 616 triangles, rebuilt per frame on every rank),
+    3840x2160, 8 frames (C5's 8 spp) on 2 lanes, world 2 with the default 11 : 12 dealing (the box lets six processes use its
+    card and the ten-million-triangle scene is held three times over as it is; world 8 of the dealing and the protocol is the
+    gloo test of tests/test_dist_cpu.py). Same bar as above."""
     pdist = importlib.import_module("prismarine-core_amd.dist")
     weights = pdist.default_band_weights(2)
     assert weights == [11, 12]
-    check_equal(psm, scenes, tmp_path, 2, scene="stress", w=3840, h=2160, lanes=2, frames=2, seed=1000, mode="frames", weights=weights,
+    check_equal(psm, scenes, tmp_path, 2, scene="stress", w=3840, h=2160, lanes=2, frames=8, seed=1000, mode="frames", weights=weights,
                 timeout_ms=300000)
 
 
@@ -200,3 +202,38 @@ def test_missing_peer_times_out_instead_of_hanging(psm, ctx):
     finally:
         nd.close()
         assert not os.path.exists("/dev/shm" + name)
+
+
+def _bench_ranks(tmp_path, world, extra_env=None, timeout=420):
+    """bench.py --gpus N the way a user starts it (it spawns its ranks itself), the ranks sharing GPU 0 over the host-staged
+    transport: a rehearsal line (value null) -- here for its self-check and its multi-rank fields."""
+    env = dict(os.environ, PSM_DIST_TRANSPORT="hoststaged", PSM_DIST_BACKEND="gloo", **(extra_env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--scene", "cornell", "--width", "320", "--height", "184",
+                           "--steps", "4", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-obj-roundtrip"],
+                          env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_proves_sharded_equals_unsharded_before_it_times(tmp_path):
+    """bench.py on 2 ranks: before the warm-up it renders a small frame set through psm_dist_render_frames on the run's own
+    communicator and dealing and the same frames unsharded on rank 0 (sharded_self_check); the line then says how many ranks
+    the transport counted, what every rank traced, and sharded_check = ok."""
+    out = _bench_ranks(tmp_path, 2)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["sharded_check"] == "ok" and line["sharded_check_detail"]["largest_difference"] < 1e-5
+    rk = line["ranks"]
+    assert rk["world"] == 2 and rk["comm_ranks"] == 2 and rk["transport"] == "host-staged" and line["rccl_ranks"] is None
+    assert len(rk["rays_traced_per_rank"]) == 2 and min(rk["rays_traced_per_rank"]) > 0
+    assert sum(rk["rays_traced_per_rank"]) == round(line["rays_per_frame"] * line["steps"])
+    assert rk["per_frame_ms_over_ranks"]["traverse"]["min"] > 0 and rk["per_frame_ms_over_ranks"]["gather"]["max"] > 0
+    assert line["rehearsal"] is True and line["value"] is None      # ranks that share a GPU: never a scaling figure
+
+
+def test_bench_self_check_fails_every_rank_when_one_renders_another_picture(tmp_path):
+    """The same run with rank 1 looking at the check scene from somewhere else (PSM_BENCH_SABOTAGE_RANK): its bands of the
+    gathered image are another picture's, the check sees it, nothing is timed, every rank exits with code 4."""
+    out = _bench_ranks(tmp_path, 2, {"PSM_BENCH_SABOTAGE_RANK": "1"})
+    assert out.returncode == 4, (out.returncode, out.stderr[-2000:])
+    assert "sharded self-check FAILED" in out.stderr and not any(l.startswith("{") for l in out.stdout.splitlines())

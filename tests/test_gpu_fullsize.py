@@ -99,6 +99,57 @@ def test_build_2m_triangles_invariants(psm, ctx, scenes):
     th.close()
 
 
+def test_c1_substitute_sponza_256_1spp(psm, ctx, oracle, scenes):
+    """BASELINE config 1 -- `sponza.obj 256x256 1spp via the reference's OpenGL-compute path` -- cannot run (no GL context, no
+    glslc, no scene file: SURVEY 8c); its named substitute is the CPU oracle at 256 x 256, the reference's default Pipeline
+    size (Include/Prismarine/Pipeline.hpp:87-90). The whole Sponza-class scene (262 267 triangles), 256 x 256, one frame of
+    one sample per pixel: EVERY primary ray's hit chain -- triangle ids, t, u, v bits -- against the oracle's, then the
+    whole frame's image within 1e-4 with equal deposit counts and ray / round counts."""
+    sc = scenes.sponza_like()
+    w = h = 256
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(sc["tris"].shape[0])
+    th.loadTriangles(sc["tris"], sc["normals"], sc["mats"])
+    ms = psm.MaterialSet()
+    for m in sc["materials"]:
+        ms.addSubmat(m)
+    rt = psm.Pipeline(ctx, seed=256)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    # primary rays: all 65 536 of them
+    ob = oracle.build_scene(sc["tris"])
+    th.markDirty()
+    th.build()
+    rt.camera(sc["eye"], sc["view"])
+    rays = rt.download_rays()
+    assert rays.shape[0] == w * h
+    rt.intersection(th)
+    gh, gc = rt.download_hits(w * h)
+    oh, oc, _ = oracle.traverse(ob["nodes"], sc["tris"], ob["M"], rays["origin"], rays["direct"], 16)
+    assert np.array_equal(gc, oc) and (oc > 0).mean() > 0.5
+    for k in range(int(oc.max())):
+        m = oc > k
+        assert np.array_equal(gh["tri"][m, k], oh["tri"][m, k])                       # hit-triangle indices, chain order
+        for f in ("t", "u", "v"):
+            assert np.array_equal(gh[f][m, k].view(np.uint32), oh[f][m, k].view(np.uint32))
+    # the frame: GltfViewer::process() (Viewer.cpp:296-312) once
+    rt.setSeed(256)
+    rt.clearSampler()
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    psm.render_frame(rt, th, ms, sc["eye"], sc["view"])
+    st = ctx.stats()
+    ctx.stats_enable(False, False)
+    img = rt.snapHdr()
+    ref, ost = oracle.render_frames(sc, w, h, frames=1, seed=256, nthreads=16)
+    assert st.rays_traced == ost["rays"] and ost["rays"] > 3 * w * h
+    np.testing.assert_allclose(img[..., :3], ref[..., :3], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    assert ref[..., :3].mean() > 0.05
+    rt.close()
+    th.close()
+
+
 def test_full_1080p_frame_sampled_parity_determinism_conservation(psm, ctx, oracle, scenes):
     """BASELINE config 3: Sponza-class scene, 1920x1080, full rebuild + loop."""
     sc = scenes.sponza_like()

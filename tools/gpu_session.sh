@@ -5,6 +5,8 @@
 #   tools/gpu_session.sh bench <tag> [bench args] one bench line -> gpurun_out/<tag>.json / .err
 #   tools/gpu_session.sh tiles <tag>              tile emulation sweep (native sharded path, one GPU)
 #   tools/gpu_session.sh collect <tag> [args]     profiles/collect.sh
+#   tools/gpu_session.sh rehearsal <tag>          bench.py --gpus 2 and 4 with the ranks SHARING this GPU (host-staged transport):
+#                                                 the sharded path end to end incl. its self-check -- a rehearsal, value = null
 set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
@@ -45,5 +47,16 @@ PY
     done ;;
   collect)
     bash profiles/collect.sh "$@" ;;
+  rehearsal)
+    tag=$1; shift
+    for n in 2 4; do
+      PSM_DIST_TRANSPORT=hoststaged PSM_DIST_BACKEND=gloo timeout -k 10 400 python bench.py --gpus $n --steps 16 --warmup 4 --no-cpu-baseline --repeats 2 "$@" > gpurun_out/${tag}_gpus${n}_hoststaged.json 2> gpurun_out/${tag}_gpus${n}.err || { tail -20 gpurun_out/${tag}_gpus${n}.err; exit 1; }
+      python - <<PY
+import json
+d = json.loads([l for l in open("gpurun_out/${tag}_gpus${n}_hoststaged.json") if l.startswith("{")][-1])
+print("rehearsal $n ranks on one GPU: rehearsal=%s value=%s (%.0f Mrays/s, %.3f ms/step) sharded_check=%s comm_ranks=%s rays per rank %s" % (
+    d.get("rehearsal"), d["value"], d["rehearsal_value_mrays_s"], d["ms_per_step"], d["sharded_check"], d["ranks"]["comm_ranks"], d["ranks"]["rays_traced_per_rank"]))
+PY
+    done ;;
   *) echo "unknown step $what"; exit 2 ;;
 esac
