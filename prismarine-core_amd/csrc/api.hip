@@ -420,6 +420,7 @@ static int bvh_upload_opt(psm_bvh* b, const double* opt) {
     b->opt_uploaded = false;
     memcpy(b->opt_host, want, sizeof(b->opt_host));
     PSM_HIP(c, hipMemcpyAsync(b->d_opt, b->opt_host, 16 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    { int rc = launch_bvh_opt_changed(b); if (rc != PSM_OK) return rc; }   // first-pass transform + the bounds reduction's neutral elements: per matrix, not per build
     b->opt_uploaded = true;
     return PSM_OK;
 }

@@ -25,6 +25,7 @@ constexpr int SM_COUNT = 24;   // leaf count
 constexpr int SM_ROOT = 25;    // root link
 constexpr int SM_BFLOAT = 26;  // 8 floats: bounds after the -+1e-5 pad
 constexpr int SM_M0 = 34;      // 16 floats: first-pass transform inverse(opt)
+constexpr int SM_TICKET = 50;  // workgroups of bvh_bounds that have finished (the last one computes the fit transform and clears this)
 
 PSM_D int32_t float_to_ordered(float f) {
     int32_t i = (int32_t)f2u(f);
@@ -34,6 +35,9 @@ PSM_D float ordered_to_float(int32_t i) { return u2f((uint32_t)(i >= 0 ? i : (i 
 
 // ---- stage: bounds (hlbvh/minmax.comp:50-79 + TriangleHierarchy.inl:248-267) -------------------
 
+// Runs when the optimisation matrix is (first) uploaded, not per build: the first-pass transform inverse(opt)
+// (TriangleHierarchy.inl:226-232) and the neutral elements of the bounds reduction (minmax.comp:56); every build's last bounds
+// workgroup leaves the reduction words neutral again for the next one.
 __global__ void bvh_init_bounds(uint32_t* sm, const double* opt) {
     if (threadIdx.x == 0) {
         double mat[16];
@@ -46,11 +50,36 @@ __global__ void bvh_init_bounds(uint32_t* sm, const double* opt) {
         }
         sm[SM_COUNT] = 0;
         sm[SM_ROOT] = (uint32_t)-1;
+        sm[SM_TICKET] = 0;
     }
 }
 
-__global__ __launch_bounds__(256) void bvh_bounds(const float* __restrict__ pos, uint32_t n, uint32_t* sm) {
-    __shared__ float red[8][4];
+// TriangleHierarchy.inl:257-267: mat = inverse(translate(mn) * scale(mx - mn)) * inverse(opt),
+// double precision, cast to float -- evaluated on the device so the build never leaves the stream.
+PSM_D void fit_transform(uint32_t* sm, const double* opt, const int32_t* bounds) {
+    float mn[4], mx[4];
+    for (int c = 0; c < 4; c++) {
+        mn[c] = ordered_to_float(bounds[c]) - 0.00001f;  // minmax.comp:76-77
+        mx[c] = ordered_to_float(bounds[4 + c]) + 0.00001f;
+        sm[SM_BFLOAT + c] = f2u(mn[c]);
+        sm[SM_BFLOAT + 4 + c] = f2u(mx[c]);
+    }
+    float scale[3], offset[3];
+    for (int c = 0; c < 3; c++) { scale[c] = mx[c] - mn[c]; offset[c] = mn[c]; }
+    double mat[16];
+    gm_fit(scale, offset, opt, mat);
+    for (int r = 0; r < 4; r++)
+        for (int cc = 0; cc < 4; cc++) sm[SM_M + 4 * r + cc] = f2u((float)mat[4 * cc + r]);
+}
+
+// The bounds of the transformed vertices (minmax.comp:50-79) AND the fit transform in one launch (round 5; three launches before:
+// init, reduce, fit -- 21 us of a 0.15 ms C3 build were their launch latencies): every workgroup reduces its share (wave shuffles,
+// LDS, eight ordered-int atomics), takes a ticket, and the workgroup that draws the last one -- every other one's atomics are
+// complete, in L2, by then -- reads the result, evaluates the fit transform and leaves the reduction words neutral for the next build.
+constexpr int BOUNDS_BLOCK = 1024;   // (256 workgroups of 1024: four times the loads in flight of round 4's 256 x 256 on C5's 360 MB)
+__global__ __launch_bounds__(BOUNDS_BLOCK) void bvh_bounds(const float* __restrict__ pos, uint32_t n, uint32_t* sm, const double* opt) {
+    __shared__ float red[8][BOUNDS_BLOCK / 64];
+    __shared__ uint32_t s_last;
     float M[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) M[i] = u2f(sm[SM_M0 + i]);
@@ -83,29 +112,28 @@ __global__ __launch_bounds__(256) void bvh_bounds(const float* __restrict__ pos,
     if (threadIdx.x < 8) {
         int c = threadIdx.x;
         float v = red[c][0];
-        for (int q = 1; q < 4; q++) v = (c < 4) ? pmin(v, red[c][q]) : pmax(v, red[c][q]);
+        for (int q = 1; q < BOUNDS_BLOCK / 64; q++) v = (c < 4) ? pmin(v, red[c][q]) : pmax(v, red[c][q]);
         if (c < 4) atomicMin((int32_t*)&sm[SM_BOUNDS + c], float_to_ordered(v));
         else atomicMax((int32_t*)&sm[SM_BOUNDS + c], float_to_ordered(v));
     }
-}
-
-// TriangleHierarchy.inl:257-267: mat = inverse(translate(mn) * scale(mx - mn)) * inverse(opt),
-// double precision, cast to float -- evaluated on the device so the build never leaves the stream.
-__global__ void bvh_fit_transform(uint32_t* sm, const double* opt) {
-    if (threadIdx.x != 0) return;
-    float mn[4], mx[4];
-    for (int c = 0; c < 4; c++) {
-        mn[c] = ordered_to_float((int32_t)sm[SM_BOUNDS + c]) - 0.00001f;  // minmax.comp:76-77
-        mx[c] = ordered_to_float((int32_t)sm[SM_BOUNDS + 4 + c]) + 0.00001f;
-        sm[SM_BFLOAT + c] = f2u(mn[c]);
-        sm[SM_BFLOAT + 4 + c] = f2u(mx[c]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();   // this workgroup's eight atomics before its ticket
+        s_last = atomicAdd(&sm[SM_TICKET], 1u) == gridDim.x - 1u ? 1u : 0u;
     }
-    float scale[3], offset[3];
-    for (int c = 0; c < 3; c++) { scale[c] = mx[c] - mn[c]; offset[c] = mn[c]; }
-    double mat[16];
-    gm_fit(scale, offset, opt, mat);
-    for (int r = 0; r < 4; r++)
-        for (int cc = 0; cc < 4; cc++) sm[SM_M + 4 * r + cc] = f2u((float)mat[4 * cc + r]);
+    __syncthreads();
+    if (s_last == 0u || threadIdx.x != 0) return;
+    __threadfence();
+    int32_t b[8];
+    for (int c = 0; c < 8; c++) b[c] = __hip_atomic_load((int32_t*)&sm[SM_BOUNDS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fit_transform(sm, opt, b);
+    for (int c = 0; c < 4; c++) {   // neutral again for the next build (minmax.comp:56)
+        sm[SM_BOUNDS + c] = (uint32_t)float_to_ordered(100000.f);
+        sm[SM_BOUNDS + 4 + c] = (uint32_t)float_to_ordered(-100000.f);
+    }
+    sm[SM_COUNT] = 0;
+    sm[SM_ROOT] = (uint32_t)-1;
+    sm[SM_TICKET] = 0;
 }
 
 // traversal layout: v0, e1 = v1 - v0, e2 = v2 - v0 (the first three operations of
@@ -259,6 +287,9 @@ PSM_D LeafCalc leaf_calc(const float* __restrict__ pos, uint32_t t, const float*
     return r;
 }
 
+// (Round 5 tried the scan of the counts in the count kernel's last workgroup -- a launch less -- with every workgroup publishing its
+// count behind a release fence: on this chip a device-scope release writes the XCD's L2 back, and 9 766 of them took C5's Morton stage
+// from 0.175 to 0.62 ms (C3: 13 -> 19 us). bvh_bounds, 256 workgroups, keeps its last-workgroup step; the leaf compaction its three launches.)
 __global__ __launch_bounds__(256) void bvh_morton_count(const float* __restrict__ pos, uint32_t n,
                                                         const uint32_t* __restrict__ sm,
                                                         uint32_t* __restrict__ blockCounts) {
@@ -652,14 +683,19 @@ int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n) {
     return PSM_OK;
 }
 
+// the first-pass transform and the reduction's neutral elements: when the optimisation matrix is uploaded (api.hip: bvh_upload_opt)
+int launch_bvh_opt_changed(psm_bvh* b) {
+    bvh_init_bounds<<<1, 64, 0, b->ctx->stream>>>(b->d_small, b->d_opt);
+    PSM_HIP(b->ctx, hipGetLastError());
+    return PSM_OK;
+}
+
 int launch_bvh_bounds(psm_bvh* b) {
     psm_ctx* c = b->ctx;
     TimedScope ts(c, CAT_BOUNDS);
     uint32_t n = b->tri_count;
-    bvh_init_bounds<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
-    uint32_t grid = min((n + 255u) / 256u, 256u);  // one workgroup per CU: the 8 atomics per workgroup on the same 8 words are the cost
-    if (grid) bvh_bounds<<<grid, 256, 0, c->stream>>>(b->d_pos, n, b->d_small);
-    bvh_fit_transform<<<1, 64, 0, c->stream>>>(b->d_small, b->d_opt);
+    uint32_t grid = std::max(1u, std::min((n + BOUNDS_BLOCK - 1u) / BOUNDS_BLOCK, 256u));  // one workgroup per CU: the 8 atomics per workgroup on the same 8 words are the cost
+    bvh_bounds<<<grid, BOUNDS_BLOCK, 0, c->stream>>>(b->d_pos, n, b->d_small, b->d_opt);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }

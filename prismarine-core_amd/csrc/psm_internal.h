@@ -290,6 +290,7 @@ int launch_sort(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_max, co
 int sort_effective_algorithm(psm_ctx* c);
 int sort_check(psm_ctx* c);
 int sort_reserve(psm_ctx* c, size_t n_max);
+int launch_bvh_opt_changed(psm_bvh* b);
 int launch_bvh_bounds(psm_bvh* b);
 int launch_bvh_morton(psm_bvh* b);
 int launch_bvh_emit(psm_bvh* b);
