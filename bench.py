@@ -105,6 +105,7 @@ class Renderer:
         # frames in flight: 4 on one GPU; 12 for a tile of a sharded frame (a tile's launches are all tail: profiles/r04_tile_emulation.txt,
         # 8 -> 12 lanes with 16 hardware queues: a worker's 1/8 tile 0.611 -> 0.588 ms, C5's 3.82 -> 3.64)
         self.lanes = args.lanes if args.lanes > 0 else ((8 if self.hoststaged else 12) if (dist.world > 1 or args.emulate_tile) else 4)
+        self.active_lanes = self.lanes   # frames in flight the sharded timed region uses: main() may settle for fewer (lane calibration)
         self.lane_streams = None
         streams = None
         if stream is not None:  # lane 0 on torch's current stream, the others on torch side streams
@@ -196,7 +197,7 @@ class Renderer:
         if self.native is not None and os.environ.get("PSM_DIST_PIPELINE", "1") != "0":
             # all k frames in the C ABI: rounds, exchanges, ONE gather per frame, fold -- no drain between batches
             before = [ln.ctx.stats().rays_traced for ln in batch.lanes]
-            batch.render_frames_sharded(self.native, batch.frame_seeds(k), self.cam[0], self.cam[1], depth=self.args.depth)
+            batch.render_frames_sharded(self.native, batch.frame_seeds(k), self.cam[0], self.cam[1], depth=self.args.depth, lanes=self.active_lanes)
             return sum(ln.ctx.stats().rays_traced - b for ln, b in zip(batch.lanes, before))
         for f0 in range(0, k, self.lanes):
             seeds = batch.frame_seeds(min(self.lanes, k - f0))
@@ -684,6 +685,29 @@ def main():
     run_steps(max(args.warmup, 0))
     R.batch.sync()
 
+    # Frames in flight per rank, settled by measurement: 12 lanes on 16 hardware queues won every one-GPU tile
+    # emulation (profiles/r04_tile_emulation.txt), but no multi-GPU run has confirmed it -- RCCL's own streams share the queues there.
+    # A sharded run with the default lane count therefore times a short untimed stretch with all its lanes and with two thirds of
+    # them (12 -> 8), every rank the same stretches, and keeps the faster (the maximum over the ranks decides, as in the timed region).
+    lane_cal = None
+    if dist.active and world > 1 and args.lanes == 0 and R.native is not None and os.environ.get("PSM_DIST_PIPELINE", "1") != "0" and R.lanes >= 4:
+        alt = max(2, (R.lanes * 2 // 3) & ~1)
+        kc = 2 * R.lanes
+
+        def stretch(n):
+            R.active_lanes = n
+            dist.barrier()
+            R.batch.sync()
+            c0 = time.perf_counter()
+            run_steps(kc)
+            R.batch.sync()
+            dist.barrier()
+            return dist.max_float(time.perf_counter() - c0) / kc * 1e3
+        full, fewer = stretch(R.lanes), stretch(alt)
+        R.active_lanes = R.lanes if full <= fewer * 1.01 else alt
+        lane_cal = {"what": "untimed stretches of %d steps before the timed region, ms per step, maximum over the ranks" % kc,
+                    "lanes_%d" % R.lanes: full, "lanes_%d" % alt: fewer, "chosen": R.active_lanes}
+
     # counting pass: the frames of the timed region (same rand() streams), one after another on lane 0,
     # counters on: V, T, R are deterministic per seed; logged per bounce round
     reseed()
@@ -871,9 +895,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S-%s %d tris, %dx%d, 1 spp per step (4 steps = 4 spp), full HLBVH rebuild "
                                    "per frame + camera + <=%d bounce rounds + sample; %d frame(s) in flight per GPU" % (
-                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth, R.lanes),
+                                       args.scene.replace("_", "-"), scene["tris"].shape[0], args.width, args.height, args.depth, R.active_lanes if dist.active else R.lanes),
                        "scene": args.scene + ("+tex" if args.textured else ""), "width": args.width, "height": args.height,
-                       "parallelism": "tile%d" % world, "frames_in_flight": R.lanes, "input": obj_note,
+                       "parallelism": "tile%d" % world, "frames_in_flight": R.active_lanes if dist.active else R.lanes, "input": obj_note,
                        "band_weights": R.weights,
                        "collectives": ("none" if not dist.active else
                                        "psm_dist_* (transport %s%s)" % (R.native.transport, ": a REHEARSAL, the ranks share a GPU and exchange through host memory -- not a scaling measurement" if R.hoststaged else " from libpsm_hip.so")
@@ -898,7 +922,7 @@ def main():
             out["ranks"] = {
                 "world": world, "transport": R.native.transport if R.native is not None else "torch.distributed " + dist.backend,
                 "comm_ranks": R.native.comm_ranks if R.native is not None else None,
-                "frames_in_flight_per_rank": R.lanes, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "frames_in_flight_per_rank": R.active_lanes, "lane_calibration": lane_cal, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "rays_traced_per_rank": [int(r[0]) for r in per_rank],
                 "per_frame_ms_over_ranks": {"what": "serial kernel pass of every rank (its tile's frames one after another); gather: pack + gather + rank 0's unpack, 5 in a row",
                                             "build": mm(1), "traverse": mm(2), "shade": mm(3), "gather": mm(4) if R.native is not None else None}}

@@ -31,6 +31,7 @@ namespace NSM {
         triangleCount = 0;
     }
 
+    inline void TriangleHierarchy::refit() { if (bvh) { check(psm_bvh_refit(bvh), "TriangleHierarchy::refit"); this->resolve(); } }
     inline void TriangleHierarchy::setBuildGraph(bool enable) { if (bvh) check(psm_bvh_set_build_graph(bvh, enable ? 1 : 0), "TriangleHierarchy::setBuildGraph"); }
     inline void TriangleHierarchy::configureIntersection(bool clearDepth) { (void)clearDepth; }  // ignored by the reference's shaders too
 

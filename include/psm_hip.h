@@ -141,6 +141,11 @@ int psm_bvh_build(psm_bvh* bvh, const double* opt);
  * tiled frame drops from 31 % to 8 % of the wall time). Results are identical; enable = 0 keeps plain launches (default: 1).
  * Per-stage timing (psm_stats_enable) always uses plain launches. */
 int psm_bvh_set_build_graph(psm_bvh* bvh, int enable);
+/* Refit only (SURVEY f4 "refit-only dynamic updates"; the reference refits as the last stage of build() only): for a hierarchy
+ * that has been built and whose triangles were reloaded since -- the same number, in the same order, moved -- recompute the leaf
+ * boxes (aabbmaker.comp:165-194, with the transform of the build) and every node's child boxes bottom-up (refit.comp:21-114).
+ * Topology, ranges, triangle ids, sorted keys: the build's. PSM_ERR_STATE without a complete build of the current triangle count. */
+int psm_bvh_refit(psm_bvh* bvh);
 
 typedef struct {
     uint32_t triangle_count; /* uploaded triangles (tcounter, TriangleHierarchy.inl:209) */

@@ -187,6 +187,16 @@ def build_scene(tris, opt=None):
             "leafs": leafs, "nodes": nodes, "count": keys.shape[0], "levels": levels, "key_reads": reads}
 
 
+def refit(built, tris):
+    """psm_bvh_refit's semantics on a build_scene() result: the moved triangles' leaf boxes (aabbmaker.comp:165-194, the build's
+    transform) and the nodes' boxes bottom-up (refit.comp:21-114); topology untouched. Returns a copy of `built` with new
+    leafs / nodes."""
+    tris = np.ascontiguousarray(tris, np.float32)
+    leafs, nodes = built["leafs"].copy(), built["nodes"].copy()
+    lib().psmo_refit(_p(tris), _p(np.ascontiguousarray(built["M"], np.float32)), _p(leafs), C.c_int(leafs.shape[0]), _p(nodes), C.c_int(nodes.shape[0]))
+    return dict(built, leafs=leafs, nodes=nodes)
+
+
 def traverse(nodes, tris, M, origins, directs, nthreads=0, want_hits=True):
     tris = np.ascontiguousarray(tris, np.float32)
     origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

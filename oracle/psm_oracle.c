@@ -398,6 +398,35 @@ int psmo_build_nodes(const uint64_t* keys, const int32_t* idx, psmo_node* leafs,
     return lcounter;
 }
 
+/* Refit only: the triangles have moved, the tree stays. Leaf boxes as aabbmaker.comp:165-176,193-194 computes them,
+ * with the transform M of the build, for the triangle each leaf slot holds (a leaf stays a leaf even if its triangle would now
+ * fail aabbmaker's degeneracy tests: those decide what a BUILD keeps); then child-link.comp:38-45 (the leaf node takes its
+ * leaf's box) and refit.comp:63-110 (bottom-up union) over the nodes as built. */
+void psmo_refit(const float* tris, const float M[16], psmo_node* leafs, int nleafs, psmo_node* nodes, int nnodes) {
+    for (int s = 0; s < nleafs; s++) {
+        float v[3][4], bmn[4], bmx[4];
+        load_tri_xformed(tris, leafs[s].pdata[3], M, v);
+        for (int k = 0; k < 4; k++) {
+            bmn[k] = pmin(pmin(v[0][k], v[1][k]), v[2][k]) - PSMO_PZERO;
+            bmx[k] = pmax(pmax(v[0][k], v[1][k]), v[2][k]) + PSMO_PZERO;
+        }
+        pack_half4(bmn, &leafs[s].box[0]);
+        pack_half4(bmx, &leafs[s].box[2]);
+        if (leafs[s].pdata[2] >= 0 && leafs[s].pdata[2] < nnodes) memcpy(nodes[leafs[s].pdata[2]].box, leafs[s].box, sizeof(leafs[s].box));
+    }
+    for (int id = nnodes - 1; id >= 0; id--) {   /* BFS numbering: children after parents */
+        psmo_node* nd = &nodes[id];
+        if (nd->pdata[0] != nd->pdata[1]) {
+            const psmo_node* ln = &nodes[nd->pdata[0]];
+            const psmo_node* rn = &nodes[nd->pdata[1]];
+            nd->box[0] = half2_min(ln->box[0], rn->box[0]);
+            nd->box[1] = half2_min(ln->box[1], rn->box[1]);
+            nd->box[2] = half2_max(ln->box[2], rn->box[2]);
+            nd->box[3] = half2_max(ln->box[3], rn->box[3]);
+        }
+    }
+}
+
 /* TriangleHierarchy::build, TriangleHierarchy.inl:206-329 */
 int psmo_build(const float* tris, int n, const double opt[16], float M[16], uint64_t* keys,
                int32_t* idx, psmo_node* leafs, psmo_node* nodes) {

@@ -79,6 +79,7 @@ int psmo_find_split(const uint64_t* keys, int first, int last, uint64_t* key_rea
 int psmo_build_nodes(const uint64_t* keys, const int32_t* idx, psmo_node* leafs, int n,
                      psmo_node* nodes, int* levels, uint64_t* key_reads);
 /* whole TriangleHierarchy::build; returns leaf count; nodes sized 2*n */
+void psmo_refit(const float* tris, const float M[16], psmo_node* leafs, int nleafs, psmo_node* nodes, int nnodes);
 int psmo_build(const float* tris, int n, const double opt[16], float M[16], uint64_t* keys,
                int32_t* idx, psmo_node* leafs, psmo_node* nodes);
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "psm_device_count", "psm_ctx_create", "psm_ctx_create_on_stream", "psm_ctx_destroy", "psm_ctx_sync", "psm_ctx_copy_bandwidth", "psm_ctx_stream", "psm_last_error",
     "psm_buf_alloc", "psm_buf_free", "psm_buf_upload", "psm_buf_download", "psm_buf_ptr",
     "psm_sort_u64_u32", "psm_sort_u64_u32_dev", "psm_sort_set_algorithm", "psm_sort_get_algorithm",
-    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph",
+    "psm_bvh_create", "psm_bvh_destroy", "psm_bvh_clear", "psm_bvh_load_triangles", "psm_bvh_set_texcoords", "psm_bvh_load_mesh", "psm_bvh_build", "psm_bvh_set_build_graph", "psm_bvh_refit",
     "psm_bvh_get_info", "psm_bvh_stage_bounds", "psm_bvh_stage_morton", "psm_bvh_stage_sort",
     "psm_bvh_stage_emit", "psm_bvh_download",
     "psm_rt_create", "psm_rt_destroy", "psm_rt_resize_buffers", "psm_rt_resize", "psm_rt_set_tile", "psm_rt_set_tile_interleaved", "psm_rt_set_tile_weighted",
@@ -353,6 +353,12 @@ class TriangleHierarchy:
             return
         opt = None if optimization is None else np.ascontiguousarray(optimization, np.float64).reshape(16)
         self.ctx.check(lib().psm_bvh_build(self._h, _p(opt) if opt is not None else None), "psm_bvh_build")
+        self.resolve()
+
+    def refit(self):
+        """psm_bvh_refit (not in the reference): the triangles were reloaded -- same count, same order, moved -- and only
+        the boxes are recomputed; the tree is the last build's."""
+        self.ctx.check(lib().psm_bvh_refit(self._h), "psm_bvh_refit")
         self.resolve()
 
     def setBuildGraph(self, enable=True):
@@ -717,6 +723,74 @@ def read_pfm(path):
     return data.copy()
 
 
+def write_exr(path, image):
+    """Save an HDR snapshot as the app does on key L (PathTracerApplication::saveHdr, Application.hpp:324-343: FreeImage FIT_RGBAF ->
+    FIF_EXR, EXR_FLOAT): an OpenEXR scan-line file, channels A B G R as 32-bit floats, one scan line per chunk, NO_COMPRESSION
+    (the app asks FreeImage for PIZ; which lossless compression a file uses is invisible to its readers). The app copies row r of
+    snapHdr()'s image into FreeImage scan line r, which FreeImage counts from the BOTTOM: the file's first (top) scan line is the
+    image's last row. `image`: [h, w, 3 or 4] float; a missing alpha is written as 1."""
+    import struct
+    img = np.asarray(image, np.float32)
+    h, w = img.shape[:2]
+    rgba = np.ones((h, w, 4), np.float32)
+    rgba[..., :img.shape[2]] = img[..., :4]
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+    chlist = b"".join(n + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in (b"A", b"B", b"G", b"R")) + b"\0"   # 2 = FLOAT
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    header = (struct.pack("<ii", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", b"\0") +
+              attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") +
+              attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) +
+              attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    line_bytes = 4 * w * 4
+    first = len(header) + 8 * h
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(np.arange(h, dtype="<u8").__mul__(8 + line_bytes).__add__(first).astype("<u8").tobytes())   # offset table
+        for y in range(h):
+            row = rgba[h - 1 - y]                                   # top scan line first
+            f.write(struct.pack("<ii", y, line_bytes))
+            f.write(np.ascontiguousarray(row[:, [3, 2, 1, 0]].T, "<f4").tobytes())   # channel by channel: A, B, G, R
+
+
+def read_exr(path):
+    """The image of an uncompressed 32-bit-float scan-line OpenEXR file (what write_exr writes; any channel set), in snapHdr()'s
+    row order: [h, w, 4] RGBA, a channel the file lacks reads 0 (alpha: 1)."""
+    import struct
+    data = open(path, "rb").read()
+    magic, version = struct.unpack_from("<ii", data, 0)
+    assert magic == 20000630 and (version & 0xFF) == 2 and not (version & 0x200), "not a scan-line OpenEXR 2 file"
+    pos, attrs = 8, {}
+    while data[pos] != 0:
+        e = data.index(b"\0", pos); name = data[pos:e].decode(); pos = e + 1
+        e = data.index(b"\0", pos); typ = data[pos:e].decode(); pos = e + 1
+        (size,) = struct.unpack_from("<i", data, pos); pos += 4
+        attrs[name] = (typ, data[pos:pos + size]); pos += size
+    pos += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0", "only uncompressed, increasing-y files"
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans, cp, cl = [], 0, attrs["channels"][1]
+    while cl[cp] != 0:
+        e = cl.index(b"\0", cp); nm = cl[cp:e].decode(); cp = e + 1
+        ptype, = struct.unpack_from("<i", cl, cp); cp += 16
+        assert ptype == 2, "only 32-bit float channels"
+        chans.append(nm)
+    out = np.zeros((h, w, 4), np.float32)
+    out[..., 3] = 1.0
+    offs = np.frombuffer(data, "<u8", h, pos)
+    for y in range(h):
+        o = int(offs[y])
+        yy, nbytes = struct.unpack_from("<ii", data, o)
+        assert nbytes == 4 * w * len(chans)
+        line = np.frombuffer(data, "<f4", w * len(chans), o + 8).reshape(len(chans), w)
+        for k, nm in enumerate(chans):
+            if nm in "RGBA":
+                out[h - 1 - (yy - y0), :, "RGBA".index(nm)] = line[k]
+    return out
+
+
 def sharded_rounds(rays, intersector, materials, depth=16):
     """The bounce loop of Viewer.cpp:304-310 for one tile of a sharded frame, as a generator: yields
     the local ray count and is sent the GLOBAL count (sum over tiles), so the reference's
@@ -880,11 +954,12 @@ class FrameBatch:
             ln.rays._obj = ln.th
         return list(rounds)
 
-    def render_frames_sharded(self, native, seeds, cam_inv, proj_inv, depth=16, rebuild=True):
-        """len(seeds) tile-sharded frames with all lanes in flight and no drain between batches (psm_dist_render_frames)."""
-        k, n = len(seeds), self.n
-        rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes])
-        bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes])
+    def render_frames_sharded(self, native, seeds, cam_inv, proj_inv, depth=16, rebuild=True, lanes=None):
+        """len(seeds) tile-sharded frames with all lanes (or the first `lanes` of them) in flight and no drain between batches
+        (psm_dist_render_frames)."""
+        k, n = len(seeds), (self.n if lanes is None else max(1, min(int(lanes), self.n)))
+        rts = (C.c_void_p * n)(*[ln.rays._h for ln in self.lanes[:n]])
+        bvhs = (C.c_void_p * n)(*[ln.th._h for ln in self.lanes[:n]])
         sd = (C.c_uint32 * max(k, 1))(*[v & 0xFFFFFFFF for v in seeds])
         rounds = (C.c_uint32 * max(k, 1))()
         ci = np.ascontiguousarray(cam_inv, np.float32).reshape(16)
@@ -892,7 +967,7 @@ class FrameBatch:
         rc = lib().psm_dist_render_frames(native._h, rts, bvhs, C.c_uint32(n), _p(ci), _p(pi), sd, C.c_uint32(k), C.c_uint32(depth),
                                           C.c_int(int(rebuild)), None, self.master._h, rounds)
         self.lanes[0].ctx.check(rc, "psm_dist_render_frames")
-        for ln in self.lanes:
+        for ln in self.lanes[:n]:
             ln.th._dirty = False
             ln.rays._obj = ln.th
         return list(rounds)[:k]

@@ -432,6 +432,7 @@ int psm_bvh_stage_bounds(psm_bvh* b, const double* opt) {
     if (b->tri_count == 0) return set_err(c, PSM_ERR_STATE, "build: no triangles");
     { int rc = bvh_upload_opt(b, opt); if (rc != PSM_OK) return rc; }
     b->built = false;  // a new build has begun: the node records of the last one can no longer be produced (psm_bvh_download)
+    b->topo_tris = 0;  // ... nor can it be refitted: its transform and keys are being replaced
     int rc = launch_bvh_bounds(b);
     if (rc == PSM_OK) b->bounds_done = true;
     return rc;
@@ -457,7 +458,25 @@ int psm_bvh_stage_emit(psm_bvh* b) {
     (void)hipSetDevice(b->ctx->device);
     if (!b->sort_done) return set_err(b->ctx, PSM_ERR_STATE, "emit before sort");
     int rc = launch_bvh_emit(b);
-    if (rc == PSM_OK) b->built = true;
+    if (rc == PSM_OK) { b->built = true; b->topo_tris = b->tri_count; }
+    return rc;
+}
+
+// Refit only (no entry point of the reference does this on its own: its refit is the last stage of build()): the
+// triangles of a hierarchy that was built have moved -- same count, reloaded in the same order -- and only the boxes are
+// recomputed: leaf boxes (aabbmaker.comp:165-194) with the build's transform, every node's child boxes bottom-up
+// (refit.comp:21-114). Topology, ranges and triangle ids stay the build's (a triangle the build dropped as degenerate stays
+// dropped, one that has become degenerate keeps its leaf). C3: 0.04 ms against the rebuild's 0.14.
+int psm_bvh_refit(psm_bvh* b) {
+    if (!b) return PSM_ERR_INVALID;
+    psm_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    if (b->tri_count == 0 || b->topo_tris != b->tri_count)
+        return set_err(c, PSM_ERR_STATE, "psm_bvh_refit: no complete build of this triangle count to refit (build first; reload the same number of triangles)");
+    TimedScope ts(c, CAT_BUILD);
+    int rc = launch_bvh_refit_leaves(b);
+    if (rc == PSM_OK) rc = launch_bvh_emit(b);
+    if (rc == PSM_OK) b->bounds_done = b->morton_done = b->sort_done = b->built = true;
     return rc;
 }
 static int bvh_build_plain(psm_bvh* b, const double* opt) {
@@ -530,6 +549,7 @@ int psm_bvh_build(psm_bvh* b, const double* opt) {
         return bvh_build_plain(b, opt);
     }
     c->sort_error_word = b->graph_error_word;
+    b->topo_tris = b->tri_count;
     b->bounds_done = b->morton_done = b->sort_done = b->built = true;
     b->records_valid = false;
     return PSM_OK;

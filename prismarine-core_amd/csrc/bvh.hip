@@ -344,6 +344,19 @@ __global__ __launch_bounds__(256) void bvh_morton_write(const float* __restrict_
     }
 }
 
+// Refit only: the leaf boxes of the triangles as they are NOW -- aabbmaker.comp:165-176,193-194 with the transform the
+// hierarchy was built with -- into the slots the build gave them. The segment tree and bvh_emit then recompute every node's child
+// boxes (refit.comp:21-114) from them; the sorted keys are untouched, so ranges, links and triangle ids come out as built.
+__global__ __launch_bounds__(256) void bvh_refit_leaves(const float* __restrict__ pos, const uint32_t* __restrict__ sm,
+                                                        const int32_t* __restrict__ leaftri, uint4* __restrict__ leafbox) {
+    float M[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) M[i] = u2f(sm[SM_M + i]);
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= sm[SM_COUNT]) return;
+    leafbox[s] = leaf_calc(pos, (uint32_t)leaftri[s], M).box;
+}
+
 // ---- stage: emit + boxes ---------------------------------------------------------------------
 
 // sortable-key box: mins in x,y (min-reduced), maxes in z,w (max-reduced), per 16-bit lane
@@ -710,6 +723,16 @@ int launch_bvh_morton(psm_bvh* b) {
     scan_blocks<<<1, 1024, 0, c->stream>>>(b->d_block, nb, b->d_small + SM_COUNT);
     bvh_morton_write<<<nb, 256, 0, c->stream>>>(b->d_pos, n, b->d_small, b->d_block, b->d_keys, b->d_idx,
                                                 b->d_leafbox, b->d_leaftri);
+    PSM_HIP(c, hipGetLastError());
+    return PSM_OK;
+}
+
+int launch_bvh_refit_leaves(psm_bvh* b) {
+    psm_ctx* c = b->ctx;
+    TimedScope ts(c, CAT_MORTON);
+    const uint32_t n = b->tri_count;   // upper bound of the leaf count
+    if (n == 0) return PSM_OK;
+    bvh_refit_leaves<<<(n + 255u) / 256u, 256, 0, c->stream>>>(b->d_pos, b->d_small, b->d_leaftri, b->d_leafbox);
     PSM_HIP(c, hipGetLastError());
     return PSM_OK;
 }

@@ -150,6 +150,7 @@ struct psm_bvh {
     size_t cap = 0;
     uint32_t tri_count = 0;
     bool built = false, bounds_done = false, morton_done = false, sort_done = false;
+    uint32_t topo_tris = 0;       // triangle count of the last complete build whose sorted keys, leaf slots and transform are still on the device (psm_bvh_refit); 0: none
     float* d_pos = nullptr;       // 9 floats / triangle
     float* d_nrm = nullptr;       // 9 floats / triangle
     int32_t* d_mats = nullptr;    // material id / triangle
@@ -294,6 +295,7 @@ int launch_bvh_opt_changed(psm_bvh* b);
 int launch_bvh_bounds(psm_bvh* b);
 int launch_bvh_morton(psm_bvh* b);
 int launch_bvh_emit(psm_bvh* b);
+int launch_bvh_refit_leaves(psm_bvh* b);
 int launch_bvh_emit_records(psm_bvh* b);
 int launch_bvh_prepare_tris(psm_bvh* b, uint32_t first, uint32_t n);
 int launch_bvh_load_mesh(psm_bvh* b, const psm_mesh_desc* d, const psm_accessor* d_acc, const psm_buffer_view* d_views);

@@ -228,6 +228,8 @@ def test_bench_proves_sharded_equals_unsharded_before_it_times(tmp_path):
     assert len(rk["rays_traced_per_rank"]) == 2 and min(rk["rays_traced_per_rank"]) > 0
     assert sum(rk["rays_traced_per_rank"]) == round(line["rays_per_frame"] * line["steps"])
     assert rk["per_frame_ms_over_ranks"]["traverse"]["min"] > 0 and rk["per_frame_ms_over_ranks"]["gather"]["max"] > 0
+    cal = rk["lane_calibration"]      # the default lane count is settled by measurement: all lanes against two thirds of them
+    assert cal["chosen"] == rk["frames_in_flight_per_rank"] and cal["chosen"] in (8, 4) and cal["lanes_8"] > 0 and cal["lanes_4"] > 0
     assert line["rehearsal"] is True and line["value"] is None      # ranks that share a GPU: never a scaling figure
 
 

@@ -244,9 +244,7 @@ def _built_equals_oracle(psm, oracle, th, ob):
     # the traversal records (written by the build: every node puts its own id into its parent's record) against the
     # reference-shaped records (links found by findSplit, produced on demand): same links, same twelve box coordinates
     n32 = th.download(psm.BVH_NODE32, np.uint32, 8 * (n - 1)).reshape(n - 1, 8)
-    off_n, off_t = getattr(th, "_node_off", 0), getattr(th, "_tri_off", 0)
-    want_link = np.where(link >= 0, link + off_n, ~(~link + off_t))
-    assert np.array_equal(n32[:, 6:8].view(np.int32), want_link.astype(np.int32))
+    assert np.array_equal(n32[:, 6:8].view(np.int32), link.astype(np.int32))
     def half(a, k):   # k-th fp16 of a row of packed words
         return (a[:, k // 2] >> (16 * (k % 2))) & 0xFFFF
     for side, first in ((0, 0), (4, 6)):      # left box: halves 0..5 of the record, right box: 6..11
@@ -307,6 +305,54 @@ def test_rebuild_replayed_as_captured_graph_is_bit_exact(psm, ctx, oracle, scene
         th.markDirty()
         th.build()
         _built_equals_oracle(psm, oracle, th, ob2)
+    th.close()
+
+
+def test_refit_only_keeps_the_tree_and_matches_the_oracle(psm, ctx, oracle, scenes):
+    """psm_bvh_refit (refit-only dynamic updates): the triangles of a built hierarchy are reloaded, moved -- the node
+    records afterwards are the build's topology with the boxes of oracle.refit (aabbmaker.comp:165-194 + refit.comp:21-114), bit
+    for bit, twice in a row (a refit of a refit), rays hit what the oracle's traversal of that tree hits, a rebuild afterwards is
+    a build again; without a build, or with another triangle count, the call is refused."""
+    sc = scenes.sponza_like(n_tris=20011)
+    th = psm.TriangleHierarchy(ctx)
+    th.allocate(sc["tris"].shape[0])
+    th.loadTriangles(sc["tris"], sc["normals"], sc["mats"])
+    with pytest.raises(psm.PsmError):
+        th.refit()                                   # nothing built yet
+    th.build()
+    ob = oracle.build_scene(sc["tris"])
+    _built_equals_oracle(psm, oracle, th, ob)
+    rng = np.random.RandomState(4)
+    tris = sc["tris"]
+    lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    for step in range(2):
+        tris = np.clip(tris + rng.normal(0, 0.03, tris.shape), lo, hi).astype(np.float32)   # (inside the build's bounds: its transform stays)
+        th.clearTribuffer()
+        th.loadTriangles(tris, scenes.prepare_normals(tris), sc["mats"])
+        th.refit()
+        ob = oracle.refit(ob, tris)
+        _built_equals_oracle(psm, oracle, th, ob)
+    # traversal of the refitted tree
+    w, h = 96, 54
+    rt = psm.Pipeline(ctx, seed=5)
+    rt.resizeBuffers(w, h)
+    rt.resize(w, h)
+    cam = scenes.camera_matrices(sc["eye"], sc["view"], w, h)
+    rt.camera_matrices(cam[0], cam[1], time=3)
+    rays = rt.download_rays()
+    rt.intersection(th, force=True)
+    gh, gc = rt.download_hits(rays.shape[0])
+    oh, oc, _ = oracle.traverse(ob["nodes"], tris, ob["M"], rays["origin"], rays["direct"], 8)
+    _hits_equal(gh, gc, oh, oc)
+    rt.close()
+    # another triangle count: no refit; a rebuild is a build
+    th.clearTribuffer()
+    th.loadTriangles(tris[:-5], scenes.prepare_normals(tris[:-5]), sc["mats"][:-5])
+    with pytest.raises(psm.PsmError):
+        th.refit()
+    th.markDirty()
+    th.build()
+    _built_equals_oracle(psm, oracle, th, oracle.build_scene(tris[:-5]))
     th.close()
 
 
