@@ -119,11 +119,11 @@ static int ctx_create(int device, void* ext_stream, bool use_ext, psm_ctx** out)
         delete c;
         return PSM_ERR_HIP;
     }
-    if (const char* t = std::getenv("PSM_SORT_TUNE")) {   // study knob (tools/sort_bench.py): "S_small,S_large,threads[,cap_small,cap_large]" of radix_local
-        unsigned a = 0, b = 0, th = 0, cs = 4096, cl = 5120;
-        const int got = std::sscanf(t, "%u,%u,%u,%u,%u", &a, &b, &th, &cs, &cl);
-        if (got >= 3 && a >= 64 && a < cs && b >= 64 && b < cl && (th == 512 || th == 1024)) {
-            c->sort_hybrid_s_small = a; c->sort_hybrid_s_large = b; c->sort_hybrid_threads = th;
+    if (const char* t = std::getenv("PSM_SORT_TUNE")) {   // study knob (tools/sort_bench.py): "S_small,S_large,threads[,cap_small,cap_large[,threads_large]]" of radix_local
+        unsigned a = 0, b = 0, th = 0, cs = 4096, cl = 4096, thl = 0;
+        const int got = std::sscanf(t, "%u,%u,%u,%u,%u,%u", &a, &b, &th, &cs, &cl, &thl);
+        if (got >= 3 && a >= 64 && a < cs && b >= 64 && b < cl && (th == 512 || th == 1024) && (thl == 0 || thl == 512 || thl == 1024)) {
+            c->sort_hybrid_s_small = a; c->sort_hybrid_s_large = b; c->sort_hybrid_threads = th; c->sort_hybrid_threads_large = thl ? thl : th;
             c->sort_hybrid_cap_small = cs; c->sort_hybrid_cap_large = cl;
         }
     }

@@ -76,7 +76,8 @@ PSM_D void fit_transform(uint32_t* sm, const double* opt, const int32_t* bounds)
 // init, reduce, fit -- 21 us of a 0.15 ms C3 build were their launch latencies): every workgroup reduces its share (wave shuffles,
 // LDS, eight ordered-int atomics), takes a ticket, and the workgroup that draws the last one -- every other one's atomics are
 // complete, in L2, by then -- reads the result, evaluates the fit transform and leaves the reduction words neutral for the next build.
-constexpr int BOUNDS_BLOCK = 1024;   // (256 workgroups of 1024: four times the loads in flight of round 4's 256 x 256 on C5's 360 MB)
+constexpr int BOUNDS_BLOCK = 1024;   // (256 workgroups of 1024: four times the loads in flight of round 4's 256 x 256 on C5's 360 MB; 1024 workgroups of 256 are
+                                     // equal alone and 4 % slower on a tile with 12 frames in flight, profiles/r05_wg_shapes_in_flight.txt)
 __global__ __launch_bounds__(BOUNDS_BLOCK) void bvh_bounds(const float* __restrict__ pos, uint32_t n, uint32_t* sm, const double* opt) {
     __shared__ float red[8][BOUNDS_BLOCK / 64];
     __shared__ uint32_t s_last;

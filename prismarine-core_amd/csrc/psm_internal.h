@@ -141,7 +141,7 @@ struct psm_ctx {
     int sort_algorithm = 2;             // 2 (default): hybrid -- two global passes over the top sixteen key bits, the rest in LDS; 0: histogram / scan / scatter kernels for all eight passes; 1: one-sweep
     uint32_t* sort_overflow = nullptr;  // pinned host word a hybrid sort raises when a chunk did not fit LDS (sorted through global memory: correct, slow)
     bool sort_demoted = false;          // ... seen raised: hybrid sorts of this context run as algorithm 0 from then on (psm_sort_set_algorithm clears it)
-    uint32_t sort_hybrid_s_small = 1024, sort_hybrid_s_large = 3072, sort_hybrid_threads = 1024, sort_hybrid_cap_small = 4096, sort_hybrid_cap_large = 5120;  // radix_local's stretch per workgroup, its width and its LDS capacity in keys (PSM_SORT_TUNE)
+    uint32_t sort_hybrid_s_small = 1024, sort_hybrid_s_large = 2048, sort_hybrid_threads = 1024, sort_hybrid_threads_large = 512, sort_hybrid_cap_small = 4096, sort_hybrid_cap_large = 4096;  // radix_local's stretch per workgroup, its width and its LDS capacity in keys (PSM_SORT_TUNE)
     uint32_t* sort_error_word = nullptr; // device word the look-back raises on a spin timeout
 };
 

@@ -751,15 +751,17 @@ static int sort_hybrid(psm_ctx* c, uint64_t* d_keys, uint32_t* d_vals, size_t n_
     const int pshift = key_bits - 16;
     const bool small = n_max <= (1u << 19);
     int rc = small ? sort_passes<4, 256>(c, d_keys, d_vals, n_max, d_n, pshift, 2)
-                   : sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n, pshift, 2);
+                   : sort_passes<4, 1024>(c, d_keys, d_vals, n_max, d_n, pshift, 2);   // (512- and 256-thread tiles: the same frame time with frames in flight, within the noise)
     if (rc != PSM_OK) return rc;
     // S: the stretch of bin starts a workgroup takes; a chunk fits LDS (CAP keys) while no bin is longer than CAP - S. Small sorts
     // take short stretches (1 024 of 4 096): as many workgroups as the chip has CUs matter more there than keys per workgroup.
-    // Large ones 3 072 of 5 120: a pass costs a workgroup ~5 000 cycles of barriers and LDS round trips whatever the chunk holds
-    // (tools/sort_log.py), so longer chunks are cheaper per key; 5 120 keys are what two workgroups per CU leave room for
-    // (profiles/r05_sort_sweep.txt: C5 0.465 ms with 2 048 of 4 096, 0.408 with 3 072 of 5 120, 0.406 with 4 096 of 6 144 x 512 threads)
+    // Large ones 2 048 of 4 096 with 512-thread workgroups. Alone on the chip longer chunks under wider workgroups are faster -- a pass
+    // costs a workgroup ~5 000 cycles of barriers and LDS round trips whatever the chunk holds (tools/sort_log.py): C5 0.43 ms this way,
+    // 0.41 with 3 072 of 5 120 x 1 024 threads, profiles/r05_sort_sweep.txt -- but a sort shares the chip with the other frames'
+    // one-wave traversal workgroups, and a 16-wave workgroup waits for a CU to empty: C5's frame with 4 frames in flight 11.40 ms this
+    // way against 11.79 (profiles/r05_wg_shapes_in_flight.txt; the sort's launch in that trace: 2.6 ms instead of 0.25 alone)
     const uint32_t S = small ? c->sort_hybrid_s_small : c->sort_hybrid_s_large;
-    const uint32_t cap = small ? c->sort_hybrid_cap_small : c->sort_hybrid_cap_large, threads = c->sort_hybrid_threads;
+    const uint32_t cap = small ? c->sort_hybrid_cap_small : c->sort_hybrid_cap_large, threads = small ? c->sort_hybrid_threads : c->sort_hybrid_threads_large;
     const uint32_t grid = (uint32_t)((n_max + S - 1) / S);
 #define PSM_LOCAL(CAP_, TH_) \
     if (cap == CAP_ && threads == TH_) { \

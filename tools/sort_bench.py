@@ -59,7 +59,7 @@ def bench(ctx, rs, label, keys):
 ALGOS = [int(x) for x in sys.argv[sys.argv.index('--algos') + 1].split(',')] if '--algos' in sys.argv else [0, 1, 2]
 ctx = psm.Context(0)
 rs = psm.RadixSort(ctx)
-print("# PSM_SORT_TUNE=%s" % os.environ.get("PSM_SORT_TUNE", "(default 1024,2048,1024)"))
+print("# PSM_SORT_TUNE=%s" % os.environ.get("PSM_SORT_TUNE", "(default 1024,2048,1024,4096,4096,512)"))
 for n in (() if "--no-uniform" in sys.argv else (262267, 2_000_000, 9_999_616)):
     rng = np.random.RandomState(1)
     keys = (rng.randint(0, 2 ** 62, size=n, dtype=np.int64).astype(np.uint64)) >> np.uint64(1)

@@ -28,7 +28,7 @@ lib.psm_sortlog_set.argtypes = [C.c_void_p]
 for name, sc in (("S-sponza-like", scenes.sponza_like()),) + (() if "--no-stress" in sys.argv else (("S-stress", scenes.stress()),)):
     keys = morton_keys(ctx, sc)
     n = keys.shape[0]
-    S = 1024 if n <= (1 << 19) else 3072
+    S = 1024 if n <= (1 << 19) else 2048
     if os.environ.get("PSM_SORT_TUNE"):
         t = [int(v) for v in os.environ["PSM_SORT_TUNE"].split(",")]
         S = t[0] if n <= (1 << 19) else t[1]
