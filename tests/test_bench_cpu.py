@@ -3,7 +3,7 @@
 The contract (task statement (4)): `achieved` = algorithmic bytes per launch / average launch duration of
 the kernel the timed region launches; `peak` 8000 GB/s; `frac` = achieved / peak; the counters' physical figures lead the
 object; a note whenever SURVEY 8(d)'s bytes per step over ms_per_step pass the peak; PMC figures only where a committed
-pass exists for the workload (profiles/traffic_r04.json)."""
+pass exists for the workload (profiles/traffic_r05.json) and still describes the kernels (its provenance block)."""
 import hashlib
 import importlib
 import json
@@ -94,9 +94,14 @@ def test_replayed_counters_are_flagged_stale_once_a_kernel_source_changes(tmp_pa
 
 
 def test_committed_traffic_file_matches_its_profiles():
-    """profiles/traffic_r04.json (what bench.py quotes) holds the three traversal kernels of C3 and C5 with the fields the
-    roofline uses, and its in-flight launch average agrees with the committed kernel-trace summary of the same run."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json")))
+    """profiles/traffic_r05.json (what bench.py quotes) holds the traversal kernels of C3 and C5 with the fields the roofline
+    uses, its in-flight launch average agrees with the committed kernel-trace summary of the same run, and it names the kernel
+    sources its passes ran with -- which are the sources of this tree (the counters were collected after the last kernel change)."""
+    bench = importlib.import_module("bench")
+    d = json.load(open(os.path.join(ROOT, "profiles", "traffic_r05.json")))
+    assert set(d["provenance"]["sources_sha256"]) == set(bench.KERNEL_SOURCES) and d["provenance"]["commit"]
+    path, prov, stale, why = bench.traffic_provenance()
+    assert os.path.basename(path) == "traffic_r05.json" and not stale, why
     ents = {(e["scene"], e["kernel"]): e for e in d["entries"]}
     for scene in ("sponza_like", "stress"):
         for k in ("psm::rt_traverse<false, false, true>", "psm::rt_traverse<false, false, false>"):
@@ -105,6 +110,6 @@ def test_committed_traffic_file_matches_its_profiles():
             assert 0.3 < e["valu_lane_utilisation"] < 0.7 and e["alone_avg_us"] > 0 and e["sq_per_launch"]["SQ_INSTS_VALU"] > 0
     tag = {"sponza_like": "c3", "stress": "c5"}
     for scene, c in tag.items():
-        rows = [l.split() for l in open(os.path.join(ROOT, "profiles", "r04_%s_kt_stats.txt" % c)) if "false, false, tru" in l]
+        rows = [l.split() for l in open(os.path.join(ROOT, "profiles", "r05_%s_kt_stats.txt" % c)) if "false, false, tru" in l]
         avg_us = float(rows[0][-2])
         assert abs(avg_us - ents[(scene, "psm::rt_traverse<false, false, true>")]["in_flight_avg_us"]) < 0.01 * avg_us

@@ -34,8 +34,8 @@ PY
     IFS=';' read -ra LIST <<< "$CFGS"
     for cfg in "${LIST[@]}"; do
       set -- $cfg
-      line=$(timeout -k 10 300 python bench.py --no-cpu-baseline --no-obj-roundtrip --force-dist --emulate-tile $1 --lanes $2 --band-weights $3 --steps ${TILE_STEPS:-32} --warmup 4 2>> gpurun_out/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.3f ms/frame  %.1f Mrays/s' % (d['ms_per_step'], d['value']))")
-      echo "tile $1 lanes $2 weights $3: $line" | tee -a gpurun_out/$tag.txt
+      line=$(timeout -k 10 300 python bench.py --no-cpu-baseline --no-obj-roundtrip --force-dist --emulate-tile $1 --lanes $2 --band-weights $3 --steps ${TILE_STEPS:-32} --warmup ${TILE_WARMUP:-4} $TILE_EXTRA 2>> gpurun_out/$tag.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.3f ms/frame  %.1f Mrays/s' % (d['ms_per_step'], d['value']))")
+      echo "tile $1 lanes $2 weights $3 steps ${TILE_STEPS:-32} $TILE_EXTRA: $line" | tee -a gpurun_out/$tag.txt
     done ;;
   sweep)   # tools/gpu_session.sh sweep <tag> "<args 1>;<args 2>;..."   one short bench line per argument set
     tag=$1; shift
