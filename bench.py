@@ -874,7 +874,7 @@ def main():
             small = timed_k.get("rounds_below_min_rays_run_single_launch")
             if small and whole_k.get("valu_insts_per_launch") and whole_k["R"]:
                 insts += whole_k["valu_insts_per_launch"] * whole_k["launches"] * (small["R"] / whole_k["R"])
-            e_sh, _ = pmc_entry(args.scene, args.width, args.height, "rt_shade<false, false>")
+            e_sh, _ = pmc_entry(args.scene, args.width, args.height, "rt_shade<false, false, false>")   # TEX, MULTI, BOTH: the texture-less, single-hierarchy, one-lobe instantiation the bench scenes run
             sh = (e_sh or {}).get("sq_per_launch", {}).get("SQ_INSTS_VALU")
             if sh:
                 insts += sh * len(round_log)
