@@ -1,22 +1,22 @@
-// sort.hip -- stable LSD radix sort of (u64 key, u32 value) pairs for gfx950.
+// sort.hip -- stable radix sort of (u64 key, u32 value) pairs for gfx950.
 //
 // Replaces psm::RadixSort::sort (Include/Prismarine/Radix.hpp:47-74) and the shaders it drives
 // (ShadersSDK/radix/{histogram,pfx-work,permute}.comp): 8 passes x 8 bits, ascending, stable,
 // result back in the input buffers.  The reference runs 32 workgroups, three dispatches per pass, and
-// sorts each 256-key block with eight 1-bit ballot splits.  Here:
-//   radix_hist_all   ONE sweep over the keys builds all eight 256-bin digit histograms (8 KB of LDS per
-//                    workgroup, one atomic per non-empty bin at the end): 8 B/key read once, not per pass
-//   radix_onesweep   one launch per pass: a tile of 256*ITEMS keys is ranked with wave64 match-any ballots,
-//                    learns where its digits start by a decoupled look-back over the tiles before it
-//                    (one 32-bit {count | flag} word per tile and digit), is staged through LDS in digit
-//                    order and written out as coalesced runs: 12 B/key read + 12 B/key written per pass
-// = 200 B/key and 10 launches, against 256 B/key and 24 launches for the three-kernel passes
-// (radix_hist / radix_scan / radix_scatter below). Measured on MI355X (tools/sort_bench.py) the
-// three-kernel passes are FASTER at every size -- 0.113 vs 0.146 ms for 262 267 keys, 0.21 vs 0.53 ms for 2 M,
-// 0.77 vs 0.93 ms for 10 M (round 3's tile shapes, pass_tile below): a look-back hop is a ~1 us round trip through L2 across XCDs and the tiles of a pass
-// all start together (the chip holds as many tiles as a pass has), so the look-back chain costs more than the
-// two extra launches and the 8 B/key it saves. The three-kernel pass is therefore the default;
-// psm_sort_set_algorithm(ctx, 1) selects the one-sweep sort, and the parity tests run both.
+// sorts each 256-key block with eight 1-bit ballot splits.  Three implementations, one result (psm_sort_set_algorithm):
+//   2 (default, round 5)  HYBRID: the LSD passes of the top sixteen key bits (radix_hist / radix_scan / radix_scatter, twice),
+//                    then radix_local sorts chunks of whole sixteen-bit bins by the remaining digits in LDS and writes them
+//                    back once -- 7 launches, a key moves through HBM three times (see "the hybrid sort" below)
+//   0                radix_hist / radix_scan / radix_scatter for all eight passes: 24 launches, 256 B/key
+//   1                radix_hist_all: ONE sweep over the keys builds all eight 256-bin digit histograms (8 KB of LDS per
+//                    workgroup, one atomic per non-empty bin at the end): 8 B/key read once, not per pass; then per pass
+//                    radix_onesweep: a tile of 256*ITEMS keys is ranked with wave64 match-any ballots, learns where its
+//                    digits start by a decoupled look-back over the tiles before it (one 32-bit {count | flag} word per tile
+//                    and digit), is staged through LDS in digit order and written out as coalesced runs -- 200 B/key and
+//                    10 launches, and SLOWER than 0 at every size: a look-back hop is a ~1 us round trip through
+//                    L2 across XCDs and the tiles of a pass all start together (the chip holds as many tiles as a pass has)
+// tools/sort_bench.py on MI355X (profiles/r05_sort_bench.txt): 262 267 Morton codes 0.049 / 0.104 / 0.135 ms (hybrid / 0 / 1),
+// 2 M keys 0.104 / 0.178 / 0.515, 10 M Morton codes 0.434 / 0.681 / 0.900. The parity tests run all three.
 //
 // Look-back protocol (cdna_hip_programming.md Guideline 16, "R2 granule"): a status word carries value and
 // flag together and is written by ONE relaxed agent-scope atomic store and read by relaxed agent-scope atomic
