@@ -308,6 +308,41 @@ def test_rebuild_replayed_as_captured_graph_is_bit_exact(psm, ctx, oracle, scene
     th.close()
 
 
+def test_build_of_a_clustered_scene_overflows_the_hybrid_sort_and_falls_back(psm, ctx, oracle, scenes):
+    """A scene whose bounds are set by two far-away outliers while everything else sits in a thousandth of them: its Morton
+    codes share their top bits, a sixteen-bit bin holds thousands of keys, the hybrid sort's chunk does not fit LDS. The build
+    must be bit-exact all the same -- through the workgroup's global-memory path the first time, through the eight-pass sort
+    the context falls back to afterwards, plain and as a re-captured graph -- and psm_sort_get_algorithm must say so."""
+    base = scenes.sponza_like(n_tris=20011)["tris"]
+    lo, hi = base.reshape(-1, 3).min(0), base.reshape(-1, 3).max(0)
+    tris = ((base - lo) * np.float32(0.001) + lo).astype(np.float32)        # the scene, shrunk into a corner of its own bounds
+    tris = np.ascontiguousarray(np.concatenate([tris, base[:2] + (hi - lo) * np.float32(0.9)], 0))   # two triangles far out keep the bounds wide
+    sc = {"tris": tris, "normals": scenes.prepare_normals(tris), "mats": np.zeros(tris.shape[0], np.int32)}
+    ob = oracle.build_scene(tris)
+    top = (ob["keys"] >> np.uint64(47)).astype(np.int64)
+    assert np.bincount(top - top.min()).max() > 4096      # one bin is longer than a chunk's LDS
+    rs = psm.RadixSort(ctx)
+    assert rs.getAlgorithm() == (2, 2)
+    th = _load(psm, ctx, sc)
+    for k in range(4):           # first build: plain launches, hybrid with the slow chunk; then the fallback, then its graph
+        th.markDirty()
+        th.build()
+        _built_equals_oracle(psm, oracle, th, ob)
+        assert rs.getAlgorithm() == (2, 0)
+    th.close()
+    rs.setAlgorithm(2)           # (the fixture does this for the next test anyway)
+    # a well-spread scene on the re-armed context stays hybrid
+    sc2 = scenes.sponza_like(n_tris=20011)
+    th = _load(psm, ctx, sc2)
+    ob2 = oracle.build_scene(sc2["tris"])
+    for k in range(3):
+        th.markDirty()
+        th.build()
+        _built_equals_oracle(psm, oracle, th, ob2)
+    assert rs.getAlgorithm() == (2, 2)
+    th.close()
+
+
 def test_refit_only_keeps_the_tree_and_matches_the_oracle(psm, ctx, oracle, scenes):
     """psm_bvh_refit (refit-only dynamic updates): the triangles of a built hierarchy are reloaded, moved -- the node
     records afterwards are the build's topology with the boxes of oracle.refit (aabbmaker.comp:165-194 + refit.comp:21-114), bit
