@@ -353,7 +353,7 @@ def sharded_self_check(psm, scenes, dist, R):
         elif not want[..., :3].max() > 0.05:
             ok, why = 0, "the check frames are black"
     want_r = [int(v) for v in dist.sum_ints(want_r)]          # rank 0's unsharded rounds per frame, to everybody
-    if ok and rounds is not None and dist.min_int(1) == 1 and [int(v) for v in rounds] != want_r and sum(want_r) > 0:
+    if ok and rounds is not None and sum(want_r) > 0 and [int(v) for v in rounds] != want_r:   # (all zeros: rank 0 had failed before it got there)
         ok, why = 0, "rank %d ran %s rounds per frame, the unsharded frames %s" % (dist.rank, [int(v) for v in rounds], want_r)
     if dist.min_int(ok) == 0:
         if not ok:

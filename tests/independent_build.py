@@ -10,6 +10,7 @@ node of a level gets children base + 2 i, base + 2 i + 1).
 
 leaves(tris, M) -> keys (n,) uint64, boxes (n, 2, 3) float16 [min, max], tri ids (n,)
 tree(sorted_keys, sorted_slots, boxes, tri_ids) -> pdata (2n-1, 4) int32, box_min / box_max (2n-1, 3) float16
+leaf_box(tri, M) -> (2, 3) float16: one triangle's leaf box (a refit-only update: tree() again with the build's keys and new boxes)
 """
 import numpy as np
 
@@ -49,6 +50,15 @@ def leaves(tris, M):
         boxes.append([(mn - PZERO).astype(np.float32).astype(np.float16), (mx + PZERO).astype(np.float32).astype(np.float16)])  # :197-202
         ids.append(t)
     return np.array(keys, np.uint64), np.array(boxes, np.float16).reshape(-1, 2, 3), np.array(ids, np.int32)
+
+
+def leaf_box(tri, M):
+    """calcTriBox + the PZERO pad + packHalf (aabbmaker.comp:38-49,193-202) of ONE triangle: what a refit-only update
+    recomputes for every leaf the build kept (no degeneracy test: that decides what a BUILD keeps)."""
+    v = [transform(M, tri[k]) for k in range(3)]
+    mn = np.minimum(np.minimum(v[0], v[1]), v[2])
+    mx = np.maximum(np.maximum(v[0], v[1]), v[2])
+    return np.array([(mn - PZERO).astype(np.float32).astype(np.float16), (mx + PZERO).astype(np.float32).astype(np.float16)], np.float16)
 
 
 def nlz64(x):
