@@ -316,6 +316,10 @@ __global__ __launch_bounds__(1024) void scan_blocks(uint32_t* __restrict__ g, ui
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
+// (Round 5 also built the leaf compaction as ONE launch with a decoupled look-back -- tile tickets, one {flag | count} word per tile
+// published by a relaxed atomic store, 64 predecessors looked at per step by the tile's first wave: bit-exact, and SLOWER: C3 13 -> 31 us,
+// C5 0.172 -> 0.906 ms. 39 061 tickets and as many exit counts on one address are ~23 ns each through the device-scope atomic path;
+// the second read of the positions the three launches pay for is cheaper. With the release-fence variant above: two ways to lose.)
 // canonical leaf slot `to` = rank among kept triangles in ascending t (SURVEY a-8)
 __global__ __launch_bounds__(256) void bvh_morton_write(const float* __restrict__ pos, uint32_t n,
                                                         const uint32_t* __restrict__ sm,
@@ -423,6 +427,33 @@ __global__ __launch_bounds__(256) void bvh_segtree(uint4* __restrict__ seg, SegL
         if (7 < nvalid && j7 + 1 < ((in_count_max + 127u) >> 7)) seg[lv.off[7] + j7 + 1] = b;
         uint32_t j8 = k >> 8;
         if (8 < nvalid && j8 < ((in_count_max + 255u) >> 8)) seg[lv.off[8] + j8] = box_union(a, b);
+    }
+}
+
+// Levels 9 and up of a tree whose level 8 has at most 4096 entries (up to 2^20 leaves), in ONE workgroup: level 8 -- written by the
+// launch before -- goes to LDS, every further level is the pairwise union of the one below, kept in LDS for the next and written
+// out. (Round 5: bvh_segtree<false> took one launch per eight levels -- two for C3's 18 levels, each a 5-us gap in a 0.14 ms build.)
+struct SegTop {
+    uint32_t off[32];
+};
+__global__ __launch_bounds__(1024) void bvh_segtree_top(uint4* __restrict__ seg, SegTop lv, uint32_t n_max, int nlev) {
+    __shared__ uint4 a[4096];
+    __shared__ uint4 b[2048];
+    uint4* prev = a;
+    uint4* next = b;
+    uint32_t m = (n_max + 255u) >> 8;   // entries of level 8 (upper bound; entries beyond the leaf count hold the identity)
+    for (uint32_t j = threadIdx.x; j < m; j += 1024) prev[j] = seg[lv.off[8] + j];
+    __syncthreads();
+    for (int k = 9; k < nlev; k++) {
+        const uint32_t mk = (m + 1u) >> 1;
+        for (uint32_t j = threadIdx.x; j < mk; j += 1024) {
+            const uint4 v = box_union(prev[2 * j], 2 * j + 1 < m ? prev[2 * j + 1] : box_identity());
+            next[j] = v;
+            seg[lv.off[k] + j] = v;
+        }
+        __syncthreads();
+        uint4* t = prev; prev = next; next = t;   // (the level above is at most half as long: it fits whichever array is free)
+        m = mk;
     }
 }
 
@@ -744,7 +775,8 @@ int launch_bvh_emit(psm_bvh* b) {
     uint32_t n = b->tri_count;  // upper bound of the leaf count
     if (n == 0) return PSM_OK;
     int nlev = (int)b->seg_off.size() - 1;  // levels 0..nlev-1
-    for (int L0 = 0; L0 < nlev; L0 += 8) {
+    const bool top = nlev > 9 && ((n + 255u) >> 8) <= 4096u;   // everything above level 8 in one workgroup
+    for (int L0 = 0; L0 < (top ? 8 : nlev); L0 += 8) {
         SegLevels lv;
         for (int q = 0; q < 9; q++) lv.off[q] = (uint32_t)b->seg_off[(size_t)std::min(L0 + q, nlev)];
         uint32_t in_max = (n + (1u << L0) - 1u) >> L0;
@@ -755,6 +787,11 @@ int launch_bvh_emit(psm_bvh* b) {
         else
             bvh_segtree<false><<<grid, 256, 0, c->stream>>>(b->d_seg, lv, in_max, b->d_small, nullptr, nullptr, nullptr,
                                                             nullptr, L0, nlev - L0);
+    }
+    if (top) {
+        SegTop lv;
+        for (int q = 0; q < 32; q++) lv.off[q] = (uint32_t)b->seg_off[(size_t)std::min(q, nlev)];
+        bvh_segtree_top<<<1, 1024, 0, c->stream>>>(b->d_seg, lv, n, nlev);
     }
     SegTree st;
     st.seg = b->d_seg;
