@@ -91,7 +91,6 @@ int psm_device_count(void) {
 }
 
 static int ctx_create(int device, void* ext_stream, bool use_ext, psm_ctx** out);
-
 int psm_ctx_create(int device, psm_ctx** out) { return ctx_create(device, nullptr, false, out); }
 int psm_ctx_create_on_stream(int device, void* hip_stream, psm_ctx** out) { return ctx_create(device, hip_stream, true, out); }
 
