@@ -473,6 +473,8 @@ typedef struct {
     uint64_t node_visits;     /* V (only counted while counting is enabled) */
     uint64_t tri_tests;       /* T */
     uint64_t stack_drops, iter_caps, baked_drops, chain_pool_drops, ray_limit_drops;
+                              /* chain_pool_drops: equal-distance chains cut to their head because the chain pool (currentRayLimit / 2
+                               * entries beside one head per ray; Pipeline.inl:193) was full */
     uint32_t traverse_launches;
     float traverse_ms;        /* sum of HIP-event durations of the traverse kernel */
     float build_ms, sort_ms, shade_ms, camera_ms, sample_ms;

@@ -205,6 +205,13 @@ def traverse(nodes, tris, M, origins, directs, nthreads=0, want_hits=True):
     hits = np.zeros((n, BAKED_CAP), HIT_DT) if want_hits else None
     counts = np.zeros(n, np.int32)
     ctr = Counters()
+    if nodes.shape[0] == 0:
+        # A build that kept no triangle (a scene flat in an axis: the fit transform divides by a zero extent and aabbmaker.comp:176
+        # drops every box) leaves no tree. The reference returns from build() before it touches the old one (TriangleHierarchy.inl:282)
+        # and would trace that; the product's rule is the defined one: no node, no traversal, no hit.
+        if want_hits:
+            hits["t"], hits["tri"] = INFINITY, -1
+        return hits, counts, ctr
     lib().psmo_traverse_batch(_p(np.ascontiguousarray(nodes)), _p(tris), _p(np.ascontiguousarray(M, np.float32)),
                               _p(origins), _p(directs), C.c_int(n), _p(hits) if want_hits else None,
                               _p(counts), C.byref(ctr), C.c_int(nthreads))
