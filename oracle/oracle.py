@@ -206,9 +206,9 @@ def traverse(nodes, tris, M, origins, directs, nthreads=0, want_hits=True):
     counts = np.zeros(n, np.int32)
     ctr = Counters()
     if nodes.shape[0] == 0:
-        # A build that kept no triangle (a scene flat in an axis: the fit transform divides by a zero extent and aabbmaker.comp:176
-        # drops every box) leaves no tree. The reference returns from build() before it touches the old one (TriangleHierarchy.inl:282)
-        # and would trace that; the product's rule is the defined one: no node, no traversal, no hit.
+        # A build that kept no triangle (a soup of points and needles: every triangle fails aabbmaker.comp:160) leaves no tree. The
+        # reference returns from build() before it touches the old one (TriangleHierarchy.inl:282) and would trace that; the
+        # product's rule is the defined one: no node, no traversal, no hit.
         if want_hits:
             hits["t"], hits["tri"] = INFINITY, -1
         return hits, counts, ctr

@@ -86,17 +86,22 @@ static inline void load_tri_xformed(const float* tris, int t, const float M[16],
 
 /* hlbvh/minmax.comp:50-79 + host reduce TriangleHierarchy.inl:248-255.
  * min/max are exact and order independent; every partial carries the -+1e-5
- * pad (minmax.comp:76-77) so the reduced result is (exact min) - 1e-5f. */
+ * pad (minmax.comp:76-77) so the reduced result is (exact min) - 1e-5f.
+ * The shader reduces in an order of its own (two primitives per thread, a tree in shared memory, a host loop over the
+ * workgroups); for that to have ONE result when a coordinate is NaN -- GLSL leaves min / max of a NaN undefined -- min and max
+ * here are minNum / maxNum, what the v_min_f32 / v_max_f32 of the reference's target hardware compute (and its min3 / max3
+ * path, minmax.comp:30-34): a NaN coordinate is ignored, whatever the order. For every other input the result is the same
+ * as with `y < x ? y : x` (zeros of either sign give the same padded bound). */
 void psmo_minmax(const float* tris, int n, const float M[16], float mn[4], float mx[4]) {
     for (int c = 0; c < 4; c++) { mn[c] = 100000.f; mx[c] = -100000.f; }
     for (int t = 0; t < n; t++) {
         float v[3][4];
         load_tri_xformed(tris, t, M, v);
         for (int c = 0; c < 4; c++) {
-            float lo = pmin(pmin(v[0][c], v[1][c]), v[2][c]);
-            float hi = pmax(pmax(v[0][c], v[1][c]), v[2][c]);
-            mn[c] = pmin(mn[c], lo);
-            mx[c] = pmax(mx[c], hi);
+            float lo = smin(smin(v[0][c], v[1][c]), v[2][c]);
+            float hi = smax(smax(v[0][c], v[1][c]), v[2][c]);
+            mn[c] = smin(mn[c], lo);
+            mx[c] = smax(mx[c], hi);
         }
     }
     for (int c = 0; c < 4; c++) { mn[c] = mn[c] - 0.00001f; mx[c] = mx[c] + 0.00001f; }

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from test_gpu_parity import _built_equals_oracle, _check_build, _hits_equal, _load, _rays_equal, _trace_both
+from test_gpu_parity import _built_equals_oracle, _check_build, _hits_equal, _load, _rays_equal, _select_schedule, _trace_both
 from util import bits
 
 pytestmark = pytest.mark.gpu
@@ -305,3 +305,72 @@ def test_fuzzed_refit_matches_the_oracle(psm, ctx, oracle, scenes, seed):
     th.refit()
     _built_equals_oracle(psm, oracle, th, oracle.refit(ob, moved))
     th.close()
+
+
+def fuzz_schedule(rng):
+    """A traversal schedule psm_rt_set_traverse_mode / _phases / _adaptive / _solo accept, drawn at random."""
+    kind = rng.randint(0, 3)
+    kw = {"solo": int(rng.randint(0, 5))}
+    if kind == 0:
+        return "whole", kw
+    if kind == 1:
+        kw["caps"] = [int(x) for x in rng.randint(1, 60, rng.randint(1, 8))]
+        return "phased", kw
+    kw.update(min_live=int(rng.randint(2, 65)), min_steps=int(rng.randint(0, 40)), final_rays=int(rng.choice([0, 64, 1000, 65536])),
+              max_launches=int(rng.randint(2, 16)))
+    return "adaptive", kw
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_schedules_on_fuzzed_soups(psm, ctx, oracle, scenes, seed):
+    """Every way a ray can be carried through its traversal -- one launch, launches capped at random step counts, hand-over below a
+    random number of live lanes, the solo gear from 0 to 4 rays -- on the soups and their rays (long chains of coplanar duplicates
+    included, which cannot hand over): hits, chains, V, T, drops and caps as the oracle's uninterrupted loop."""
+    tris, origin, direct, tags = fuzz_case(seed)
+    rng = np.random.RandomState(21000 + seed)
+    mode, kw = fuzz_schedule(rng)
+    n, m = tris.shape[0], origin.shape[0]
+    sc = {"tris": tris, "normals": np.zeros_like(tris), "mats": np.zeros(n, np.int32)}
+    sc["normals"][:, :, 1] = 1.0
+    th = _load(psm, ctx, sc)
+    th.build()
+    ob = oracle.build_scene(tris)
+    rays = np.zeros(m, psm.RAY_DT)
+    rays["origin"], rays["direct"], rays["color"] = origin, direct, 1.0
+    rays["bitfield"] = 1 | (3 << 8)
+    rays["texel"] = np.arange(m) % 100
+    rays["pkey"] = np.arange(m)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(128, 128)
+    _select_schedule(rt, mode, kw)
+    rt.upload_rays(rays)
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    assert rt.intersection(th) == 1
+    st = ctx.stats()
+    ctx.stats_enable(False, False)
+    gh, gc = rt.download_hits(m)
+    oh, oc, octr = oracle.traverse(ob["nodes"], tris, ob["M"], origin, direct, 8)
+    assert st.chain_pool_drops == 0
+    _hits_equal(gh, gc, oh, oc)
+    assert (st.node_visits, st.tri_tests, st.stack_drops, st.iter_caps) == (octr.node_visits, octr.tri_tests, octr.stack_drops, octr.iter_caps), (mode, kw, tags)
+    rt.close()
+    th.close()
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_soup_with_non_finite_vertices(psm, ctx, oracle, scenes, seed):
+    """A few vertices at +-infinity or NaN (a broken export): the bounds reduction, the fit transform and aabbmaker's tests meet
+    them in min / max / compare positions whose semantics psm_math.h restates from GLSL as the oracle does. Same bits, stage by stage."""
+    tris, origin, direct, tags = fuzz_case(seed)
+    rng = np.random.RandomState(25000 + seed)
+    n = tris.shape[0]
+    k = max(1, n // 50)
+    bad = rng.choice([np.inf, -np.inf, np.nan], k)
+    tris[rng.randint(0, n, k), rng.randint(0, 3, k), rng.randint(0, 3, k)] = bad.astype(np.float32)
+    sc = {"tris": tris, "normals": np.zeros_like(tris), "mats": np.zeros(n, np.int32)}
+    sc["normals"][:, :, 1] = 1.0
+    _check_build(psm, ctx, oracle, sc)
+    gh, gc, st, oh, oc, octr = _trace_both(psm, ctx, oracle, tris, origin[:1024], direct[:1024])
+    _hits_equal(gh, gc, oh, oc)
+    assert (st.node_visits, st.tri_tests) == (octr.node_visits, octr.tri_tests)
