@@ -241,6 +241,8 @@ def traverse_chain(nodes, tris, M, origins, directs, hits, counts, tri_base, nth
     directs = np.ascontiguousarray(directs, np.float32).reshape(-1, 3)
     assert hits.flags.c_contiguous and counts.flags.c_contiguous and hits.shape == (origins.shape[0], BAKED_CAP)
     ctr = Counters()
+    if nodes.shape[0] == 0:   # no node, no traversal (see traverse): the chains stay as they are
+        return ctr
     lib().psmo_traverse_chain_batch(_p(np.ascontiguousarray(nodes)), _p(tris), _p(np.ascontiguousarray(M, np.float32)),
                                     _p(origins), _p(directs), C.c_int(origins.shape[0]), _p(hits), _p(counts),
                                     C.c_int(tri_base), C.byref(ctr), C.c_int(nthreads))

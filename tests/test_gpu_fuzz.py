@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from test_gpu_parity import _built_equals_oracle, _check_build, _hits_equal, _load, _rays_equal, _select_schedule, _trace_both
+from test_gpu_parity import _built_equals_oracle, _check_build, _global_tri, _hits_equal, _load, _rays_equal, _select_schedule, _trace_both
 from util import bits
 
 pytestmark = pytest.mark.gpu
@@ -163,11 +163,10 @@ def test_fuzzed_soup_with_an_optimisation_matrix(psm, ctx, oracle, scenes, seed)
     th.close()
 
 
-@pytest.mark.parametrize("seed", _seeds())
-def test_fuzzed_frames_shade_like_the_oracle(psm, ctx, oracle, scenes, seed):
-    """Whole bounce rounds on the soups: random materials (black, brighter than 1, rough to mirror, dielectric to full metal, some
-    emissive), normals that are the face's, random unit vectors or zero (loader.comp:119-128 falls back), a ragged image size.
-    Hit chains and the next round's ray queue slot for slot bit for bit, deposit counts exactly, sums to float-atomic order."""
+def fuzz_scene(seed, scenes):
+    """A renderable scene of one seed -- a `visible` soup, random materials (black, brighter than 1, rough to mirror, dielectric to full
+    metal, some emissive), normals that are the face's, random unit vectors or zero (loader.comp:119-128 falls back), in four of ten
+    cases textures in random parts over texcoords far outside 0..1, a camera that looks at a triangle -- and a ragged image size."""
     tris, _, _, tags = fuzz_case(seed, visible=True)
     rng = np.random.RandomState(9000 + seed)
     n = tris.shape[0]
@@ -180,6 +179,15 @@ def test_fuzzed_frames_shade_like_the_oracle(psm, ctx, oracle, scenes, seed):
         em = tuple(float(x) for x in rng.uniform(0, 8, 3)) if rng.rand() < 0.25 else (0.0, 0.0, 0.0)
         materials.append({"diffuse": d + (1.0,), "specular": (0.0, rough, metal, 0.0), "emissive": em + (1.0,)})
     mats = rng.randint(0, nk, n).astype(np.int32)
+    texcoords = textures = None
+    if rng.rand() < 0.4:   # any texture in any part (a height map as an albedo, an albedo as a normal map), texcoords far outside 0..1
+        textures = scenes.procedural_textures()
+        texcoords = np.ascontiguousarray((rng.uniform(-1, 1, (n, 3, 2)) * 10.0 ** rng.uniform(-1, 1.5)).astype(np.float32))
+        for mm in materials:
+            for part in ("diffusePart", "specularPart", "bumpPart", "emissivePart"):
+                if rng.rand() < 0.5:
+                    mm[part] = int(rng.randint(1, 6))
+        tags.append("tex")
     kind = rng.randint(0, 3)
     if kind == 0:
         normals = scenes.prepare_normals(tris)
@@ -194,8 +202,20 @@ def test_fuzzed_frames_shade_like_the_oracle(psm, ctx, oracle, scenes, seed):
     away = rng.normal(0, 1, 3)
     away /= np.linalg.norm(away)
     eye = (centre + away * np.linalg.norm(span) * rng.uniform(0.2, 2.0)).astype(np.float32)   # ... from inside or outside the soup
-    scene = {"tris": tris, "normals": normals, "mats": mats, "materials": materials, "eye": eye, "view": centre}
+    scene = {"tris": tris, "normals": normals, "mats": mats, "materials": materials, "eye": eye, "view": centre, "texcoords": texcoords}
     w, h = int(rng.randint(17, 120)), int(rng.randint(9, 80))
+    scene["textures"] = textures
+    scene["name"] = "fuzz%d" % seed
+    return scene, w, h, tags
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_frames_shade_like_the_oracle(psm, ctx, oracle, scenes, seed):
+    """Whole bounce rounds on the soups: random materials (black, brighter than 1, rough to mirror, dielectric to full metal, some
+    emissive), normals that are the face's, random unit vectors or zero (loader.comp:119-128 falls back), a ragged image size.
+    Hit chains and the next round's ray queue slot for slot bit for bit, deposit counts exactly, sums to float-atomic order."""
+    scene, w, h, tags = fuzz_scene(seed, scenes)
+    tris, normals, mats, materials, texcoords, textures = (scene[k] for k in ("tris", "normals", "mats", "materials", "texcoords", "textures"))
     th = _load(psm, ctx, scene)
     th.build()
     rt = psm.Pipeline(ctx)
@@ -204,10 +224,17 @@ def test_fuzzed_frames_shade_like_the_oracle(psm, ctx, oracle, scenes, seed):
     ms = psm.MaterialSet()
     for mm in materials:
         ms.addSubmat(mm)
+    if textures:
+        ts = psm.TextureSet()
+        for slot in sorted(textures):
+            assert ts.loadTexture(textures[slot]) == slot
+        ms.setTextureSet(ts)
     cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
     ob = oracle.build_scene(tris)
     marr = scenes.materials_array(materials)
     cfg = oracle.make_cfg(w, h, material_count=len(marr))
+    if textures:
+        oracle.set_textures(cfg, texcoords, textures)
     lights = oracle.default_lights(1)
     rt.camera_matrices(cam[0], cam[1], time=seed)
     orays, ocoord, osum, oflag = oracle.camera(cfg, cam[0], cam[1], seed)
@@ -374,3 +401,256 @@ def test_fuzzed_soup_with_non_finite_vertices(psm, ctx, oracle, scenes, seed):
     gh, gc, st, oh, oc, octr = _trace_both(psm, ctx, oracle, tris, origin[:1024], direct[:1024])
     _hits_equal(gh, gc, oh, oc)
     assert (st.node_visits, st.tri_tests) == (octr.node_visits, octr.tri_tests)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_soup_cut_into_chained_hierarchies(psm, ctx, oracle, scenes, seed):
+    """SURVEY f4, multi-BVH: the soup cut into two to four hierarchies (the last one repeating triangles of the others: equal-distance
+    hits that come from different hierarchies), intersection() called once per hierarchy over the same rays, each under a random
+    schedule -- the chain after every call as oracle.traverse_chain's (directTraverse.comp:219-249, 335-346)."""
+    tris, origin, direct, tags = fuzz_case(seed)
+    rng = np.random.RandomState(29000 + seed)
+    n = tris.shape[0]
+    if n < 8:
+        return
+    dup = rng.randint(0, n, max(1, n // 6))
+    tris = np.ascontiguousarray(np.concatenate([tris, tris[dup]]))
+    k = int(rng.randint(2, 5))
+    cuts = np.sort(rng.choice(np.arange(1, n), k - 2, replace=False)) if k > 2 else np.zeros(0, np.int64)
+    edges = [0] + [int(c) for c in cuts] + [n, n + dup.size]
+    parts = [np.arange(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+    ths, obs = [], []
+    for ix in parts:
+        sc = {"tris": np.ascontiguousarray(tris[ix]), "normals": np.zeros((ix.size, 3, 3), np.float32), "mats": np.zeros(ix.size, np.int32)}
+        sc["normals"][:, :, 1] = 1.0
+        th = _load(psm, ctx, sc)
+        th.build()
+        ths.append(th)
+        obs.append(oracle.build_scene(sc["tris"]))
+    m = origin.shape[0]
+    rays = np.zeros(m, psm.RAY_DT)
+    rays["origin"], rays["direct"], rays["color"] = origin, direct, 1.0
+    rays["bitfield"] = 1 | (3 << 8)
+    rays["texel"] = np.arange(m) % 100
+    rays["pkey"] = np.arange(m)
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(128, 128)
+    rt.upload_rays(rays)
+    oh, oc = None, None
+    for j, ix in enumerate(parts):
+        _select_schedule(rt, *fuzz_schedule(rng))
+        ctx.stats_enable(False, True)
+        ctx.stats_reset()
+        rt.intersection(ths[j])
+        drops = ctx.stats().chain_pool_drops
+        ctx.stats_enable(False, False)
+        if j == 0:
+            oh, oc, _ = oracle.traverse(obs[0]["nodes"], tris[ix], obs[0]["M"], origin, direct, 8)
+        else:
+            oracle.traverse_chain(obs[j]["nodes"], np.ascontiguousarray(tris[ix]), obs[j]["M"], origin, direct, oh, oc, int(ix[0]), 8)
+        gh, gc = rt.download_hits(m)
+        if drops:   # the chain pool is full (every call of a round allocates its chains anew): cut chains keep their head, see the frames test
+            cut = (gc == 1) & (oc > 1)
+            assert int(cut.sum()) == drops
+            _hits_equal(_global_tri(gh, gc, parts), gc, oh, np.where(cut, 1, oc))
+            break
+        _hits_equal(_global_tri(gh, gc, parts), gc, oh, oc)
+    rt.close()
+    for th in ths:
+        th.close()
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_frames_on_lanes_equal_the_oracles_frames(psm, oracle, scenes, seed):
+    """psm_lanes_render under random conditions -- 1..5 lanes, 1..9 frames, depth 1..16, with and without the rebuild per frame -- on
+    the fuzzed scenes: the accumulated image, the deposit counts and the rounds and rays of every frame as the same frames rendered one
+    after another by the oracle."""
+    scene, w, h, tags = fuzz_scene(seed, scenes)
+    rng = np.random.RandomState(33000 + seed)
+    lanes, frames = int(rng.randint(1, 6)), int(rng.randint(1, 10))
+    depth, rebuild = int(rng.choice([1, 2, 3, 16])), bool(rng.rand() < 0.7)
+    w, h = min(w, 64), min(h, 48)
+    batch = psm.FrameBatch(lanes, w, h, seed=seed + 5)
+    batch.allocate(scene["tris"].shape[0])
+    batch.loadTriangles(scene["tris"], scene["normals"], scene["mats"], scene["texcoords"])
+    ms = psm.MaterialSet()
+    for mm in scene["materials"]:
+        ms.addSubmat(mm)
+    if scene["textures"]:
+        ts = psm.TextureSet()
+        for slot in sorted(scene["textures"]):
+            ts.loadTexture(scene["textures"][slot])
+        ms.setTextureSet(ts)
+    batch.applyMaterials(ms)
+    if not rebuild:
+        for ln in batch.lanes:
+            ln.th.build()
+    for ln in batch.lanes:
+        ln.ctx.stats_enable(False, True)
+        ln.ctx.stats_reset()
+    per_frame = batch.render(frames, scene["eye"], scene["view"], depth=depth, rebuild=rebuild)
+    img = batch.snapHdr()
+    if sum(ln.ctx.stats().chain_pool_drops for ln in batch.lanes):   # a full chain pool cuts chains (frames test): which ones is a matter of timing
+        batch.close()
+        return
+    sc = dict(scene)
+    if not sc["textures"]:
+        sc.pop("textures")
+        sc.pop("texcoords")
+    ref, st = oracle.render_frames(sc, w, h, frames=frames, seed=seed + 5, depth=depth, frame_streams=True)
+    fin = np.isfinite(ref[..., :3])
+    assert np.array_equal(np.isfinite(img[..., :3]), fin)
+    np.testing.assert_allclose(img[..., :3][fin], ref[..., :3][fin], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    assert len(per_frame) == frames
+    assert sum(r for _, r in per_frame) == st["rays"] and sum(k for k, _ in per_frame) == len(st["rounds"]), (lanes, frames, depth, rebuild, tags)
+    batch.close()
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_tile_sharding_equals_the_whole_frame(psm, ctx, oracle, scenes, seed):
+    """SURVEY 8(e) on the fuzzed scenes: the frame dealt in 8-row bands over 2..6 ranks under random band weights (ranks without a
+    band included), every rank's camera queue as the oracle's, the bounce loop in lock step on the global ray count, the tiles
+    gathered into one rank's pipeline (psm_dist_gather_tiles' one launch over the ranks' dense tiles): the unsharded frame's sums
+    to float-atomic order, its deposit counts exactly."""
+    import importlib
+    pdist = importlib.import_module("prismarine-core_amd.dist")
+    scene, w, h, tags = fuzz_scene(seed, scenes)
+    rng = np.random.RandomState(37000 + seed)
+    world = int(rng.randint(2, 7))
+    weights = None if rng.rand() < 0.4 else [int(x) for x in rng.randint(0, 4, world)]
+    if weights is not None and sum(weights) == 0:
+        weights[int(rng.randint(0, world))] = 1
+    root = int(rng.randint(0, world))
+    th = _load(psm, ctx, scene)
+    th.build()
+    ms = psm.MaterialSet()
+    for mm in scene["materials"]:
+        ms.addSubmat(mm)
+    if scene["textures"]:
+        ts = psm.TextureSet()
+        for slot in sorted(scene["textures"]):
+            ts.loadTexture(scene["textures"][slot])
+        ms.setTextureSet(ts)
+    cam = scenes.camera_matrices(scene["eye"], scene["view"], w, h)
+    cfg = oracle.make_cfg(w, h, material_count=len(scene["materials"]))
+
+    def lockstep(pipes):
+        gens = [psm.sharded_rounds(rt, th, ms, depth=4) for rt in pipes]
+        local = [next(g) for g in gens]
+        alive = [True] * len(gens)
+        while any(alive):
+            total = sum(local)
+            for i, g in enumerate(gens):
+                if alive[i]:
+                    try:
+                        local[i] = g.send(total)
+                    except StopIteration:
+                        alive[i] = False
+
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    full = psm.Pipeline(ctx, seed=seed + 1)
+    full.resizeBuffers(w, h)
+    full.resize(w, h)
+    full.camera_matrices(cam[0], cam[1])
+    lockstep([full])
+    want, _, _ = full.download_texels()
+    pipes = []
+    for r in range(world):
+        rt = psm.Pipeline(ctx, seed=seed + 1)
+        rt.resizeBuffers(w, h)
+        rt.resize(w, h)
+        rt.setTileInterleaved(r, world, weights)
+        assert rt.tile_texels() == pdist.owned_texels(r, world, w, h, weights)
+        rt.camera_matrices(cam[0], cam[1], time=None)
+        pipes.append(rt)
+    t0, _ = oracle.rand_next(seed + 1)
+    for r, rt in enumerate(pipes):
+        orays, *_ = oracle.camera_interleaved(cfg, cam[0], cam[1], t0, r, world, weights)
+        _rays_equal(rt.download_rays(), orays)
+    assert sum(rt.tile_texels() for rt in pipes) == w * h
+    lockstep(pipes)
+    drops = ctx.stats().chain_pool_drops
+    ctx.stats_enable(False, False)
+    if not drops:   # (a full chain pool cuts chains by timing: frames test)
+        per = pdist.largest_tile_texels(world, w, h, weights) * 16
+        hall = ctx.buf_alloc(per * world)
+        pall, _ = ctx.buf_ptr(hall)
+        for r in range(world):
+            pipes[r].pack_texels_dev(pall + r * per)
+        pipes[root].unpack_tiles_dev(world, root, pall, per // 4)
+        got, _, _ = pipes[root].download_texels()
+        fin = np.isfinite(want[:, :3])
+        assert np.array_equal(np.isfinite(got[:, :3]), fin)
+        np.testing.assert_allclose(got[:, :3][fin], want[:, :3][fin], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(got[:, 3], want[:, 3])
+        ctx.buf_free(hall)
+    for rt in pipes + [full]:
+        rt.close()
+    th.close()
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fuzzed_viewer_frames_with_lights_sky_and_sampling(psm, ctx, oracle, scenes, seed):
+    """Whole frames the way the viewer renders them (Viewer.cpp:296-312) under random settings: one to three spherical lights of
+    random place, size and colour (one of them below the horizon now and then), an equirect sky of random texels, the 360-degree
+    camera, a ray grid up to twice the window (sampler.comp:37-97), a depth limit, one to three accumulated frames. The display image
+    within 1e-4 of the oracle's, its sample counts exactly."""
+    scene, w, h, tags = fuzz_scene(seed, scenes)
+    rng = np.random.RandomState(41000 + seed)
+    frames, depth = int(rng.randint(1, 4)), int(rng.choice([1, 2, 4, 16]))
+    ss = int(rng.choice([1, 1, 2]))
+    dw, dh = min(w, 72), min(h, 48)
+    gw, gh = dw * ss, dh * ss
+    L = oracle.default_lights(int(rng.randint(1, 4)))
+    for i in range(L.shape[0]):
+        if i > 0 or rng.rand() < 0.5:
+            v = rng.normal(0, 1, 3)
+            L[i]["lightVector"] = (v[0], v[1], v[2], float(10.0 ** rng.uniform(0.5, 3)))
+            L[i]["lightColor"] = tuple(float(x) for x in rng.uniform(0, 200, 3)) + (float(rng.uniform(0.5, 50)),)
+            L[i]["lightOffset"] = tuple(float(x) for x in rng.uniform(-0.5, 0.5, 3)) + (0.0,)
+            L[i]["lightAmbient"] = tuple(float(x) for x in rng.uniform(0, 0.1, 3)) + (0.0,)
+    sky = rng.randint(0, 256, (int(rng.randint(1, 40)), int(rng.randint(1, 70)), 4)).astype(np.uint8) if rng.rand() < 0.4 else None
+    mode360 = rng.rand() < 0.25
+    th = _load(psm, ctx, scene)
+    th.build()
+    rt = psm.Pipeline(ctx)
+    rt.resizeBuffers(gw, gh)
+    rt.resize(dw, dh)
+    ms = psm.MaterialSet()
+    for mm in scene["materials"]:
+        ms.addSubmat(mm)
+    if scene["textures"]:
+        ts = psm.TextureSet()
+        for slot in sorted(scene["textures"]):
+            ts.loadTexture(scene["textures"][slot])
+        ms.setTextureSet(ts)
+    rt.setLights(L)
+    if sky is not None:
+        rt.setSkybox(sky)
+    if mode360:
+        rt.switchMode()
+    rt.setSeed(seed + 11)
+    ctx.stats_enable(False, True)
+    ctx.stats_reset()
+    for _ in range(frames):
+        psm.render_frame(rt, th, ms, scene["eye"], scene["view"], depth=depth)
+    drops = ctx.stats().chain_pool_drops
+    ctx.stats_enable(False, False)
+    img = rt.snapHdr()
+    assert img.shape == (dh, dw, 4)
+    if not drops:
+        sc = dict(scene)
+        if not sc["textures"]:
+            sc.pop("textures")
+            sc.pop("texcoords")
+        ref, st = oracle.render_frames(sc, gw, gh, frames=frames, seed=seed + 11, depth=depth, lights=L, skybox=sky, display=(dw, dh), enable360=mode360)
+        fin = np.isfinite(ref[..., :3])
+        assert np.array_equal(np.isfinite(img[..., :3]), fin)
+        np.testing.assert_allclose(img[..., :3][fin], ref[..., :3][fin], rtol=1e-4, atol=1e-5)
+        assert np.array_equal(img[..., 3], ref[..., 3])
+    if sky is not None:
+        rt.setSkybox(None)
+    rt.close()
+    th.close()
