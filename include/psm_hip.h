@@ -337,7 +337,9 @@ typedef struct {
 int psm_rt_download_rays(psm_rt* rt, psm_ray* dst, uint32_t max_rays, uint32_t* count);
 /* hits: max_rays*8 entries (chain of ray i at [8*i, 8*i+counts[i])) */
 int psm_rt_download_hits(psm_rt* rt, psm_hit* hits, int32_t* counts, uint32_t max_rays);
-/* replace the current ray queue (host pointer) -- lets tests drive traverse with chosen rays */
+/* replace the current ray queue (host pointer) -- lets tests drive traverse with chosen rays. count <= currentRayLimit
+ * (PSM_ERR_CAPACITY); every ray's texel must lie inside the ray grid, 0 <= texel < w * h (PSM_ERR_INVALID): shading deposits
+ * a ray's radiance into the texel it names */
 int psm_rt_upload_rays(psm_rt* rt, const psm_ray* src, uint32_t count);
 int psm_rt_download_texels(psm_rt* rt, float* sum_rgba, float* coord_xy, int32_t* flags);
 

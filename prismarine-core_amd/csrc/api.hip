@@ -1038,6 +1038,10 @@ int psm_rt_upload_rays(psm_rt* r, const psm_ray* src, uint32_t count) {
     (void)hipSetDevice(c->device);
     if (!r->qA[0]) return set_err(c, PSM_ERR_STATE, "upload_rays before resizeBuffers");
     if (count > r->limit) return set_err(c, PSM_ERR_CAPACITY, "upload_rays: exceeds currentRayLimit");
+    // a ray deposits its radiance into the texel it names (rt_shade: _collect): one outside the grid would write past the texel arrays
+    for (uint32_t i = 0; i < count; i++)
+        if (src[i].texel < 0 || (uint64_t)src[i].texel >= (uint64_t)r->w * r->h)
+            return set_err(c, PSM_ERR_INVALID, "upload_rays: a ray's texel lies outside the ray grid");
     std::vector<float4> A(count), B(count), C(count);
     for (uint32_t i = 0; i < count; i++) {
         A[i].x = src[i].origin[0]; A[i].y = src[i].origin[1]; A[i].z = src[i].origin[2];

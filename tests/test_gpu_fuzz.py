@@ -278,7 +278,7 @@ def test_fuzzed_frames_shade_like_the_oracle(psm, ctx, oracle, scenes, seed):
 
 @pytest.mark.parametrize("seed", _seeds())
 def test_fuzzed_keys_sort_stably(psm, ctx, oracle, seed):
-    """The hybrid sort against numpy's stable order on keys whose sixteen-bit bins are as uneven as a generator can make them:
+    """The three sorts (mostly the hybrid one) against numpy's stable order on keys whose sixteen-bit bins are as uneven as a generator can make them:
     a few bins hold most keys (some longer than a chunk's LDS: the slow path and the fall-back), the rest are sparse; runs of equal
     keys; keys that differ in one digit only; 63- and 64-bit keys."""
     rng = np.random.RandomState(13000 + seed)
@@ -296,6 +296,7 @@ def test_fuzzed_keys_sort_stably(psm, ctx, oracle, seed):
     keys = (hi << np.uint64(48 if rng.rand() < 0.5 else 47)) | low
     vals = rng.permutation(n).astype(np.uint32)
     rs = psm.RadixSort(ctx)
+    rs.setAlgorithm(int(rng.choice([0, 1, 2, 2])))     # eight passes, one-sweep, hybrid
     try:
         gk, gv = rs.sort_arrays(keys, vals)
     finally:

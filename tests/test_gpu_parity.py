@@ -1651,6 +1651,15 @@ def test_errors_are_reported(psm, ctx):
     rt = psm.Pipeline(ctx)
     with pytest.raises(psm.PsmError):
         ctx.check(psm.lib().psm_rt_traverse(rt._h, th._h), "traverse before build")
+    rt.resizeBuffers(16, 8)
+    rays = np.zeros(4, psm.RAY_DT)
+    rays["direct"], rays["bitfield"] = 1.0, 1 | (3 << 8)
+    for bad in (16 * 8, -1, 2 ** 31 - 1):     # a ray deposits into the texel it names: one outside the grid is refused at the door
+        rays["texel"][2] = bad
+        with pytest.raises(psm.PsmError):
+            rt.upload_rays(rays)
+    rays["texel"][2] = 16 * 8 - 1
+    rt.upload_rays(rays)
     rt.close()
     th.close()
     big = psm.TriangleHierarchy(ctx)
