@@ -28,7 +28,7 @@ def _seeds():
     return list(range(16))
 
 
-def fuzz_case(seed, visible=False):
+def fuzz_case(seed, visible=False, big=False):
     """(tris float32 [n, 3, 3], origin [m, 3], direct [m, 3], tags) of one seed. `visible`: a soup a camera sees something of --
     hundreds of triangles or more, each a few per cent of the box, scales within what INFINITY = 10000 (constants.glsl:82) lets hit."""
     rng = np.random.RandomState(1000 + seed)
@@ -40,6 +40,9 @@ def fuzz_case(seed, visible=False):
         n = int(rng.choice([257, 1000, 4099]))
         extent = np.float32(10.0) ** rng.uniform(-0.5, 0.5, 3).astype(np.float32)
         size = np.float32(10.0) ** np.float32(rng.uniform(-1.3, -0.4))
+    if big:   # many workgroups, sort tiles and segment-tree levels: runs of equal codes that span them, bins longer than a chunk
+        n = int(rng.choice([200003, 524288, 1000003]))
+        size = np.float32(10.0) ** np.float32(rng.uniform(-3.5, -1.5))
     centre = rng.uniform(-1, 1, (n, 1, 3)).astype(np.float32)
     if rng.rand() < 0.3:                                                              # clustered: most triangles in a few clumps
         k = rng.randint(1, 6)
@@ -655,3 +658,26 @@ def test_fuzzed_viewer_frames_with_lights_sky_and_sampling(psm, ctx, oracle, sce
         rt.setSkybox(None)
     rt.close()
     th.close()
+
+
+def _big_seeds():
+    spec = os.environ.get("PSM_FUZZ_BIG_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(4))
+
+
+@pytest.mark.parametrize("seed", _big_seeds())
+def test_fuzzed_big_soups(psm, ctx, oracle, scenes, seed):
+    """The soups at 200 003 .. 1 000 003 triangles: hundreds of workgroups per kernel, hundreds of sort tiles and LDS chunks, segment
+    trees twenty levels deep -- with the grid, duplicate and cluster pathologies that make runs of equal Morton codes span them and
+    push the hybrid sort into its slow path. Every build stage bit for bit, then the rays."""
+    tris, origin, direct, tags = fuzz_case(seed + 100000, big=True)
+    n = tris.shape[0]
+    sc = {"tris": tris, "normals": np.zeros_like(tris), "mats": np.zeros(n, np.int32)}
+    sc["normals"][:, :, 1] = 1.0
+    _check_build(psm, ctx, oracle, sc)
+    gh, gc, st, oh, oc, octr = _trace_both(psm, ctx, oracle, tris, origin, direct)
+    _hits_equal(gh, gc, oh, oc)
+    assert (st.node_visits, st.tri_tests, st.stack_drops, st.iter_caps) == (octr.node_visits, octr.tri_tests, octr.stack_drops, octr.iter_caps), tags
