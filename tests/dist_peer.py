@@ -33,6 +33,11 @@ def make_scene(scenes, cfg):
         return scenes.sponza_like()
     if name == "stress":        # BASELINE C5's scene: S-stress, 9 999 616 triangles
         return scenes.stress()
+    if name.startswith("fuzz:"):   # tests/test_gpu_fuzz.py's scene of that seed, without its textures (the ranks load none)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sc, _, _, _ = importlib.import_module("test_gpu_fuzz").fuzz_scene(int(name[5:]), scenes)
+        sc["materials"] = [{k: v for k, v in m.items() if not k.endswith("Part")} for m in sc["materials"]]
+        return sc
     raise KeyError(name)
 
 
