@@ -355,6 +355,7 @@ __global__ __launch_bounds__(TRAV_BLOCK, 8) void rt_traverse(TravArgs ka) {
     __shared__ int stack[STACK_CAP][TRAV_BLOCK];
     __shared__ uint32_t xch[TRAV_BLOCK / 64][SOLO_MAX][XCH_WORDS];   // solo_ray: rays on their way from their lanes to the wave
     const int tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < TRAV_BLOCK);   // (the launch bound does not tell the optimiser: with one wave per workgroup `tid & ~63` is 0 and `tid >> 6` is 0 -- a register and a spill less)
     const bool resume = PHASED && ph.in_count != nullptr;
     const uint32_t total = resume ? *ph.in_count : nrays;
     // with few rays left there is nothing to pack them with: the launch finishes them

@@ -51,9 +51,9 @@ def test_traversal_step_stays_lean_and_out_of_scratch(tmp_path):
         blk = meta[meta.index(".name:           " + kern):]
         blk = blk[:blk.index(".wavefront_size")]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 64, kern
-        # (the hand-over kernel parks two vector registers of its prologue in scratch -- stored before the batch loop, reloaded in a
-        # batch's set-up and in the hand-over's write-out; the step itself has no scratch access: `mem == 4` above)
-        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) <= (2 if "ILb0ELb0ELb1E" in kern else 0), kern
+        # (round 4's hand-over kernel parked two vector registers of its prologue in scratch; one of them was `tid & ~63`, which is 0
+        # with one wave per workgroup -- the launch bound did not tell the optimiser, a __builtin_assume does: no spill in either kernel)
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, kern
         # (one scalar of the hand-over kernel's prologue is parked in a vector lane since the solo gear came: lines 105 / 244 of
         # its assembly, long before the loop; the walk above would count a reload inside the step)
         assert int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1)) <= 1, kern
