@@ -44,6 +44,11 @@ def leaves(tris, M):
             continue
         mn = np.minimum(np.minimum(v[0], v[1]), v[2])                           # calcTriBox, :38-49
         mx = np.maximum(np.maximum(v[0], v[1]), v[2])
+        # :176, greaterEqualF(branges, 0) = (range - 0) > -PZERO (mathlib.glsl:12) on all three axes: true for every finite box, false
+        # for a NaN one (a singular fit transform: a scene so flat, so far out, that its padded extent rounds to zero). Round 5's
+        # fuzzer found this reading without the test (tests/test_oracle_cpu.py::test_fuzzed_soups_oracle_against_the_independent_readings)
+        if not all(F(F(mx[k] - mn[k]) - F(0.0)) > -PZERO for k in range(3)):
+            continue
         q = np.floor(np.clip(c, F(0.0), F(0.99999)).astype(np.float32) * F(2097152.0))     # :187-189
         q = np.clip(q.astype(np.int64), 0, 0x1FFFFF)
         keys.append(morton3(q[0], q[1], q[2]))
