@@ -315,8 +315,11 @@ def shade_round(tris, normals, tri_mats, materials, mat_offset, lights, sky, tim
             ray.set(BASIS, 0)
         # reclaim the current ray (:235-251): storeRay deposits, addRayToList queues
         bounce = ray.get(BOUNCE) - 1
-        ray.final = np.maximum(ray.final, F(0.0))
-        ray.color = np.maximum(ray.color, F(0.0))
+        # max(vec3(0.0f), v): GLSL's max(x, y) is `x < y ? y : x`, so a NaN component of v gives x = 0 -- numpy's maximum would hand the NaN
+        # on and the ray would stay active with a NaN colour (round 5: the fuzzer's black full-metal surfaces,
+        # tests/test_oracle_cpu.py::test_fuzzed_scenes_shade_against_the_independent_reading)
+        ray.final = np.where(F(0.0) < ray.final, ray.final, F(0.0)).astype(np.float32)
+        ray.color = np.where(F(0.0) < ray.color, ray.color, F(0.0)).astype(np.float32)
         if bounce < 0 or mlength(ray.color) < F(0.0001) or n == 0:
             ray.set(ACT, 0)
         ray.set(BOUNCE, bounce if bounce >= 0 else 0)
